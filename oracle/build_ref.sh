@@ -1,0 +1,41 @@
+#!/bin/bash
+# oracle/build_ref.sh -- TEST INFRASTRUCTURE ONLY.
+#
+# Builds the *pristine reference* CPU path (Cpp/Source/Test.cpp + Maths.cpp + vendored enkiTS)
+# from the sources where they lie under /root/reference into oracle/_ref/ (git-ignored, but it
+# travels to the GPU box).  Nothing from /root/reference is copied into the repo: Test.cpp is
+# streamed through sed to the compiler's stdin only to turn the compile-time macro
+# DO_SAMPLES_PER_PIXEL (Config.h:22) into the runtime variable g_tpt_ref_spp (ref_shim.cpp); every
+# other line is compiled as is.  With g_tpt_ref_spp == 4 the build is the reference as shipped.
+#
+#   libtpt_ref.so       oracle flags : -O2 -msse4.1 -ffp-contract=off       (bit-stable; the pin)
+#   libtpt_ref_fast.so  "as shipped" : -O3 -ffast-math -mavx2 -mfma (≈ -march=native, portable to the GPU box host; mirrors /fp:fast, GCC_FAST_MATH)
+#
+# -include string.h : Test.cpp:379 uses memcpy without including <string.h>.
+# -msse4.1          : MathSimd.h:17 includes <smmintrin.h>.
+set -e
+REF=${TPT_REFERENCE_DIR:-/root/reference}
+S=$REF/Cpp/Source
+HERE=$(cd "$(dirname "$0")" && pwd)
+OUT=$HERE/_ref
+if [ ! -f "$S/Test.cpp" ]; then
+    echo "build_ref.sh: reference sources not found under $S (expected on the GPU box); keeping prebuilt files" >&2
+    exit 0
+fi
+mkdir -p "$OUT"
+TMP=$(mktemp -d)
+trap 'rm -rf "$TMP"' EXIT
+build() {  # name, flags...
+    local name=$1; shift
+    local common="-std=c++11 -fPIC -DNDEBUG -Wno-attributes -include string.h -I$S"
+    ( cd "$TMP" && sed '/#include <atomic>/a #undef DO_SAMPLES_PER_PIXEL\n#define DO_SAMPLES_PER_PIXEL g_tpt_ref_spp\nextern int g_tpt_ref_spp;' "$S/Test.cpp" \
+        | g++ $common "$@" -x c++ -c - -o "$TMP/$name.Test.o" )
+    g++ $common "$@" -c "$S/Maths.cpp" -o "$TMP/$name.Maths.o"
+    g++ $common "$@" -c "$S/enkiTS/TaskScheduler.cpp" -o "$TMP/$name.ts.o"
+    g++ $common "$@" -c "$S/enkiTS/TaskScheduler_c.cpp" -o "$TMP/$name.tsc.o"
+    g++ $common "$@" -c "$HERE/ref_shim.cpp" -o "$TMP/$name.shim.o"
+    g++ -shared -o "$OUT/$name.so" "$TMP/$name.Test.o" "$TMP/$name.Maths.o" "$TMP/$name.ts.o" "$TMP/$name.tsc.o" "$TMP/$name.shim.o" -lpthread
+}
+build libtpt_ref      -O2 -msse4.1 -ffp-contract=off
+build libtpt_ref_fast -O3 -msse4.1 -mavx2 -mfma -ffast-math
+echo "built $OUT/libtpt_ref.so $OUT/libtpt_ref_fast.so"

@@ -1,0 +1,80 @@
+/* oracle/tpt_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C) of the reference's Trace/HitWorld/Scatter hot path
+ * (/root/reference/Cpp/Source/Test.cpp, Maths.cpp, Maths.h).  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load this; the product (toypathtracer_amd/, include/) never
+ * does.  See oracle/README.md for how it is pinned against the pristine reference build.
+ */
+#ifndef TPT_ORACLE_H
+#define TPT_ORACLE_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Layout contract of the reference (sizes asserted by its GPU hosts, Cpp/Windows/TestWin.cpp:132-134) */
+typedef struct { float cx, cy, cz, radius, invRadius; } TptoSphere;                 /* 20 B, Maths.h:354-364 */
+typedef struct { int type; float albedo[3]; float emissive[3]; float roughness, ri; } TptoMaterial; /* 36 B, Test.cpp:36-44 */
+typedef struct {
+    float origin[3], lowerLeftCorner[3], horizontal[3], vertical[3], uu[3], vv[3], ww[3];
+    float lensRadius;
+} TptoCamera;                                                                       /* 88 B, Maths.h:444-449 */
+
+enum { TPTO_LAMBERT = 0, TPTO_METAL = 1, TPTO_DIELECTRIC = 2 };                     /* Test.cpp:38 */
+enum { TPTO_FLAG_ANIMATE = 1, TPTO_FLAG_PROGRESSIVE = 2 };                          /* Test.h:4-8 */
+/* RNG seeding: ROW_SERIAL == Test.cpp:280 (one stream per row, carried along x);
+ * PER_PIXEL == the reference's own GPU formula, Cpp/Windows/ComputeShader.hlsl:380. */
+enum { TPTO_SEED_ROW_SERIAL = 0, TPTO_SEED_PER_PIXEL = 1 };
+/* MATH_LIBM calls the host libm like the reference; MATH_TPT uses tpt_oracle_math.h (bit-identical
+ * to glibc 2.35 on the path's whole input domain, and executable on the GPU). */
+enum { TPTO_MATH_LIBM = 0, TPTO_MATH_TPT = 1 };
+/* FOLD_RECURSIVE == Test.cpp:216 nesting  matE + lightE + attenuation*Trace(...);
+ * FOLD_FORWARD   == radiance += throughput*(matE+lightE); throughput *= attenuation (same paths,
+ * same ray counts, colour differs by rounding only). */
+enum { TPTO_FOLD_RECURSIVE = 0, TPTO_FOLD_FORWARD = 1 };
+
+typedef struct {
+    int width, height;
+    int y0, y1;          /* rows [y0,y1) are rendered; backbuffer always addresses the full image */
+    int spp;             /* DO_SAMPLES_PER_PIXEL, Config.h:22 */
+    int frame;           /* frameCount */
+    unsigned flags;      /* TestFlags */
+    int seed_mode, math_mode, fold_mode;
+    int threads;         /* <=0: all cores (OpenMP over rows; rows are independent) */
+} TptoParams;
+
+int tpto_default_scene(TptoSphere* spheres, TptoMaterial* mats, int capacity); /* returns 46; Test.cpp:13-31,46-64 */
+void tpto_animate(TptoSphere* spheres, float time);                            /* Test.cpp:304-308 */
+void tpto_update_derived(TptoSphere* spheres, int count);                      /* Maths.h:359 */
+void tpto_camera(TptoCamera* cam, const float lookFrom[3], const float lookAt[3], const float vup[3],
+                 float vfov, float aspect, float aperture, float focusDist);   /* Maths.h:418-435 */
+void tpto_default_camera(TptoCamera* cam, int width, int height);              /* Test.cpp:309-319,341 */
+
+/* Render one frame into backbuffer (w*h*4 floats, RGB written, alpha untouched; Test.cpp:266-300).
+ * Returns the number of rays (HitWorld calls; Test.cpp:122,199). */
+int64_t tpto_render(const TptoSphere* spheres, const TptoMaterial* mats, int count,
+                    const TptoCamera* cam, const TptoParams* p, float* backbuffer);
+
+/* HitSpheres alone (Maths.cpp:165-202) for unit tests: returns id or -1, fills t/pos/normal. */
+int tpto_hit_spheres(const TptoSphere* spheres, int count, const float orig[3], const float dir[3],
+                     float tMin, float tMax, float* outT, float outPos[3], float outNormal[3]);
+
+/* RNG pieces for unit tests (Maths.cpp:5-47) */
+uint32_t tpto_xorshift32(uint32_t* state);
+float tpto_random_float01(uint32_t* state);
+
+/* replicated libm (tpt_oracle_math.h) exposed for tests */
+float tpto_sinf(float x);
+float tpto_cosf(float x);
+float tpto_pow5f(float x);
+/* exhaustive/sampled comparison against the host libm: return number of mismatching results */
+int64_t tpto_check_sincos_vs_libm(void);
+int64_t tpto_check_pow5_vs_libm(uint32_t stride);
+
+uint32_t tpto_fnv1a(const void* data, uint64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,118 @@
+/* tpt_hip.h -- C ABI of the MI355X (gfx950, HIP) implementation of ToyPathTracer's
+ * Trace / HitWorld / Scatter hot path.
+ *
+ * Drop-in boundary: the first block mirrors, one to one, the reference's "Test API"
+ * (/root/reference/Cpp/Source/Test.h:10-17) that every reference host links against
+ * (Cpp/Windows/TestWin.cpp:76,258,265,315-316; Cpp/Apple/Renderer.mm:155,181,225,234;
+ * Cpp/Emscripten/main.cpp:59-60).  The shared library ALSO exports those six functions with the
+ * reference's C++ linkage and exact signatures (see tpt_test_api.h), so a host compiled against the
+ * reference's own Test.h links against libtoypathtracer_hip.so instead of Test.cpp+Maths.cpp+enkiTS
+ * without source changes.  Precedent for an extern "C" veneer over this API in the reference:
+ * Cpp/Emscripten/main.cpp:46-61.
+ *
+ * Everything is plain C: pointers, ints, floats.  No HIP / torch types appear in any signature
+ * (streams and device buffers travel as void* / float*).  All functions return 0 on success and a
+ * negative code on failure (tptGetLastError() has the text); nothing throws across the boundary.
+ * The reference API itself has no error channel (all void): the C++-linkage wrappers print the error
+ * to stderr and abort() -- there is NO CPU fallback.
+ *
+ * Not thread-safe / not re-entrant, like the reference (global scheduler + global scene,
+ * Test.cpp:13,34,46,66-69,237).  One context per process == one GPU per process.
+ */
+#ifndef TPT_HIP_H
+#define TPT_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- TestFlags, Test.h:4-8 */
+enum { TPT_FLAG_ANIMATE = 1 << 0, TPT_FLAG_PROGRESSIVE = 1 << 1 };
+
+/* ================= 1. the reference Test API (Test.h:10-17), C spelling ================= */
+
+/* InitializeTest(), Test.h:10 / Test.cpp:240-246.  Picks the HIP device (env TPT_DEVICE, else
+ * LOCAL_RANK, else 0), creates the stream, uploads the built-in 46-sphere scene. */
+int tptInitialize(void);
+/* ShutdownTest(), Test.h:11 / Test.cpp:248-253. */
+int tptShutdown(void);
+/* UpdateTest(time, frameCount, screenWidth, screenHeight, testFlags), Test.h:13 / Test.cpp:302-342:
+ * animate spheres 1 and 8 if TPT_FLAG_ANIMATE, derive 1/r and r^2, emissive list, camera;
+ * uploads the scene arrays when they changed. */
+int tptUpdate(float time, int frameCount, int screenWidth, int screenHeight, unsigned testFlags);
+/* DrawTest(time, frameCount, w, h, backbuffer, outRayCount, testFlags), Test.h:14 / Test.cpp:344-367.
+ * `backbuffer` is a HOST pointer to w*h*4 floats, read-modify-written in place (RGB blended with the
+ * previous contents, alpha untouched); synchronous: on return the frame and *outRayCount are final.
+ * With row sharding active (tptSetRowShard) only this rank's rows are touched. */
+int tptDraw(float time, int frameCount, int screenWidth, int screenHeight, float* backbuffer, int* outRayCount,
+            unsigned testFlags);
+/* GetObjectCount / GetSceneDesc, Test.h:16-17 / Test.cpp:369-384: sizes are 20 / 36 / 88 bytes and
+ * the copies are byte-compatible with the reference's Sphere / Material / Camera structs. */
+int tptGetObjectCount(int* outCount, int* outObjectSize, int* outMaterialSize, int* outCamSize);
+int tptGetSceneDesc(void* outObjects, void* outMaterials, void* outCam, void* outEmissives, int* outEmissiveCount);
+
+/* ================= 2. what the reference fixes at compile time, as run-time state ================= */
+
+/* DO_SAMPLES_PER_PIXEL, Config.h:22 (default 4). */
+int tptSetSamplesPerPixel(int spp);
+/* RNG seeding.  0 = ROW_SERIAL: one XorShift stream per image row carried along x (Test.cpp:280);
+ * bit-identical to the reference CPU image, parallel over rows only (debug / verification).
+ * 1 = PER_PIXEL (default): one stream per pixel, the reference's own GPU formula
+ * (Cpp/Windows/ComputeShader.hlsl:380); parallel over pixels. */
+int tptSetSeedMode(int mode);
+/* Colour fold.  0 = RECURSIVE (default): matE + lightE + attenuation*Trace(...) nesting of
+ * Test.cpp:216, bit-identical colours.  1 = FORWARD: radiance += throughput*e (same rays, colours
+ * equal up to rounding, no LDS bounce stack). */
+int tptSetFoldMode(int mode);
+/* Replace the static scene tables (Test.cpp:13-31, 46-64).  spheres: count x 20 B {center xyz, radius,
+ * invRadius(ignored)}; materials: count x 36 B {int type; albedo xyz; emissive xyz; roughness; ri}.
+ * count <= 0 or NULL restores the built-in scene. */
+int tptSetScene(const void* spheres, const void* materials, int count);
+/* Camera ctor arguments (Maths.h:418; defaults Test.cpp:309-319).  NULL lookFrom restores defaults. */
+int tptSetCamera(const float* lookFrom, const float* lookAt, float vfovDegrees, float aperture, float focusDist);
+
+/* ================= 3. device-resident / multi-GPU path ================= */
+
+/* Use an existing HIP stream (hipStream_t passed as void*, e.g. torch.cuda.current_stream().cuda_stream).
+ * NULL -> the context's own stream. */
+int tptSetStream(void* hipStream);
+/* Row sharding for one-process-per-GPU rendering: the image's rows are dealt out in stripes of
+ * `stripeRows` rows, round-robin over `numParts` ranks; this context renders the stripes of `part`
+ * into a COMPACT local tile (tptLocalRowCount(h) rows).  Seeds depend on the global (x,y) only, so
+ * the union of the tiles is bit-identical to a 1-GPU render.  (0,1,0) or numParts<=1 disables. */
+int tptSetRowShard(int stripeRows, int numParts, int part);
+int tptLocalRowCount(int screenHeight);
+/* global image row of local tile row `localRow` */
+int tptLocalRowToGlobal(int localRow);
+/* Asynchronous draw into a DEVICE buffer holding this rank's tile: localRows*w*4 floats, the
+ * accumulation buffer stays resident in HBM across frames.  Enqueued on the context's stream;
+ * returns immediately.  Ray counts accumulate in a device counter (tptRayCounterRead). */
+int tptDrawDevice(float time, int frameCount, int screenWidth, int screenHeight, float* deviceTile, unsigned testFlags);
+/* Synchronise the stream and return the monotonic total of rays traced by this context. */
+int tptRayCounterRead(int64_t* outTotalRays);
+int tptSynchronize(void);
+/* hipEvent bracket on the context's stream, for kernel-only timing (as the reference times its
+ * Dispatch with timestamp queries, TestWin.cpp:299-302). */
+int tptTimerBegin(void);
+int tptTimerEnd(float* outMilliseconds); /* synchronises */
+
+/* ================= 4. tuning / test hooks ================= */
+
+/* hitSpheres: 0 = two-phase (default), 1 = simple loop.  persistent: 1 = persistent waves with lane
+ * refill (default), 0 = one thread per pixel.  ldsScene: 1 = stage sphere records in LDS (default
+ * when they fit), 0 = read them from global memory, -1 = auto. */
+int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene);
+/* device math unit tests: op 0 sqrt 1 div 2 sin 3 cos 4 pow5 5 rnd01^16 6 schlick 7 normalize.x; host arrays */
+int tptTestMath(int op, const float* a, const float* b, float* out, int n);
+/* intersect n host rays ([n][6] = origin, direction) with the current scene on the GPU */
+int tptTestHitSpheres(int hitSpheres, const float* rays, int* outId, float* outT, int n);
+/* kernel resource facts for DESIGN/bench: occupancy (blocks/CU), LDS bytes/block, grid size of the last launch */
+int tptGetLaunchInfo(int* outBlocksPerCU, int* outLdsBytes, int* outGridBlocks, int* outNumCUs);
+const char* tptGetLastError(void);
+const char* tptGetDeviceName(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

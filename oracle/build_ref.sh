@@ -8,7 +8,8 @@
 # DO_SAMPLES_PER_PIXEL (Config.h:22) into the runtime variable g_tpt_ref_spp (ref_shim.cpp); every
 # other line is compiled as is.  With g_tpt_ref_spp == 4 the build is the reference as shipped.
 #
-#   libtpt_ref.so       oracle flags : -O2 -msse4.1 -ffp-contract=off       (bit-stable; the pin)
+#   libtpt_ref.so        SIMD path, oracle flags : -O2 -msse4.1 -ffp-contract=off  (bit-stable)
+#   libtpt_ref_scalar.so SCALAR path (the parity target), same flags + -D__EMSCRIPTEN__ (Config.h:9-13)
 #   libtpt_ref_fast.so  "as shipped" : -O3 -ffast-math -mavx2 -mfma (≈ -march=native, portable to the GPU box host; mirrors /fp:fast, GCC_FAST_MATH)
 #
 # -include string.h : Test.cpp:379 uses memcpy without including <string.h>.
@@ -37,5 +38,10 @@ build() {  # name, flags...
     g++ -shared -o "$OUT/$name.so" "$TMP/$name.Test.o" "$TMP/$name.Maths.o" "$TMP/$name.ts.o" "$TMP/$name.tsc.o" "$TMP/$name.shim.o" -lpthread
 }
 build libtpt_ref      -O2 -msse4.1 -ffp-contract=off
+# The reference's own SCALAR path (float3 and HitSpheres without SSE): Config.h:9-13 switches SIMD off
+# when __EMSCRIPTEN__ is defined (that is how its WebAssembly build runs); __EMSCRIPTEN_PTHREADS__
+# keeps the enkiTS threads (Config.h:15-19).  No source is touched.  This is "the reference CPU
+# scalar path" BASELINE.json's north_star names as the parity target.
+build libtpt_ref_scalar -O2 -ffp-contract=off -D__EMSCRIPTEN__ -D__EMSCRIPTEN_PTHREADS__
 build libtpt_ref_fast -O3 -msse4.1 -mavx2 -mfma -ffast-math
-echo "built $OUT/libtpt_ref.so $OUT/libtpt_ref_fast.so"
+echo "built $OUT/libtpt_ref.so $OUT/libtpt_ref_scalar.so $OUT/libtpt_ref_fast.so"

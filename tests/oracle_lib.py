@@ -1,7 +1,7 @@
 """ctypes bindings for the CHECKERS under oracle/ (test infrastructure only).
 
   Oracle  -> oracle/_build/libtpt_oracle.so  (C restatement, oracle/tpt_oracle.c)
-  Ref     -> oracle/_ref/libtpt_ref.so       (pristine reference build, oracle/build_ref.sh)
+  Ref     -> oracle/_ref/libtpt_ref_scalar.so (pristine reference, its own scalar path) / libtpt_ref.so (SIMD)
 
 Nothing under toypathtracer_amd/ imports this module.
 """
@@ -126,25 +126,29 @@ class Oracle:
 
 
 class Ref:
-    """The pristine reference build (oracle/_ref/libtpt_ref.so). Not re-entrant, global scene."""
+    """The pristine reference build (oracle/build_ref.sh). Not re-entrant, global scene.
+    variant: "scalar" (the reference's own scalar path = the parity target), "simd" (as in the repo,
+    oracle flags), "fast" (SIMD, -O3 -ffast-math: how the reference ships)."""
     _inst = {}
+    FILES = {"scalar": "libtpt_ref_scalar.so", "simd": "libtpt_ref.so", "fast": "libtpt_ref_fast.so"}
 
     @classmethod
-    def available(cls, fast=False):
-        return os.path.exists(cls.path(fast))
-
-    @staticmethod
-    def path(fast=False):
-        return os.path.join(ORACLE_DIR, "_ref", "libtpt_ref_fast.so" if fast else "libtpt_ref.so")
+    def available(cls, variant="scalar"):
+        return os.path.exists(cls.path(variant))
 
     @classmethod
-    def get(cls, fast=False):
-        if fast not in cls._inst:
-            cls._inst[fast] = cls(fast)
-        return cls._inst[fast]
+    def path(cls, variant="scalar"):
+        return os.path.join(ORACLE_DIR, "_ref", cls.FILES[variant])
 
-    def __init__(self, fast=False):
-        self.lib = lib = C.CDLL(self.path(fast))
+    @classmethod
+    def get(cls, variant="scalar"):
+        if variant not in cls._inst:
+            cls._inst[variant] = cls(variant)
+        return cls._inst[variant]
+
+    def __init__(self, variant="scalar"):
+        self.variant = variant
+        self.lib = lib = C.CDLL(self.path(variant))
         lib.tptref_draw.restype = C.c_int
         lib.tptref_draw.argtypes = [C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_uint]
         lib.tptref_update.argtypes = [C.c_float, C.c_int, C.c_int, C.c_int, C.c_uint]

@@ -1,0 +1,79 @@
+"""Pins the oracle (oracle/tpt_oracle.c) to the pristine reference: committed golden vectors made
+from oracle/_ref/libtpt_ref.so (tests/golden/make_golden.py) and, when the reference build is
+present, live bit-for-bit comparison."""
+import numpy as np
+import pytest
+
+from common import goldens, golden_scene, oracle_frames
+from oracle_lib import (FLAG_PROGRESSIVE, FOLD_FORWARD, FOLD_RECURSIVE, MATH_LIBM, MATH_TPT, SEED_PER_PIXEL,
+                        SEED_ROW_SERIAL, fnv1a)
+
+
+@pytest.mark.parametrize("case", goldens(), ids=lambda c: "%dx%dx%d_f%d_fl%d" % (c["width"], c["height"], c["spp"], c["frames"], c["flags"]))
+@pytest.mark.parametrize("math_mode", [MATH_LIBM, MATH_TPT], ids=["libm", "tptmath"])
+def test_oracle_reproduces_reference_goldens(oracle, case, math_mode):
+    if case["width"] * case["height"] * case["spp"] * case["frames"] > 4e6 and math_mode == MATH_LIBM:
+        pytest.skip("big case checked once (tptmath)")
+    rays, bb, _ = oracle_frames(oracle, case["width"], case["height"], case["spp"], case["frames"], case["flags"],
+                                case["time"], seed_mode=SEED_ROW_SERIAL, math_mode=math_mode, fold_mode=FOLD_RECURSIVE)
+    assert rays == case["rays"]
+    assert "%08x" % fnv1a(bb) == case["fnv"]
+    assert float(bb[..., 3].max()) == 0.0  # alpha never written (Maths.h:38)
+    for c in range(3):
+        assert abs(float(bb[..., c].mean(dtype=np.float64)) - case["mean_rgb"][c]) < 1e-12
+
+
+def test_scalar_and_simd_reference_agree_on_static_scenes():
+    """Recorded at golden-generation time: the reference's SIMD build gives the same image as its scalar
+    path on every static-scene case (BASELINE.md's hashes were made with the SIMD build)."""
+    for c in goldens():
+        if not (c["flags"] & 1):
+            assert c["rays"] == c["simd_rays"] and c["fnv"] == c["simd_fnv"]
+
+
+def test_baseline_md_goldens_are_in_the_fixture():
+    """The golden vectors quoted in BASELINE.md section 2 are the ones committed."""
+    by = {(c["width"], c["height"], c["spp"], c["frames"], c["flags"]): c for c in goldens()}
+    assert by[(640, 360, 4, 1, 2)]["rays"] == 4204569 and by[(640, 360, 4, 1, 2)]["fnv"] == "a299de4a"
+    assert by[(640, 360, 1, 1, 2)]["rays"] == 1050173 and by[(640, 360, 1, 1, 2)]["fnv"] == "641c3e8f"
+    assert by[(1280, 720, 4, 1, 2)]["rays"] == 16809105
+    assert by[(1280, 720, 4, 3, 2)]["rays"] == 50450142 and by[(1280, 720, 4, 3, 2)]["fnv"] == "16cce49a"
+
+
+def test_default_scene_matches_reference_scene_desc(oracle):
+    s, m, cam, em = golden_scene()
+    so, mo = oracle.default_scene()
+    assert so.tobytes() == s.tobytes() and mo.tobytes() == m.tobytes()
+    assert list(em) == [8, 45]
+    co = oracle.default_camera(640, 360)
+    for name in cam.dtype.names:  # numeric equality: the SSE cross product of the reference build yields +0 where scalar gives -0
+        assert np.array_equal(co[name], cam[name]), name
+
+
+@pytest.mark.parametrize("w,h,spp,frames", [(96, 54, 1, 1), (160, 90, 4, 2), (131, 77, 8, 2), (64, 64, 16, 1)])
+def test_oracle_vs_live_reference(oracle, ref, w, h, spp, frames):
+    rr, rb = ref.render_frames(w, h, spp, frames)
+    ro, ob, _ = oracle_frames(oracle, w, h, spp, frames, seed_mode=SEED_ROW_SERIAL, math_mode=MATH_LIBM)
+    assert rr == ro
+    assert rb.tobytes() == ob.tobytes()
+
+
+def test_row_range_and_threads_do_not_change_the_image(oracle):
+    s, m = oracle.default_scene()
+    cam = oracle.default_camera(120, 80)
+    for seed in (SEED_ROW_SERIAL, SEED_PER_PIXEL):
+        r_full, full = oracle.render(s, m, cam, 120, 80, 2, 3, seed_mode=seed)
+        parts = np.zeros_like(full)
+        r = 0
+        for (y0, y1) in [(0, 7), (7, 40), (40, 80)]:
+            rr, _ = oracle.render(s, m, cam, 120, 80, 2, 3, seed_mode=seed, backbuffer=parts, y0=y0, y1=y1, threads=1)
+            r += rr
+        assert r == r_full and parts.tobytes() == full.tobytes()
+
+
+def test_forward_fold_same_rays_and_colours_within_rounding(oracle):
+    r0, a, _ = oracle_frames(oracle, 200, 120, 4, 2, seed_mode=SEED_PER_PIXEL, fold_mode=FOLD_RECURSIVE)
+    r1, b, _ = oracle_frames(oracle, 200, 120, 4, 2, seed_mode=SEED_PER_PIXEL, fold_mode=FOLD_FORWARD)
+    assert r0 == r1
+    err = np.abs(a[..., :3].astype(np.float64) - b[..., :3]) / np.maximum(np.abs(a[..., :3]), 1e-6)
+    assert err.max() < 5e-6

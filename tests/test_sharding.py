@@ -1,0 +1,87 @@
+"""Row-stripe sharding: index logic, and the N>1 exchange step (gather + counter reduce) with
+world_size 2 over gloo on CPU.  The tile renderer here is the oracle (there is no GPU); the product's
+tptSetRowShard / tptLocalRowCount mirror toypathtracer_amd.sharding (checked on the GPU in
+test_gpu_parity.py::test_sharded_equals_unsharded)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from toypathtracer_amd import sharding
+
+
+@pytest.mark.parametrize("h,stripe,parts", [(360, 8, 8), (720, 4, 8), (117, 8, 2), (100, 16, 4), (7, 8, 2), (64, 64, 1)])
+def test_partition_is_a_permutation(h, stripe, parts):
+    rows = np.concatenate([sharding.local_to_global_rows(h, stripe, parts, p) for p in range(parts)])
+    assert sorted(rows.tolist()) == list(range(h))
+    for p in range(parts):
+        assert sharding.local_row_count(h, stripe, parts, p) == len(sharding.local_to_global_rows(h, stripe, parts, p))
+
+
+def test_product_row_mapping_matches_python():
+    from toypathtracer_amd import api
+    lib = api.load_library()
+    for (h, stripe, parts) in [(360, 8, 8), (117, 8, 2), (100, 16, 4), (7, 8, 2)]:
+        for p in range(parts):
+            lib.tptSetRowShard(stripe, parts, p)
+            rows = sharding.local_to_global_rows(h, stripe, parts, p)
+            assert lib.tptLocalRowCount(h) == len(rows)
+            assert [lib.tptLocalRowToGlobal(i) for i in range(len(rows))] == rows.tolist()
+    lib.tptSetRowShard(0, 1, 0)
+
+
+def _worker(rank, world, port, w, h, stripe, q):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from oracle_lib import Oracle, SEED_PER_PIXEL
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    o = Oracle.get()
+    s, m = o.default_scene()
+    cam = o.default_camera(w, h)
+    sf = sharding.ShardedFrame(w, h, stripe, rank, world, torch.device("cpu"), dist)
+    total = None
+    for frame in range(2):
+        # render this rank's rows (progressive accumulation stays in the rank's own tile)
+        full = np.zeros((h, w, 4), np.float32)
+        rows = sharding.local_to_global_rows(h, stripe, world, rank)
+        full[rows] = sf.tile[: len(rows)].numpy()
+        rays = 0
+        for y in rows:
+            r, _ = o.render(s, m, cam, w, h, 2, frame, seed_mode=SEED_PER_PIXEL, backbuffer=full, y0=int(y), y1=int(y) + 1, threads=1)
+            rays += r
+        sf.tile[: len(rows)] = torch.from_numpy(full[rows])
+        img, total = sf.gather(rays)
+    if rank == 0:
+        q.put((img.numpy().copy(), total))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_reassembles_the_single_process_image(oracle):
+    from oracle_lib import SEED_PER_PIXEL
+    w, h, stripe, world = 64, 42, 4, 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, w, h, stripe, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    img, total = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sc, m = oracle.default_scene()
+    cam = oracle.default_camera(w, h)
+    bb = np.zeros((h, w, 4), np.float32)
+    rays_last = 0
+    for frame in range(2):
+        rays_last, _ = oracle.render(sc, m, cam, w, h, 2, frame, seed_mode=SEED_PER_PIXEL, backbuffer=bb)
+    assert total == rays_last
+    assert img.tobytes() == bb.tobytes()

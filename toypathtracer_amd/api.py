@@ -1,0 +1,234 @@
+"""ctypes mirror of the reference's Test API (Cpp/Source/Test.h:10-17) over libtoypathtracer_hip.so.
+
+Function names, argument order and meaning follow the reference so that tests read like a host of
+the reference would (Cs/Program.cs:16-31, Cpp/Windows/TestWin.cpp:308-340):
+
+    InitializeTest(); UpdateTest(t, frame, w, h, flags); rays = DrawTest(t, frame, w, h, backbuffer, flags)
+
+Only plain pointers/ints/floats cross the boundary (include/tpt_hip.h).  Errors raise TptError;
+nothing here renders on the CPU.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+kFlagAnimate = 1 << 0      # Test.h:6
+kFlagProgressive = 1 << 1  # Test.h:7
+SEED_ROW_SERIAL, SEED_PER_PIXEL = 0, 1
+FOLD_RECURSIVE, FOLD_FORWARD = 0, 1
+
+# layout contract of the reference (TestWin.cpp:132-134): 20 / 36 / 88 bytes
+SPHERE_DT = np.dtype([("cx", "<f4"), ("cy", "<f4"), ("cz", "<f4"), ("radius", "<f4"), ("invRadius", "<f4")])
+MATERIAL_DT = np.dtype([("type", "<i4"), ("albedo", "<f4", 3), ("emissive", "<f4", 3), ("roughness", "<f4"), ("ri", "<f4")])
+CAMERA_DT = np.dtype([("origin", "<f4", 3), ("lowerLeftCorner", "<f4", 3), ("horizontal", "<f4", 3), ("vertical", "<f4", 3),
+                      ("uu", "<f4", 3), ("vv", "<f4", 3), ("ww", "<f4", 3), ("lensRadius", "<f4")])
+
+
+class TptError(RuntimeError):
+    pass
+
+
+_lib = None
+
+# every symbol include/tpt_hip.h declares (checked by tests/test_abi.py)
+C_ABI_SYMBOLS = [
+    "tptInitialize", "tptShutdown", "tptUpdate", "tptDraw", "tptGetObjectCount", "tptGetSceneDesc",
+    "tptSetSamplesPerPixel", "tptSetSeedMode", "tptSetFoldMode", "tptSetScene", "tptSetCamera", "tptSetStream",
+    "tptSetRowShard", "tptLocalRowCount", "tptLocalRowToGlobal", "tptDrawDevice", "tptRayCounterRead",
+    "tptSynchronize", "tptTimerBegin", "tptTimerEnd", "tptSetKernelVariant", "tptTestMath", "tptTestHitSpheres",
+    "tptGetLaunchInfo", "tptGetLastError", "tptGetDeviceName",
+]
+# the reference's own C++ symbols (nm of the compiled Test.cpp), exported for link-level drop-in
+CXX_ABI_SYMBOLS = [
+    "_Z14InitializeTestv", "_Z12ShutdownTestv", "_Z10UpdateTestfiiij", "_Z8DrawTestfiiiPfRij",
+    "_Z14GetObjectCountRiS_S_S_", "_Z12GetSceneDescPvS_S_S_Pi",
+]
+
+
+def library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtoypathtracer_hip.so")
+
+
+def load_library():
+    """dlopen the HIP library (built by __graft_entry__.build() / csrc/build.sh). Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise TptError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(toypathtracer_amd/csrc/build.sh). There is no CPU fallback.")
+    lib = C.CDLL(path)
+    i, f, u, p = C.c_int, C.c_float, C.c_uint, C.c_void_p
+    sigs = {
+        "tptInitialize": [], "tptShutdown": [], "tptUpdate": [f, i, i, i, u],
+        "tptDraw": [f, i, i, i, p, C.POINTER(i), u],
+        "tptGetObjectCount": [C.POINTER(i)] * 4, "tptGetSceneDesc": [p, p, p, p, C.POINTER(i)],
+        "tptSetSamplesPerPixel": [i], "tptSetSeedMode": [i], "tptSetFoldMode": [i], "tptSetScene": [p, p, i],
+        "tptSetCamera": [p, p, f, f, f], "tptSetStream": [p], "tptSetRowShard": [i, i, i], "tptLocalRowCount": [i],
+        "tptLocalRowToGlobal": [i], "tptDrawDevice": [f, i, i, i, p, u], "tptRayCounterRead": [C.POINTER(C.c_int64)],
+        "tptSynchronize": [], "tptTimerBegin": [], "tptTimerEnd": [C.POINTER(f)], "tptSetKernelVariant": [i, i, i],
+        "tptTestMath": [i, p, p, p, i], "tptTestHitSpheres": [i, p, p, p, i], "tptGetLaunchInfo": [C.POINTER(i)] * 4,
+    }
+    for name, args in sigs.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = i
+    lib.tptGetLastError.restype = C.c_char_p
+    lib.tptGetDeviceName.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def _chk(rc, where):
+    if rc != 0:
+        raise TptError(f"{where}: {_lib.tptGetLastError().decode()}")
+
+
+# ---------------------------------------------------------------- the reference API
+def InitializeTest():
+    _chk(load_library().tptInitialize(), "InitializeTest")
+
+
+def ShutdownTest():
+    _chk(load_library().tptShutdown(), "ShutdownTest")
+
+
+def UpdateTest(time, frameCount, screenWidth, screenHeight, testFlags):
+    _chk(load_library().tptUpdate(time, frameCount, screenWidth, screenHeight, testFlags), "UpdateTest")
+
+
+def DrawTest(time, frameCount, screenWidth, screenHeight, backbuffer, testFlags):
+    """backbuffer: C-contiguous float32 numpy array of screenWidth*screenHeight*4, modified in place.
+    Returns outRayCount."""
+    assert isinstance(backbuffer, np.ndarray) and backbuffer.dtype == np.float32 and backbuffer.flags.c_contiguous
+    assert backbuffer.size == screenWidth * screenHeight * 4
+    rays = C.c_int(0)
+    _chk(load_library().tptDraw(time, frameCount, screenWidth, screenHeight, backbuffer.ctypes.data, C.byref(rays),
+                                testFlags), "DrawTest")
+    return rays.value
+
+
+def GetObjectCount():
+    v = [C.c_int() for _ in range(4)]
+    _chk(load_library().tptGetObjectCount(*[C.byref(x) for x in v]), "GetObjectCount")
+    return tuple(x.value for x in v)
+
+
+def GetSceneDesc():
+    n, so, sm, sc = GetObjectCount()
+    assert (so, sm, sc) == (SPHERE_DT.itemsize, MATERIAL_DT.itemsize, CAMERA_DT.itemsize)
+    s, m, cam = np.zeros(n, SPHERE_DT), np.zeros(n, MATERIAL_DT), np.zeros(1, CAMERA_DT)
+    em = np.zeros(n, np.int32)
+    cnt = C.c_int()
+    _chk(load_library().tptGetSceneDesc(s.ctypes.data, m.ctypes.data, cam.ctypes.data, em.ctypes.data, C.byref(cnt)),
+         "GetSceneDesc")
+    return s, m, cam, em[:cnt.value].copy()
+
+
+# ---------------------------------------------------------------- run-time knobs / device path
+def set_samples_per_pixel(spp):
+    _chk(load_library().tptSetSamplesPerPixel(spp), "tptSetSamplesPerPixel")
+
+
+def set_seed_mode(mode):
+    _chk(load_library().tptSetSeedMode(mode), "tptSetSeedMode")
+
+
+def set_fold_mode(mode):
+    _chk(load_library().tptSetFoldMode(mode), "tptSetFoldMode")
+
+
+def set_kernel_variant(hit_spheres=0, persistent=1, lds_scene=-1):
+    _chk(load_library().tptSetKernelVariant(hit_spheres, persistent, lds_scene), "tptSetKernelVariant")
+
+
+def set_scene(spheres=None, materials=None):
+    lib = load_library()
+    if spheres is None:
+        _chk(lib.tptSetScene(None, None, 0), "tptSetScene")
+        return
+    s = np.ascontiguousarray(spheres, SPHERE_DT)
+    m = np.ascontiguousarray(materials, MATERIAL_DT)
+    assert len(s) == len(m)
+    _chk(lib.tptSetScene(s.ctypes.data, m.ctypes.data, len(s)), "tptSetScene")
+
+
+def set_camera(look_from=None, look_at=None, vfov=60.0, aperture=0.02, focus_dist=3.0):
+    lib = load_library()
+    if look_from is None:
+        _chk(lib.tptSetCamera(None, None, 0.0, 0.0, 0.0), "tptSetCamera")
+        return
+    a = np.asarray(look_from, np.float32)
+    b = np.asarray(look_at, np.float32)
+    _chk(lib.tptSetCamera(a.ctypes.data, b.ctypes.data, vfov, aperture, focus_dist), "tptSetCamera")
+
+
+def set_stream(stream_handle):
+    _chk(load_library().tptSetStream(C.c_void_p(stream_handle) if stream_handle else None), "tptSetStream")
+
+
+def set_row_shard(stripe_rows, num_parts, part):
+    _chk(load_library().tptSetRowShard(stripe_rows, num_parts, part), "tptSetRowShard")
+
+
+def local_row_count(height):
+    return load_library().tptLocalRowCount(height)
+
+
+def draw_device(time, frameCount, screenWidth, screenHeight, device_ptr, testFlags):
+    """Asynchronous DrawTest into a device-resident tile (raw device pointer, e.g. tensor.data_ptr())."""
+    _chk(load_library().tptDrawDevice(time, frameCount, screenWidth, screenHeight, C.c_void_p(device_ptr), testFlags),
+         "tptDrawDevice")
+
+
+def ray_counter_read():
+    v = C.c_int64()
+    _chk(load_library().tptRayCounterRead(C.byref(v)), "tptRayCounterRead")
+    return v.value
+
+
+def synchronize():
+    _chk(load_library().tptSynchronize(), "tptSynchronize")
+
+
+def timer_begin():
+    _chk(load_library().tptTimerBegin(), "tptTimerBegin")
+
+
+def timer_end():
+    ms = C.c_float()
+    _chk(load_library().tptTimerEnd(C.byref(ms)), "tptTimerEnd")
+    return ms.value
+
+
+def launch_info():
+    v = [C.c_int() for _ in range(4)]
+    load_library().tptGetLaunchInfo(*[C.byref(x) for x in v])
+    return dict(blocks_per_cu=v[0].value, lds_bytes=v[1].value, grid_blocks=v[2].value, num_cus=v[3].value)
+
+
+def device_name():
+    return load_library().tptGetDeviceName().decode()
+
+
+def test_math(op, a, b=None):
+    a = np.ascontiguousarray(a, np.float32)
+    out = np.empty_like(a)
+    bp = None
+    if b is not None:
+        b = np.ascontiguousarray(b, np.float32)
+        bp = b.ctypes.data
+    _chk(load_library().tptTestMath(op, a.ctypes.data, bp, out.ctypes.data, a.size), "tptTestMath")
+    return out
+
+
+def test_hit_spheres(rays, hit_spheres=0):
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+    n = rays.shape[0]
+    ids = np.empty(n, np.int32)
+    ts = np.empty(n, np.float32)
+    _chk(load_library().tptTestHitSpheres(hit_spheres, rays.ctypes.data, ids.ctypes.data, ts.ctypes.data, n),
+         "tptTestHitSpheres")
+    return ids, ts

@@ -1,0 +1,30 @@
+// tpt_device.h -- kernel argument block shared by tpt_kernels.hip (device) and tpt_host.cpp (host).
+#pragma once
+#include "tpt_trace.h"
+
+#define TPT_BLOCK 256        // 4 waves per workgroup
+#define TPT_CHUNK_PIXELS 256 // pixels a persistent wave pulls per atomic (4 tiles of 8x8)
+
+namespace tpt {
+
+struct KernelArgs {
+    SceneView scene;
+    FrameConsts fc;
+    float* backbuffer; // device, [nLocalRows][width][4] floats: the rows this GPU owns, compact
+    // row sharding: local row ly <-> image row (ly / stripeRows) * stripeStride + stripeOffset + ly % stripeRows
+    int nLocalRows, stripeRows, stripeStride, stripeOffset;
+    int tilesX;     // 8x8 tiles per row of tiles
+    int numItems;   // pixels incl. tile padding (PER_PIXEL) or rows (ROW_SERIAL)
+    int numChunks, chunkSize;
+    unsigned totalWaves;
+    unsigned* work;                  // [0] next chunk, [1] finished waves (persistent variant)
+    unsigned long long* rayCounter;  // monotonic total of rays traced by this context
+};
+
+} // namespace tpt
+
+size_t tptLdsBytes(const tpt::KernelArgs& a, int fold, bool ldsScene);
+hipError_t tptLaunchTrace(const tpt::KernelArgs& a, int hs, int fold, bool persist, bool ldsScene, int blocks, size_t lds, hipStream_t stream);
+int tptTraceOccupancy(int hs, int fold, bool persist, bool ldsScene, size_t lds);
+hipError_t tptLaunchMathTest(int op, const float* a, const float* b, float* out, int n, hipStream_t stream);
+hipError_t tptLaunchHitTest(const tpt::KernelArgs& a, int hs, const float* rays, int* outId, float* outT, int n, hipStream_t stream);

@@ -1,0 +1,575 @@
+// tpt_host.cpp -- host runtime + C ABI (include/tpt_hip.h) + the reference's C++ Test API
+// (include/tpt_test_api.h == Cpp/Source/Test.h:10-17) for the MI355X path tracer.
+//
+// Replaces, on the host side: InitializeTest/ShutdownTest (Test.cpp:240-253; the enkiTS scheduler is
+// replaced by a HIP stream), UpdateTest (Test.cpp:302-342; scene prep stays on the host, results are
+// uploaded to HBM when dirty), DrawTest (Test.cpp:344-367; the row fan-out becomes one kernel
+// launch), GetObjectCount/GetSceneDesc (Test.cpp:369-384).
+//
+// There is deliberately NO CPU rendering path in this library: if HIP is unavailable every entry
+// point fails loudly.
+#include "../../include/tpt_hip.h"
+#include "../../include/tpt_test_api.h"
+#include "tpt_device.h"
+#include "tpt_scene.h"
+#include <hip/hip_runtime.h>
+#include <map>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string>
+
+using namespace tpt;
+
+namespace {
+
+struct Context {
+    bool inited = false;
+    int device = 0, numCUs = 0;
+    std::string deviceName, err;
+    hipStream_t ownStream = nullptr, stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // host scene state (the reference's statics, Test.cpp:13-69)
+    std::vector<SpherePOD> spheres;
+    std::vector<MaterialPOD> mats;
+    CameraSetup camSetup = defaultCameraSetup();
+    CameraPOD cam;
+    PackedScene packed;
+    bool sceneDirty = true; // host arrays changed since last pack+upload
+    bool updated = false;   // tptUpdate ran at least once
+
+    // device scene
+    float* dPairs = nullptr;
+    f4* dSph4 = nullptr;
+    float* dInvR = nullptr;
+    f4* dMats = nullptr;
+    f4* dLights = nullptr;
+
+    // run-time versions of the reference's compile-time switches
+    int spp = 4;                     // DO_SAMPLES_PER_PIXEL, Config.h:22
+    int seedMode = SEED_PER_PIXEL;
+    int foldMode = FOLD_RECURSIVE;
+    int hs = HS_TWO_PHASE, persist = 1, ldsScene = -1;
+    int stripeRows = 0, numParts = 1, part = 0;
+
+    unsigned* dWork = nullptr;
+    unsigned long long* dRays = nullptr;
+    long long lastTotal = 0;
+
+    float* dFrame = nullptr; // device tile behind the host-pointer DrawTest
+    size_t frameCap = 0;
+
+    std::map<int, int> occCache;
+    int lastBlocksPerCU = 0, lastLds = 0, lastGrid = 0;
+};
+
+Context g;
+
+int fail(const std::string& what)
+{
+    g.err = what;
+    return -1;
+}
+int hipFail(hipError_t e, const char* what)
+{
+    g.err = std::string(what) + ": " + hipGetErrorString(e);
+    return -2;
+}
+#define HIPCHK(x)                                   \
+    do {                                            \
+        hipError_t _e = (x);                        \
+        if (_e != hipSuccess) return hipFail(_e, #x); \
+    } while (0)
+
+int localRows(int h)
+{
+    if (g.numParts <= 1 || g.stripeRows <= 0) return h;
+    const int S = g.stripeRows, stride = S * g.numParts, off = S * g.part;
+    int full = h / stride, rem = h % stride;
+    int rows = full * S;
+    int extra = rem - off;
+    if (extra > 0) rows += extra < S ? extra : S;
+    return rows;
+}
+int localToGlobal(int ly)
+{
+    if (g.numParts <= 1 || g.stripeRows <= 0) return ly;
+    const int S = g.stripeRows;
+    return (ly / S) * S * g.numParts + S * g.part + (ly % S);
+}
+
+template <class T>
+int ensureDev(T*& p, int& cap, int need)
+{
+    if (need <= cap && p) return 0;
+    if (p) HIPCHK(hipFree(p));
+    p = nullptr;
+    int n = need < 64 ? 64 : need;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&p), sizeof(T) * (size_t)n));
+    cap = n;
+    return 0;
+}
+
+struct ScenePtrCaps {
+    int pairs = 0, sph4 = 0, invR = 0, mats = 0, lights = 0;
+} caps;
+
+int uploadSceneTracked()
+{
+    packScene(g.spheres, g.mats, g.packed);
+    const PackedScene& P = g.packed;
+    int rc;
+    if ((rc = ensureDev(g.dPairs, caps.pairs, P.nPairs * 8))) return rc;
+    if ((rc = ensureDev(g.dSph4, caps.sph4, P.nPairs * 2))) return rc;
+    if ((rc = ensureDev(g.dInvR, caps.invR, P.nPairs * 2))) return rc;
+    if ((rc = ensureDev(g.dMats, caps.mats, P.nSpheres * 3))) return rc;
+    if ((rc = ensureDev(g.dLights, caps.lights, P.nLights * 2 + 2))) return rc;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipMemcpy(g.dPairs, P.pairs.data(), P.pairs.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(g.dSph4, P.sph4.data(), P.sph4.size() * sizeof(f4), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(g.dInvR, P.invR.data(), P.invR.size() * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(g.dMats, P.mats.data(), P.mats.size() * sizeof(f4), hipMemcpyHostToDevice));
+    if (!P.lights.empty())
+        HIPCHK(hipMemcpy(g.dLights, P.lights.data(), P.lights.size() * sizeof(f4), hipMemcpyHostToDevice));
+    g.sceneDirty = false;
+    return 0;
+}
+
+SceneView deviceView()
+{
+    SceneView sv;
+    sv.pairs = g.dPairs;
+    sv.sph4 = g.dSph4;
+    sv.invR = g.dInvR;
+    sv.mats = g.dMats;
+    sv.lights = g.dLights;
+    sv.nSpheres = g.packed.nSpheres;
+    sv.nPairs = g.packed.nPairs;
+    sv.nLights = g.packed.nLights;
+    return sv;
+}
+
+int requireInit()
+{
+    if (!g.inited) return fail("tpt: not initialised (call tptInitialize / InitializeTest first)");
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+const char* tptGetLastError(void) { return g.err.c_str(); }
+const char* tptGetDeviceName(void) { return g.deviceName.c_str(); }
+
+int tptInitialize(void)
+{
+    if (g.inited) return 0;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail("tptInitialize: no HIP device visible (this library has no CPU fallback)");
+    int dev = 0;
+    const char* env = getenv("TPT_DEVICE");
+    if (!env) env = getenv("LOCAL_RANK");
+    if (env) dev = atoi(env);
+    if (dev < 0 || dev >= count) dev = dev % count;
+    HIPCHK(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    g.device = dev;
+    g.numCUs = prop.multiProcessorCount;
+    g.deviceName = std::string(prop.name) + " (" + prop.gcnArchName + ")";
+    HIPCHK(hipStreamCreateWithFlags(&g.ownStream, hipStreamNonBlocking));
+    g.stream = g.ownStream;
+    HIPCHK(hipEventCreate(&g.ev0));
+    HIPCHK(hipEventCreate(&g.ev1));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dWork), 64));
+    HIPCHK(hipMemset(g.dWork, 0, 64));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dRays), 64));
+    HIPCHK(hipMemset(g.dRays, 0, 64));
+    g.lastTotal = 0;
+    if (g.spheres.empty()) defaultScene(g.spheres, g.mats);
+    g.sceneDirty = true;
+    g.inited = true;
+    return 0;
+}
+
+int tptShutdown(void)
+{
+    if (!g.inited) return 0;
+    hipStreamSynchronize(g.stream);
+    hipFree(g.dPairs); hipFree(g.dSph4); hipFree(g.dInvR); hipFree(g.dMats); hipFree(g.dLights);
+    hipFree(g.dWork); hipFree(g.dRays); hipFree(g.dFrame);
+    g.dPairs = nullptr; g.dSph4 = nullptr; g.dInvR = nullptr; g.dMats = nullptr; g.dLights = nullptr;
+    g.dWork = nullptr; g.dRays = nullptr; g.dFrame = nullptr;
+    g.frameCap = 0;
+    caps = ScenePtrCaps();
+    hipEventDestroy(g.ev0); hipEventDestroy(g.ev1);
+    hipStreamDestroy(g.ownStream);
+    g.ownStream = g.stream = nullptr;
+    g.inited = false;
+    g.updated = false;
+    g.occCache.clear();
+    return 0;
+}
+
+int tptSetStream(void* hipStream)
+{
+    if (requireInit()) return -1;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    g.stream = hipStream ? reinterpret_cast<hipStream_t>(hipStream) : g.ownStream;
+    return 0;
+}
+
+int tptSetSamplesPerPixel(int spp)
+{
+    if (spp < 1 || spp > 65536) return fail("tptSetSamplesPerPixel: spp out of range");
+    g.spp = spp;
+    return 0;
+}
+int tptSetSeedMode(int mode)
+{
+    if (mode != SEED_ROW_SERIAL && mode != SEED_PER_PIXEL) return fail("tptSetSeedMode: 0 (ROW_SERIAL) or 1 (PER_PIXEL)");
+    g.seedMode = mode;
+    return 0;
+}
+int tptSetFoldMode(int mode)
+{
+    if (mode != FOLD_RECURSIVE && mode != FOLD_FORWARD) return fail("tptSetFoldMode: 0 (RECURSIVE) or 1 (FORWARD)");
+    g.foldMode = mode;
+    return 0;
+}
+int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene)
+{
+    g.hs = hitSpheres ? HS_SIMPLE : HS_TWO_PHASE;
+    g.persist = persistent ? 1 : 0;
+    g.ldsScene = ldsScene < 0 ? -1 : (ldsScene ? 1 : 0);
+    return 0;
+}
+
+int tptSetScene(const void* spheres, const void* materials, int count)
+{
+    if (!spheres || !materials || count <= 0) {
+        defaultScene(g.spheres, g.mats);
+    } else {
+        if (count > (1 << 20)) return fail("tptSetScene: too many spheres");
+        const SpherePOD* s = static_cast<const SpherePOD*>(spheres);
+        const MaterialPOD* m = static_cast<const MaterialPOD*>(materials);
+        g.spheres.assign(s, s + count);
+        g.mats.assign(m, m + count);
+    }
+    g.sceneDirty = true;
+    return 0;
+}
+
+int tptSetCamera(const float* lookFrom, const float* lookAt, float vfov, float aperture, float focusDist)
+{
+    if (!lookFrom || !lookAt) {
+        g.camSetup = defaultCameraSetup();
+        return 0;
+    }
+    for (int i = 0; i < 3; ++i) {
+        g.camSetup.lookFrom[i] = lookFrom[i];
+        g.camSetup.lookAt[i] = lookAt[i];
+    }
+    g.camSetup.vfov = vfov;
+    g.camSetup.aperture = aperture;
+    g.camSetup.focusDist = focusDist;
+    return 0;
+}
+
+int tptSetRowShard(int stripeRows, int numParts, int part)
+{
+    if (numParts <= 1 || stripeRows <= 0) {
+        g.stripeRows = 0; g.numParts = 1; g.part = 0;
+        return 0;
+    }
+    if (part < 0 || part >= numParts) return fail("tptSetRowShard: part out of range");
+    g.stripeRows = stripeRows; g.numParts = numParts; g.part = part;
+    return 0;
+}
+int tptLocalRowCount(int screenHeight) { return localRows(screenHeight); }
+int tptLocalRowToGlobal(int localRow) { return localToGlobal(localRow); }
+
+// UpdateTest, Test.cpp:302-342
+int tptUpdate(float time, int frameCount, int screenWidth, int screenHeight, unsigned testFlags)
+{
+    (void)frameCount;
+    if (requireInit()) return -1;
+    if (screenWidth <= 0 || screenHeight <= 0) return fail("tptUpdate: bad size");
+    if ((testFlags & TPT_FLAG_ANIMATE) && g.spheres.size() > 8) { // Test.cpp:304-308
+        g.spheres[1].cy = cosf(time) + 1.0f;
+        g.spheres[8].cz = sinf(time) * 0.3f;
+        g.sceneDirty = true;
+    }
+    if (g.sceneDirty) {
+        int rc = uploadSceneTracked();
+        if (rc) return rc;
+    }
+    g.cam = makeCamera(g.camSetup, float(screenWidth) / float(screenHeight)); // Test.cpp:341
+    g.updated = true;
+    return 0;
+}
+
+int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, unsigned testFlags)
+{
+    (void)time; // stored but never read by the reference either (Test.cpp:257,347)
+    if (requireInit()) return -1;
+    if (!g.updated) return fail("tptDrawDevice: call tptUpdate (UpdateTest) first");
+    if (!deviceTile || w <= 0 || h <= 0) return fail("tptDrawDevice: bad arguments");
+    if (g.sceneDirty) {
+        int rc = uploadSceneTracked();
+        if (rc) return rc;
+    }
+    KernelArgs a;
+    a.scene = deviceView();
+    a.fc = makeFrameConsts(g.cam, w, h, g.spp, frameCount, testFlags, g.seedMode);
+    a.backbuffer = deviceTile;
+    a.nLocalRows = localRows(h);
+    if (g.numParts > 1 && g.stripeRows > 0) {
+        a.stripeRows = g.stripeRows;
+        a.stripeStride = g.stripeRows * g.numParts;
+        a.stripeOffset = g.stripeRows * g.part;
+    } else {
+        a.stripeRows = h > 0 ? h : 1;
+        a.stripeStride = a.stripeRows;
+        a.stripeOffset = 0;
+    }
+    if (a.nLocalRows <= 0) return 0; // nothing to do on this rank
+    a.tilesX = (w + 7) / 8;
+    const int tilesY = (a.nLocalRows + 7) / 8;
+    const bool rowSerial = g.seedMode == SEED_ROW_SERIAL;
+    a.numItems = rowSerial ? a.nLocalRows : a.tilesX * tilesY * 64;
+    a.work = g.dWork;
+    a.rayCounter = g.dRays;
+
+    // LDS scene staging: default when {centre,r^2}+1/r (20 B/sphere) + lights + bounce stack fit in 64 KB
+    const int nPad = a.scene.nPairs * 2;
+    bool ldsScene = g.ldsScene < 0 ? ((size_t)nPad * 20 + 4096 + (g.foldMode == FOLD_RECURSIVE ? 40960 : 0) <= 65536) : (g.ldsScene != 0);
+    const size_t lds = tptLdsBytes(a, g.foldMode, ldsScene);
+    if (lds > 160 * 1024) return fail("tptDrawDevice: scene too large for LDS staging; use tptSetKernelVariant(.., .., 0)");
+
+    const int key = (g.hs ? 8 : 0) | (g.foldMode ? 4 : 0) | (g.persist ? 2 : 0) | (ldsScene ? 1 : 0) | ((int)(lds / 256) << 4);
+    int occ;
+    auto it = g.occCache.find(key);
+    if (it == g.occCache.end()) {
+        occ = tptTraceOccupancy(g.hs, g.foldMode, g.persist != 0, ldsScene, lds);
+        g.occCache[key] = occ;
+    } else {
+        occ = it->second;
+    }
+    int blocks;
+    if (g.persist) {
+        const int resident = g.numCUs * occ; // workgroups that can be co-resident
+        const int wavesPerBlock = TPT_BLOCK / 64;
+        int chunk = rowSerial ? 1 : TPT_CHUNK_PIXELS;
+        // small frames: hand out single 8x8 tiles so every resident wave gets several chunks
+        if (!rowSerial && a.numItems / TPT_CHUNK_PIXELS < 8 * resident * wavesPerBlock) chunk = 64;
+        a.chunkSize = chunk;
+        a.numChunks = (a.numItems + chunk - 1) / chunk;
+        blocks = (a.numChunks + wavesPerBlock - 1) / wavesPerBlock;
+        if (blocks > resident) blocks = resident;
+        if (blocks < 1) blocks = 1;
+        a.totalWaves = (unsigned)(blocks * wavesPerBlock);
+    } else {
+        a.chunkSize = 0;
+        a.numChunks = 0;
+        blocks = (a.numItems + TPT_BLOCK - 1) / TPT_BLOCK;
+        a.totalWaves = 0;
+    }
+    g.lastBlocksPerCU = occ;
+    g.lastLds = (int)lds;
+    g.lastGrid = blocks;
+    HIPCHK(tptLaunchTrace(a, g.hs, g.foldMode, g.persist != 0, ldsScene, blocks, lds, g.stream));
+    return 0;
+}
+
+int tptRayCounterRead(int64_t* outTotalRays)
+{
+    if (requireInit()) return -1;
+    unsigned long long v = 0;
+    HIPCHK(hipMemcpyAsync(&v, g.dRays, sizeof(v), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    if (outTotalRays) *outTotalRays = (int64_t)v;
+    return 0;
+}
+
+int tptSynchronize(void)
+{
+    if (requireInit()) return -1;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
+int tptTimerBegin(void)
+{
+    if (requireInit()) return -1;
+    HIPCHK(hipEventRecord(g.ev0, g.stream));
+    return 0;
+}
+int tptTimerEnd(float* outMs)
+{
+    if (requireInit()) return -1;
+    HIPCHK(hipEventRecord(g.ev1, g.stream));
+    HIPCHK(hipEventSynchronize(g.ev1));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, g.ev0, g.ev1));
+    if (outMs) *outMs = ms;
+    return 0;
+}
+
+// DrawTest, Test.cpp:344-367 (host backbuffer, synchronous)
+int tptDraw(float time, int frameCount, int w, int h, float* backbuffer, int* outRayCount, unsigned testFlags)
+{
+    if (requireInit()) return -1;
+    if (!backbuffer || w <= 0 || h <= 0) return fail("tptDraw: bad arguments");
+    const int rows = localRows(h);
+    const size_t rowBytes = (size_t)w * 4 * sizeof(float);
+    const size_t need = rowBytes * (size_t)(rows > 0 ? rows : 1);
+    if (need > g.frameCap) {
+        if (g.dFrame) HIPCHK(hipFree(g.dFrame));
+        g.dFrame = nullptr;
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dFrame), need));
+        g.frameCap = need;
+    }
+    // the host buffer is the source of truth (previous frame's RGB, caller-owned alpha): upload this rank's rows
+    const bool sharded = g.numParts > 1 && g.stripeRows > 0;
+    if (!sharded) {
+        HIPCHK(hipMemcpyAsync(g.dFrame, backbuffer, rowBytes * rows, hipMemcpyHostToDevice, g.stream));
+    } else {
+        for (int ly = 0; ly < rows; ly += g.stripeRows) {
+            int n = rows - ly < g.stripeRows ? rows - ly : g.stripeRows;
+            HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(g.dFrame) + rowBytes * ly,
+                                  reinterpret_cast<const char*>(backbuffer) + rowBytes * localToGlobal(ly), rowBytes * n,
+                                  hipMemcpyHostToDevice, g.stream));
+        }
+    }
+    int rc = tptDrawDevice(time, frameCount, w, h, g.dFrame, testFlags);
+    if (rc) return rc;
+    if (!sharded) {
+        HIPCHK(hipMemcpyAsync(backbuffer, g.dFrame, rowBytes * rows, hipMemcpyDeviceToHost, g.stream));
+    } else {
+        for (int ly = 0; ly < rows; ly += g.stripeRows) {
+            int n = rows - ly < g.stripeRows ? rows - ly : g.stripeRows;
+            HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(backbuffer) + rowBytes * localToGlobal(ly),
+                                  reinterpret_cast<const char*>(g.dFrame) + rowBytes * ly, rowBytes * n,
+                                  hipMemcpyDeviceToHost, g.stream));
+        }
+    }
+    int64_t total = 0;
+    rc = tptRayCounterRead(&total); // synchronises the stream
+    if (rc) return rc;
+    if (outRayCount) *outRayCount = (int)(total - g.lastTotal);
+    g.lastTotal = total;
+    return 0;
+}
+
+int tptGetObjectCount(int* outCount, int* outObjectSize, int* outMaterialSize, int* outCamSize) // Test.cpp:369-375
+{
+    if (g.spheres.empty()) defaultScene(g.spheres, g.mats);
+    if (outCount) *outCount = (int)g.spheres.size();
+    if (outObjectSize) *outObjectSize = (int)sizeof(SpherePOD);
+    if (outMaterialSize) *outMaterialSize = (int)sizeof(MaterialPOD);
+    if (outCamSize) *outCamSize = (int)sizeof(CameraPOD);
+    return 0;
+}
+
+int tptGetSceneDesc(void* outObjects, void* outMaterials, void* outCam, void* outEmissives, int* outEmissiveCount) // Test.cpp:377-384
+{
+    if (g.spheres.empty()) defaultScene(g.spheres, g.mats);
+    if (g.sceneDirty || g.packed.nSpheres != (int)g.spheres.size()) packScene(g.spheres, g.mats, g.packed); // fills invRadius + emissive ids
+    if (outObjects) memcpy(outObjects, g.spheres.data(), g.spheres.size() * sizeof(SpherePOD));
+    if (outMaterials) memcpy(outMaterials, g.mats.data(), g.mats.size() * sizeof(MaterialPOD));
+    if (outCam) memcpy(outCam, &g.cam, sizeof(CameraPOD));
+    if (outEmissives && !g.packed.emissive.empty())
+        memcpy(outEmissives, g.packed.emissive.data(), g.packed.emissive.size() * sizeof(int));
+    if (outEmissiveCount) *outEmissiveCount = (int)g.packed.emissive.size();
+    return 0;
+}
+
+int tptGetLaunchInfo(int* outBlocksPerCU, int* outLdsBytes, int* outGridBlocks, int* outNumCUs)
+{
+    if (outBlocksPerCU) *outBlocksPerCU = g.lastBlocksPerCU;
+    if (outLdsBytes) *outLdsBytes = g.lastLds;
+    if (outGridBlocks) *outGridBlocks = g.lastGrid;
+    if (outNumCUs) *outNumCUs = g.numCUs;
+    return 0;
+}
+
+int tptTestMath(int op, const float* a, const float* b, float* out, int n)
+{
+    if (requireInit()) return -1;
+    if (!a || !out || n <= 0) return fail("tptTestMath: bad arguments");
+    float *da = nullptr, *db = nullptr, *dout = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&da), sizeof(float) * n));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&dout), sizeof(float) * n));
+    HIPCHK(hipMemcpy(da, a, sizeof(float) * n, hipMemcpyHostToDevice));
+    if (b) {
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&db), sizeof(float) * n));
+        HIPCHK(hipMemcpy(db, b, sizeof(float) * n, hipMemcpyHostToDevice));
+    }
+    HIPCHK(tptLaunchMathTest(op, da, db, dout, n, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipMemcpy(out, dout, sizeof(float) * n, hipMemcpyDeviceToHost));
+    hipFree(da); hipFree(db); hipFree(dout);
+    return 0;
+}
+
+int tptTestHitSpheres(int hitSpheres, const float* rays, int* outId, float* outT, int n)
+{
+    if (requireInit()) return -1;
+    if (!rays || !outId || !outT || n <= 0) return fail("tptTestHitSpheres: bad arguments");
+    if (g.sceneDirty) {
+        int rc = uploadSceneTracked();
+        if (rc) return rc;
+    }
+    float *dr = nullptr, *dt = nullptr;
+    int* di = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&dr), sizeof(float) * 6 * n));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&dt), sizeof(float) * n));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&di), sizeof(int) * n));
+    HIPCHK(hipMemcpy(dr, rays, sizeof(float) * 6 * n, hipMemcpyHostToDevice));
+    KernelArgs a;
+    memset(&a, 0, sizeof(a));
+    a.scene = deviceView();
+    HIPCHK(tptLaunchHitTest(a, hitSpheres ? HS_SIMPLE : HS_TWO_PHASE, dr, di, dt, n, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipMemcpy(outId, di, sizeof(int) * n, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(outT, dt, sizeof(float) * n, hipMemcpyDeviceToHost));
+    hipFree(dr); hipFree(dt); hipFree(di);
+    return 0;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------- the reference's C++ Test API (Test.h:10-17)
+// Same names, signatures and C++ linkage, so `nm` shows the very symbols Test.cpp exports
+// (_Z14InitializeTestv, _Z12ShutdownTestv, _Z10UpdateTestfiiij, _Z8DrawTestfiiiPfRij,
+// _Z14GetObjectCountRiS_S_S_, _Z12GetSceneDescPvS_S_S_Pi).  The reference functions return void and
+// have no error channel: a HIP failure is reported on stderr and the process aborts.
+static void dieOn(int rc, const char* where)
+{
+    if (rc) {
+        fprintf(stderr, "toypathtracer_hip: %s failed: %s\n", where, tptGetLastError());
+        abort();
+    }
+}
+void InitializeTest() { dieOn(tptInitialize(), "InitializeTest"); }
+void ShutdownTest() { dieOn(tptShutdown(), "ShutdownTest"); }
+void UpdateTest(float time, int frameCount, int screenWidth, int screenHeight, unsigned testFlags)
+{
+    dieOn(tptUpdate(time, frameCount, screenWidth, screenHeight, testFlags), "UpdateTest");
+}
+void DrawTest(float time, int frameCount, int screenWidth, int screenHeight, float* backbuffer, int& outRayCount, unsigned testFlags)
+{
+    dieOn(tptDraw(time, frameCount, screenWidth, screenHeight, backbuffer, &outRayCount, testFlags), "DrawTest");
+}
+void GetObjectCount(int& outCount, int& outObjectSize, int& outMaterialSize, int& outCamSize)
+{
+    dieOn(tptGetObjectCount(&outCount, &outObjectSize, &outMaterialSize, &outCamSize), "GetObjectCount");
+}
+void GetSceneDesc(void* outObjects, void* outMaterials, void* outCam, void* outEmissives, int* outEmissiveCount)
+{
+    dieOn(tptGetSceneDesc(outObjects, outMaterials, outCam, outEmissives, outEmissiveCount), "GetSceneDesc");
+}

@@ -1,0 +1,206 @@
+// tpt_scene.h -- host-side scene state: the reference's Sphere / Material / Camera layouts, the
+// built-in 46-sphere scene, UpdateTest's per-frame preparation and the packing into the arrays the
+// kernels read (SceneView, tpt_trace.h).
+//
+// Replaces Cpp/Source/Test.cpp:13-69 (scene tables, emissive list, camera), UpdateTest :302-342,
+// Maths.h Sphere :354-364, SpheresSoA :368-404, Camera ctor :418-435, GetSceneDesc :369-384.
+// Host-only plain C++ (no HIP types) so the lane-logic test in tests/ can reuse it.
+#pragma once
+#include "tpt_trace.h"
+#include <math.h>
+#include <string.h>
+#include <vector>
+
+namespace tpt {
+
+// ---- layout contract of the reference (sizes asserted by its GPU hosts, TestWin.cpp:132-134)
+struct SpherePOD { // Maths.h:354-364, 20 B
+    float cx, cy, cz, radius, invRadius;
+};
+struct MaterialPOD { // Test.cpp:36-44, 36 B
+    int type;
+    float albedo[3], emissive[3], roughness, ri;
+};
+static_assert(sizeof(SpherePOD) == 20, "Sphere layout (TestWin.cpp:132)");
+static_assert(sizeof(MaterialPOD) == 36, "Material layout (TestWin.cpp:133)");
+static_assert(sizeof(CameraPOD) == 88, "Camera layout (TestWin.cpp:134)");
+
+struct CameraSetup { // arguments of the Camera ctor, Maths.h:418
+    float lookFrom[3], lookAt[3], vup[3];
+    float vfov, aperture, focusDist;
+};
+
+inline CameraSetup defaultCameraSetup() // Test.cpp:309-319
+{
+    CameraSetup c;
+    c.lookFrom[0] = 0; c.lookFrom[1] = 2; c.lookFrom[2] = 3;
+    c.lookAt[0] = 0; c.lookAt[1] = 0; c.lookAt[2] = 0;
+    c.vup[0] = 0; c.vup[1] = 1; c.vup[2] = 0;
+    c.vfov = 60;
+    float aperture = 0.1f;
+    aperture *= 0.2f; // DO_BIG_SCENE, Test.cpp:317-319
+    c.aperture = aperture;
+    c.focusDist = 3;
+    return c;
+}
+
+inline void st3(float* p, f3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+
+inline CameraPOD makeCamera(const CameraSetup& s, float aspect) // Maths.h:418-435 (tanf from the host libm, as the reference)
+{
+    CameraPOD cam;
+    cam.lensRadius = s.aperture / 2;
+    float theta = s.vfov * TPT_PI / 180;
+    float halfHeight = tanf(theta / 2);
+    float halfWidth = aspect * halfHeight;
+    f3 org = ld3(s.lookFrom);
+    f3 w = normalize(ld3(s.lookFrom) - ld3(s.lookAt));
+    f3 u = normalize(cross(ld3(s.vup), w));
+    f3 v = cross(w, u);
+    st3(cam.origin, org);
+    st3(cam.ww, w);
+    st3(cam.uu, u);
+    st3(cam.vv, v);
+    st3(cam.lowerLeftCorner, org - (halfWidth * s.focusDist) * u - (halfHeight * s.focusDist) * v - s.focusDist * w);
+    st3(cam.horizontal, (2 * halfWidth * s.focusDist) * u);
+    st3(cam.vertical, (2 * halfHeight * s.focusDist) * v);
+    return cam;
+}
+
+// ---- the built-in scene: same data as Test.cpp:13-31 (spheres) and :46-64 (materials)
+inline void defaultScene(std::vector<SpherePOD>& S, std::vector<MaterialPOD>& M)
+{
+    S.clear();
+    M.clear();
+    auto sphere = [&](float x, float y, float z, float r) {
+        SpherePOD s = {x, y, z, r, 0.0f};
+        S.push_back(s);
+    };
+    auto mat = [&](int type, float r, float g, float b, float er, float eg, float eb, float rough, float ri) {
+        MaterialPOD m = {type, {r, g, b}, {er, eg, eb}, rough, ri};
+        M.push_back(m);
+    };
+    const float grey[9] = {0.1f, 0.2f, 0.3f, 0.4f, 0.5f, 0.6f, 0.7f, 0.8f, 0.9f};
+    const float hue[9][3] = {{0.8f, 0.1f, 0.1f}, {0.8f, 0.5f, 0.1f}, {0.8f, 0.8f, 0.1f}, {0.4f, 0.8f, 0.1f}, {0.1f, 0.8f, 0.1f},
+                             {0.1f, 0.8f, 0.5f}, {0.1f, 0.8f, 0.8f}, {0.1f, 0.1f, 0.8f}, {0.5f, 0.1f, 0.8f}};
+    sphere(0, -100.5f, -1, 100);
+    mat(MAT_LAMBERT, 0.8f, 0.8f, 0.8f, 0, 0, 0, 0, 0);
+    const float featAlb[6][3] = {{0.8f, 0.4f, 0.4f}, {0.4f, 0.8f, 0.4f}, {0.4f, 0.4f, 0.8f}, {0.4f, 0.8f, 0.4f}, {0.4f, 0.8f, 0.4f}, {0.4f, 0.8f, 0.4f}};
+    const int featType[6] = {MAT_LAMBERT, MAT_LAMBERT, MAT_METAL, MAT_METAL, MAT_METAL, MAT_METAL};
+    const float featRough[6] = {0, 0, 0, 0, 0.2f, 0.6f};
+    for (int k = 0; k < 6; ++k) {
+        sphere((float)(2 - 2 * (k % 3)), 0, k < 3 ? -1.0f : 1.0f, 0.5f);
+        mat(featType[k], featAlb[k][0], featAlb[k][1], featAlb[k][2], 0, 0, 0, featRough[k], 0);
+    }
+    sphere(0.5f, 1, 0.5f, 0.5f);
+    mat(MAT_DIELECTRIC, 0.4f, 0.4f, 0.4f, 0, 0, 0, 0, 1.5f);
+    sphere(-1.5f, 1.5f, 0.f, 0.3f);
+    mat(MAT_LAMBERT, 0.8f, 0.6f, 0.2f, 30, 25, 15, 0, 0);
+    for (int row = 0; row < 4; ++row)
+        for (int k = 0; k < 9; ++k) {
+            sphere((float)(4 - k), 0, (float)(-3 - row), 0.5f);
+            if (row == 0) mat(MAT_LAMBERT, grey[k], grey[k], grey[k], 0, 0, 0, 0, 0);
+            if (row == 1) mat(MAT_METAL, grey[k], grey[k], grey[k], 0, 0, 0, 0, 0);
+            if (row == 2) mat(MAT_METAL, hue[k][0], hue[k][1], hue[k][2], 0, 0, 0, 0, 0);
+            if (row == 3) mat(k < 8 ? MAT_LAMBERT : MAT_METAL, hue[k][0], hue[k][1], hue[k][2], 0, 0, 0, 0, 0);
+        }
+    sphere(1.5f, 1.5f, -2, 0.3f);
+    mat(MAT_LAMBERT, 0.1f, 0.2f, 0.5f, 3, 10, 20, 0, 0);
+}
+
+// ---- packed arrays the kernels read
+struct PackedScene {
+    std::vector<float> pairs; // [nPairs][8]
+    std::vector<f4> sph4;     // [nPairs*2]
+    std::vector<float> invR;  // [nPairs*2]
+    std::vector<f4> mats;     // [n][3]
+    std::vector<f4> lights;   // [nLights][2]
+    std::vector<int> emissive; // ids, as GetSceneDesc exports them (Test.cpp:382)
+    int nSpheres = 0, nPairs = 0, nLights = 0;
+};
+
+// UpdateTest's scene half (Test.cpp:321-339): derived data, SoA, emissive list -- in kernel layout.
+inline void packScene(std::vector<SpherePOD>& S, const std::vector<MaterialPOD>& M, PackedScene& P)
+{
+    const int n = (int)S.size();
+    const int nPairs = (n + 1) / 2, nPad = nPairs * 2;
+    P.nSpheres = n;
+    P.nPairs = nPairs;
+    P.pairs.assign((size_t)nPairs * 8, 0.0f);
+    f4 zero = {0, 0, 0, 0};
+    P.sph4.assign((size_t)nPad, zero);
+    P.invR.assign((size_t)nPad, 0.0f);
+    P.mats.assign((size_t)n * 3, zero);
+    P.lights.clear();
+    P.emissive.clear();
+    const float negInf = u2f(0xff800000u);
+    for (int i = 0; i < nPad; ++i) {
+        float cx = 0, cy = 0, cz = 0, sq = negInf; // padding sphere: discriminant = -inf, never a candidate
+        if (i < n) {
+            S[i].invRadius = 1.0f / S[i].radius; // Sphere::UpdateDerivedData, Maths.h:359
+            cx = S[i].cx; cy = S[i].cy; cz = S[i].cz;
+            sq = S[i].radius * S[i].radius; // Test.cpp:329
+            P.invR[i] = S[i].invRadius;
+            f4 v = {cx, cy, cz, sq};
+            P.sph4[i] = v;
+            const MaterialPOD& m = M[i];
+            f4 m0 = {m.albedo[0], m.albedo[1], m.albedo[2], u2f((uint32_t)m.type)};
+            f4 m1 = {m.emissive[0], m.emissive[1], m.emissive[2], m.roughness};
+            f4 m2 = {m.ri, 0, 0, 0};
+            P.mats[(size_t)i * 3] = m0;
+            P.mats[(size_t)i * 3 + 1] = m1;
+            P.mats[(size_t)i * 3 + 2] = m2;
+            if (m.emissive[0] > 0 || m.emissive[1] > 0 || m.emissive[2] > 0) { // Test.cpp:334
+                f4 l0 = {cx, cy, cz, S[i].radius};
+                f4 l1 = {m.emissive[0], m.emissive[1], m.emissive[2], u2f((uint32_t)i)};
+                P.lights.push_back(l0);
+                P.lights.push_back(l1);
+                P.emissive.push_back(i);
+            }
+        } else {
+            f4 v = {cx, cy, cz, sq};
+            P.sph4[i] = v;
+        }
+        float* rec = &P.pairs[(size_t)(i / 2) * 8];
+        rec[0 + (i & 1)] = cx;
+        rec[2 + (i & 1)] = cy;
+        rec[4 + (i & 1)] = cz;
+        rec[6 + (i & 1)] = sq;
+    }
+    P.nLights = (int)P.emissive.size();
+}
+
+inline SceneView viewOf(const PackedScene& P)
+{
+    SceneView sv;
+    sv.pairs = P.pairs.data();
+    sv.sph4 = P.sph4.data();
+    sv.invR = P.invR.data();
+    sv.mats = P.mats.data();
+    sv.lights = P.lights.data();
+    sv.nSpheres = P.nSpheres;
+    sv.nPairs = P.nPairs;
+    sv.nLights = P.nLights;
+    return sv;
+}
+
+inline FrameConsts makeFrameConsts(const CameraPOD& cam, int w, int h, int spp, int frame, unsigned flags, int seedMode)
+{
+    FrameConsts fc;
+    fc.cam = cam;
+    fc.width = w;
+    fc.height = h;
+    fc.spp = spp;
+    fc.frame = frame;
+    fc.invWidth = 1.0f / w;   // Test.cpp:270
+    fc.invHeight = 1.0f / h;  // Test.cpp:271
+    float lerpFac = float(frame) / float(frame + 1); // Test.cpp:272
+    if (flags & 1u) lerpFac *= 0.9f;                 // kFlagAnimate * DO_ANIMATE_SMOOTHING, Test.cpp:273-274
+    if (!(flags & 2u)) lerpFac = 0;                  // !kFlagProgressive, Test.cpp:275-276
+    fc.lerpFac = lerpFac;
+    fc.invSpp = 1.0f / float(spp); // Test.cpp:291
+    fc.seedMode = seedMode;
+    return fc;
+}
+
+} // namespace tpt

@@ -1,0 +1,437 @@
+// tpt_trace.h -- per-lane path-tracing logic of the MI355X renderer (HitSpheres, Scatter, Trace).
+//
+// Replaces the reference's L2 hot path (Cpp/Source/Test.cpp: HitWorld :76, Scatter :83-193,
+// Trace :195-234, TraceRowJob :266-300; Maths.cpp HitSpheres :165-202; Camera::GetRay Maths.h:437)
+// with a design made for a 64-lane wavefront instead of a recursive CPU call tree:
+//
+//  * Trace's recursion and Scatter's shadow-ray loop are flattened into ONE state machine per lane
+//    (`laneStep`): every step intersects exactly one ray (camera, bounce or shadow ray) with the
+//    whole scene and then advances the lane's path.  All lanes of a wave therefore share the
+//    expensive part (the sphere loop) every step, whatever their path depth or material.
+//  * HitSpheres is two-phase.  Phase 1 is branch-free and wave-uniform: for every sphere pair the
+//    discriminant is computed with packed fp32 ops on scene data held in SGPRs (s_load), and only
+//    its sign bit is kept (v_alignbit into a 64-bit candidate mask per lane).  Phase 2 walks the few
+//    set bits of each lane (typically 1-4 of 46), gathers that sphere from LDS, recomputes the
+//    identical discriminant and does sqrt / nearest-hit bookkeeping.  Scanning candidates in
+//    ascending index with a strict `t < hitT` reproduces the reference's tie-break (lowest id).
+//  * Results are bit-identical to the reference CPU scalar path: same operation order, no FMA
+//    contraction, explicit RNG draw order, libm-free sin/cos/pow5 (tpt_math.h).
+//
+// Plain C++ shared by the gfx950 kernels (tpt_kernels.hip) and by the host-compiled lane-logic
+// test in tests/ (never by the shipped library on the CPU).
+#pragma once
+#include "tpt_math.h"
+
+namespace tpt {
+
+#if defined(__clang__)
+typedef float v2f __attribute__((ext_vector_type(2)));
+#else
+typedef float v2f __attribute__((vector_size(8)));
+#endif
+struct alignas(16) f4 {
+    float x, y, z, w;
+};
+
+#define TPT_MIN_T 0.001f // kMinT, Test.cpp:71
+#define TPT_MAX_T 1.0e7f // kMaxT, Test.cpp:72
+#define TPT_MAX_DEPTH 10 // kMaxDepth, Test.cpp:73
+
+enum { MAT_LAMBERT = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2 }; // Test.cpp:38
+enum { SEED_ROW_SERIAL = 0, SEED_PER_PIXEL = 1 };            // Test.cpp:280 / ComputeShader.hlsl:380
+enum { FOLD_RECURSIVE = 0, FOLD_FORWARD = 1 };               // Test.cpp:216 nesting / front-to-back
+enum { HS_TWO_PHASE = 0, HS_SIMPLE = 1 };
+
+// Camera: byte-for-byte the reference layout (Maths.h:444-449, 88 B) so GetSceneDesc can memcpy it.
+struct CameraPOD {
+    float origin[3], lowerLeftCorner[3], horizontal[3], vertical[3], uu[3], vv[3], ww[3];
+    float lensRadius;
+};
+
+// Device-side view of the scene (all arrays built on the host by tptUpdate, see tpt_host.cpp).
+//   pairs  : phase-1 stream, one 32-B record per sphere PAIR {cx0,cx1, cy0,cy1, cz0,cz1, sq0,sq1};
+//            wave-uniform reads -> scalar loads; odd counts are padded with sq = -inf (never hit)
+//   sph4   : {cx,cy,cz,sqRadius} per sphere for the phase-2 gather (staged into LDS by the kernel)
+//   invR   : 1/radius per sphere (Maths.h:359)
+//   mats   : 3 x f4 per sphere {albedo.xyz,type} {emissive.xyz,roughness} {ri,-,-,-}
+//   lights : 2 x f4 per emissive sphere {cx,cy,cz,radius} {emissive.xyz, id}
+struct SceneView {
+    const float* pairs;
+    const f4* sph4;
+    const float* invR;
+    const f4* mats;
+    const f4* lights;
+    int nSpheres, nPairs, nLights;
+};
+
+struct FrameConsts {
+    CameraPOD cam;
+    int width, height;
+    int spp, frame;
+    float invWidth, invHeight;
+    float lerpFac;  // Test.cpp:272-276, computed on the host
+    float invSpp;   // 1.0f / float(spp), Test.cpp:291
+    int seedMode;
+};
+
+TPT_HD f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
+
+TPT_HD uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+    return (uint32_t)(((((uint64_t)hi) << 32) | lo) >> sh);
+#endif
+}
+
+// ---------------------------------------------------------------- HitSpheres (Maths.cpp:165-202)
+// exact per-sphere test shared by both variants; expression order is the reference's (:171-190)
+TPT_HD void testSphere(f4 s, int i, f3 o, f3 d, float tMin, float& hitT, int& id)
+{
+    float coX = s.x - o.x;
+    float coY = s.y - o.y;
+    float coZ = s.z - o.z;
+    float nb = coX * d.x + coY * d.y + coZ * d.z;
+    float c = coX * coX + coY * coY + coZ * coZ - s.w;
+    float discr = nb * nb - c;
+    if (discr > 0) {
+        float discrSq = tsqrt(discr);
+        float t = nb - discrSq;
+        if (t <= tMin) t = nb + discrSq;
+        if (t > tMin && t < hitT) {
+            id = i;
+            hitT = t;
+        }
+    }
+}
+
+TPT_HD int hitSpheresSimple(const SceneView& sv, f3 o, f3 d, float tMin, float tMax, float& outT)
+{
+    float hitT = tMax;
+    int id = -1;
+    for (int i = 0; i < sv.nSpheres; ++i) testSphere(sv.sph4[i], i, o, d, tMin, hitT, id);
+    outT = hitT;
+    return id;
+}
+
+TPT_HD void phase1Pair(const float* __restrict__ rec, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f dz, uint32_t& m)
+{
+    v2f cx = {rec[0], rec[1]}, cy = {rec[2], rec[3]}, cz = {rec[4], rec[5]}, sq = {rec[6], rec[7]};
+    v2f coX = cx - ox;
+    v2f coY = cy - oy;
+    v2f coZ = cz - oz;
+    v2f nb = coX * dx + coY * dy + coZ * dz;
+    v2f c = coX * coX + coY * coY + coZ * coZ - sq;
+    v2f discr = nb * nb - c;
+    m = alignbit(m, f2u(discr[0]), 31); // m = (m << 1) | sign(discr)
+    m = alignbit(m, f2u(discr[1]), 31);
+}
+
+TPT_HD int hitSpheresTwoPhase(const SceneView& sv, f3 o, f3 d, float tMin, float tMax, float& outT)
+{
+    float hitT = tMax;
+    int id = -1;
+    const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+    const v2f dx = {d.x, d.x}, dy = {d.y, d.y}, dz = {d.z, d.z};
+    for (int pb = 0; pb < sv.nPairs; pb += 32) { // chunks of 64 spheres
+        int cnt = sv.nPairs - pb;
+        if (cnt > 32) cnt = 32;
+        const int c0 = cnt < 16 ? cnt : 16, c1 = cnt - c0;
+        const float* __restrict__ rec = sv.pairs + (size_t)pb * 8;
+        uint32_t m0 = 0, m1 = 0;
+#pragma unroll 4
+        for (int p = 0; p < c0; ++p) phase1Pair(rec + p * 8, ox, oy, oz, dx, dy, dz, m0);
+#pragma unroll 4
+        for (int p = 0; p < c1; ++p) phase1Pair(rec + (16 + p) * 8, ox, oy, oz, dx, dy, dz, m1);
+        // candidates = sign bit clear (discr >= +0); sphere (pb*2 + k) sits at bit (63-k)
+        uint32_t cand0 = ~m0 << (32 - 2 * c0);
+        uint32_t cand1 = c1 ? (~m1 << (32 - 2 * c1)) : 0u;
+        uint64_t cand = ((uint64_t)cand0 << 32) | cand1;
+        while (cand) {
+            int k = __builtin_clzll(cand);
+            cand &= ~(0x8000000000000000ull >> k);
+            int i = pb * 2 + k;
+            testSphere(sv.sph4[i], i, o, d, tMin, hitT, id);
+        }
+    }
+    outT = hitT;
+    return id;
+}
+
+template <int HS>
+TPT_HD int hitSpheres(const SceneView& sv, f3 o, f3 d, float tMin, float tMax, float& outT)
+{
+    if (HS == HS_SIMPLE) return hitSpheresSimple(sv, o, d, tMin, tMax, outT);
+    return hitSpheresTwoPhase(sv, o, d, tMin, tMax, outT);
+}
+
+// ---------------------------------------------------------------- camera (Maths.h:437-442) / sky (Test.cpp:229-231)
+TPT_HD void cameraGetRay(const CameraPOD& c, float s, float t, uint32_t& state, f3& orig, f3& dir)
+{
+    f3 rd = c.lensRadius * randomInUnitDisk(state);
+    f3 offset = ld3(c.uu) * rd.x + ld3(c.vv) * rd.y;
+    orig = ld3(c.origin) + offset;
+    dir = normalize(ld3(c.lowerLeftCorner) + s * ld3(c.horizontal) + t * ld3(c.vertical) - ld3(c.origin) - offset);
+}
+TPT_HD f3 sky(f3 dir)
+{
+    float t = 0.5f * (dir.y + 1.0f);
+    return ((1.0f - t) * mk3(1.0f, 1.0f, 1.0f) + t * mk3(0.5f, 0.7f, 1.0f)) * 0.3f;
+}
+
+// ---------------------------------------------------------------- the per-lane state machine
+enum { KIND_MAIN = 0, KIND_SHADOW = 1 };
+
+struct Lane {
+    uint32_t rng;
+    int x, y;     // pixel in full-image coordinates (y = 0 is the bottom row, Test.cpp:287)
+    int pix;      // float4 index into the (local) backbuffer
+    int sample, depth;
+    int kind, j, hitId, hitType;
+    bool active, needCamera, doMatE;
+    f3 orig, dir;                              // the ray the next step intersects
+    f3 sdir, nl, albedo, lightE, matE;         // Lambert light-loop context (Test.cpp:89-134)
+    float cosAMax;
+    f3 col;                                    // sum over samples (Test.cpp:283-290)
+    f3 prev;                                   // previous frame's RGB of this pixel (loaded early by the caller)
+    f3 radiance, throughput;                   // FOLD_FORWARD
+    int sp;                                    // FOLD_RECURSIVE: entries on the bounce stack
+    uint32_t rays;
+};
+
+// Bounce stack for FOLD_RECURSIVE: entry d = {matE+lightE (xyz), attenuation id}.  attId >= 0 ->
+// attenuation = albedo of material attId, -1 -> (1,1,1) (dielectric, Test.cpp:158).
+// Device: LDS, laid out [level][thread]; host test: plain array.
+struct BounceStack {
+    f4* base;
+    int stride; // elements between consecutive levels
+    TPT_HD void push(int level, f3 e, int attId) const
+    {
+        f4 v;
+        v.x = e.x; v.y = e.y; v.z = e.z; v.w = u2f((uint32_t)attId);
+        base[level * stride] = v;
+    }
+    TPT_HD f4 get(int level) const { return base[level * stride]; }
+};
+
+TPT_HD uint32_t pixelSeed(int seedMode, int x, int y, int frame)
+{
+    if (seedMode == SEED_PER_PIXEL) // ComputeShader.hlsl:380
+        return ((uint32_t)x * 1973u + (uint32_t)y * 9277u + (uint32_t)frame * 26699u) | 1u;
+    return ((uint32_t)y * 9781u + (uint32_t)frame * 6271u) | 1u; // Test.cpp:280 (row start)
+}
+
+// Start a pixel.  In ROW_SERIAL mode only the first pixel of a row reseeds (reseed = true).
+TPT_HD void laneBeginPixel(Lane& L, const FrameConsts& fc, int x, int y, int pix, bool reseed)
+{
+    L.x = x; L.y = y; L.pix = pix;
+    if (reseed) L.rng = pixelSeed(fc.seedMode, x, y, fc.frame);
+    L.sample = 0;
+    L.col = mk3(0, 0, 0);
+    L.needCamera = true;
+    L.active = true;
+}
+
+// One step: intersect one ray, advance the path.  Returns true when the lane's pixel is complete
+// (L.col then holds the sum over spp samples; the caller blends and stores).
+template <int HS, int FOLD>
+TPT_HD bool laneStep(Lane& L, const SceneView& sv, const FrameConsts& fc, const BounceStack& stack)
+{
+    // ---- new sample: camera ray (Test.cpp:286-289)
+    if (L.needCamera) {
+        float u = ((float)L.x + rnd01(L.rng)) * fc.invWidth;
+        float v = ((float)L.y + rnd01(L.rng)) * fc.invHeight;
+        cameraGetRay(fc.cam, u, v, L.rng, L.orig, L.dir);
+        L.depth = 0;
+        L.doMatE = true;
+        L.kind = KIND_MAIN;
+        L.needCamera = false;
+        if (FOLD == FOLD_FORWARD) {
+            L.radiance = mk3(0, 0, 0);
+            L.throughput = mk3(1, 1, 1);
+        } else {
+            L.sp = 0;
+        }
+    }
+
+    // ---- HitWorld (Test.cpp:76; counted at Test.cpp:122 and :199)
+    float t;
+    const int id = hitSpheres<HS>(sv, L.orig, L.dir, TPT_MIN_T, TPT_MAX_T, t);
+    L.rays++;
+
+    bool lightLoop = false, finish = false, bounce = false;
+    f3 term = mk3(0, 0, 0), newDir = mk3(0, 0, 0), bounceE = mk3(0, 0, 0), atten = mk3(1, 1, 1);
+    int attId = -1;
+
+    if (L.kind == KIND_SHADOW) {
+        // ---- shadow ray came back (Test.cpp:123-132)
+        f4 l0 = sv.lights[L.j * 2], l1 = sv.lights[L.j * 2 + 1];
+        if (id == (int)f2u(l1.w)) {
+            float omega = 2 * TPT_PI * (1 - L.cosAMax);
+            float dln = dot(L.dir, L.nl);
+            float mx = 0.0f < dln ? dln : 0.0f; // std::max(0.0f, dln)
+            L.lightE = L.lightE + (L.albedo * mk3(l1.x, l1.y, l1.z)) * (mx * omega / TPT_PI);
+        }
+        (void)l0;
+        L.j++;
+        lightLoop = true;
+    } else if (id < 0) {
+        term = sky(L.dir); // Test.cpp:229-231
+        finish = true;
+    } else {
+        // ---- hit: finish HitSpheres (Maths.cpp:195-197), then Scatter (Test.cpp:83-193)
+        f4 s = sv.sph4[id];
+        f3 pos = L.orig + L.dir * t;
+        f3 normal = (pos - mk3(s.x, s.y, s.z)) * sv.invR[id];
+        f4 m0 = sv.mats[id * 3], m1 = sv.mats[id * 3 + 1];
+        int type = (int)f2u(m0.w);
+        f3 albedo = mk3(m0.x, m0.y, m0.z), matE = mk3(m1.x, m1.y, m1.z);
+        if (L.depth >= TPT_MAX_DEPTH) { // Test.cpp:207 -> :220
+            term = matE;
+            finish = true;
+        } else if (type == MAT_LAMBERT) { // Test.cpp:86-136
+            f3 target = pos + normal + randomUnitVector(L.rng);
+            L.sdir = normalize(target - pos);
+            L.albedo = albedo;
+            L.nl = dot(normal, L.dir) < 0 ? normal : -normal; // Test.cpp:129 (uses r_in.dir)
+            L.lightE = mk3(0, 0, 0);
+            L.matE = L.doMatE ? matE : mk3(0, 0, 0); // Test.cpp:210
+            L.hitId = id;
+            L.j = 0;
+            L.orig = pos;
+            lightLoop = true;
+        } else if (type == MAT_METAL) { // Test.cpp:137-150
+            f3 refl = reflect(L.dir, normal);
+            newDir = normalize(refl + m1.w * randomInUnitSphere(L.rng));
+            if (dot(newDir, normal) > 0) {
+                bounce = true;
+                atten = albedo;
+                attId = id;
+                bounceE = L.doMatE ? matE : mk3(0, 0, 0);
+                L.orig = pos;
+            } else {
+                term = matE; // Test.cpp:220 (emission NOT zeroed on scatter failure)
+                finish = true;
+            }
+        } else if (type == MAT_DIELECTRIC) { // Test.cpp:151-186
+            float ri = sv.mats[id * 3 + 2].x;
+            f3 rdir = L.dir;
+            f3 refl = reflect(rdir, normal);
+            f3 outwardN, refr = mk3(0, 0, 0);
+            float nint, cosine, reflProb;
+            float dn = dot(rdir, normal);
+            if (dn > 0) {
+                outwardN = -normal;
+                nint = ri;
+                cosine = ri * dn;
+            } else {
+                outwardN = normal;
+                nint = 1.0f / ri;
+                cosine = -dn;
+            }
+            if (refract(rdir, outwardN, nint, refr))
+                reflProb = schlick(cosine, ri);
+            else
+                reflProb = 1;
+            if (rnd01(L.rng) < reflProb)
+                newDir = normalize(refl);
+            else
+                newDir = normalize(refr);
+            bounce = true;
+            atten = mk3(1, 1, 1);
+            attId = -1;
+            bounceE = L.doMatE ? matE : mk3(0, 0, 0);
+            L.orig = pos;
+        } else { // Test.cpp:187-191
+            term = matE;
+            finish = true;
+        }
+        L.hitType = type;
+    }
+
+    // ---- Lambert light sampling loop (Test.cpp:96-133), one emissive sphere per step
+    if (lightLoop) {
+        while (L.j < sv.nLights && (int)f2u(sv.lights[L.j * 2 + 1].w) == L.hitId) L.j++; // skip self (:100)
+        if (L.j < sv.nLights) {
+            f4 l0 = sv.lights[L.j * 2];
+            f3 sc = mk3(l0.x, l0.y, l0.z);
+            f3 sw = normalize(sc - L.orig);
+            f3 su = normalize(cross((sw.x < 0 ? -sw.x : sw.x) > 0.01f ? mk3(0, 1, 0) : mk3(1, 0, 0), sw));
+            f3 sv_ = cross(sw, su);
+            L.cosAMax = tsqrt(1.0f - l0.w * l0.w / sqLength(L.orig - sc));
+            float eps1 = rnd01(L.rng), eps2 = rnd01(L.rng);
+            float cosA = 1.0f - eps1 + eps1 * L.cosAMax;
+            float sinA = tsqrt(1.0f - cosA * cosA);
+            float phi = 2 * TPT_PI * eps2;
+            float sn, cs;
+            tsincosf(phi, sn, cs);
+            L.dir = su * (cs * sinA) + sv_ * (sn * sinA) + sw * cosA;
+            L.kind = KIND_SHADOW;
+        } else {
+            bounce = true;
+            newDir = L.sdir;
+            atten = L.albedo;
+            attId = L.hitId;
+            bounceE = L.matE;
+            L.hitType = MAT_LAMBERT;
+        }
+    }
+
+    // ---- Scatter succeeded: Test.cpp:210-216
+    if (bounce) {
+        if (L.hitType == MAT_LAMBERT) bounceE = bounceE + L.lightE; // matE + lightE (lightE == 0 otherwise)
+        L.doMatE = (L.hitType != MAT_LAMBERT);
+        if (FOLD == FOLD_FORWARD) {
+            L.radiance = L.radiance + L.throughput * bounceE;
+            L.throughput = L.throughput * atten;
+        } else {
+            stack.push(L.sp, bounceE, attId);
+            L.sp++;
+        }
+        L.dir = newDir;
+        L.depth++;
+        L.kind = KIND_MAIN;
+    }
+
+    // ---- path ended: fold the colour, next sample or pixel done
+    if (finish) {
+        f3 c;
+        if (FOLD == FOLD_FORWARD) {
+            c = L.radiance + L.throughput * term;
+        } else {
+            c = term;
+            for (int lv = L.sp - 1; lv >= 0; --lv) { // matE + lightE + attenuation * Trace(...), Test.cpp:216
+                f4 e = stack.get(lv);
+                int a = (int)f2u(e.w);
+                f3 at = mk3(1, 1, 1);
+                if (a >= 0) {
+                    f4 m0 = sv.mats[a * 3];
+                    at = mk3(m0.x, m0.y, m0.z);
+                }
+                c = mk3(e.x, e.y, e.z) + at * c;
+            }
+        }
+        L.col = L.col + c;
+        L.sample++;
+        if (L.sample < fc.spp)
+            L.needCamera = true;
+        else
+            return true;
+    }
+    return false;
+}
+
+// Blend with the previous frame (L.prev, read when the pixel was started: the reference reads it even when
+// lerpFac == 0, Test.cpp:293) and store RGB; alpha is never written (Test.cpp:291-296, Maths.h:38).
+TPT_HD void laneStorePixel(const Lane& L, const FrameConsts& fc, float* backbuffer)
+{
+    f3 col = L.col * fc.invSpp;
+    float* p = backbuffer + (size_t)L.pix * 4;
+    col = L.prev * fc.lerpFac + col * (1 - fc.lerpFac);
+    p[0] = col.x;
+    p[1] = col.y;
+    p[2] = col.z;
+}
+
+} // namespace tpt

@@ -1,0 +1,226 @@
+#!/usr/bin/env python
+"""bench.py -- Mray/s of the Trace/HitWorld/Scatter hot path on MI355X (BASELINE.json's metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = UpdateTest + DrawTest of ONE frame of the workload (default: BASELINE.json configs[1],
+1280x720, 4 spp, built-in 46-sphere scene, progressive accumulation on), with the accumulation
+buffer resident in HBM when the timed region starts.  Mray/s = rays (HitWorld calls: camera + bounce +
+shadow, exactly the reference's counter, Test.cpp:122,199) of the K timed frames, summed over all
+ranks, divided by the max-over-ranks wall time between two barrier+synchronize brackets.
+For N > 1 the frame's rows are dealt out in 8-row stripes round-robin over the ranks
+(toypathtracer_amd/sharding.py); every step includes its exchange (one RCCL gather of the tiles to
+rank 0 + one 8-byte sum-reduce of the ray counters), software-pipelined against the next frame.
+Total work is fixed as N grows -> "scaling": "strong".
+
+One JSON line on rank 0, with
+  roofline     : the trace kernel against the HBM roofline the north_star names (algorithmic bytes =
+                 W*H*16 B written per frame) -- plus the FP32 VALU fraction, which is what actually binds;
+                 durations from HIP events on the kernel's stream over the timed region;
+  cpu_baseline : the pristine reference (oracle/_ref, SIMD path, all host cores via enkiTS) timed on
+                 the same workload for a bounded ~10 s sample, rank 0 at N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # name: (width, height, spp, scene, label)
+    "c2": (1280, 720, 4, "default", "configs[1]: default 46-sphere scene, 1280x720, 4 spp/frame, progressive"),
+    "c3": (3840, 2160, 16, "default", "configs[2]: default 46-sphere scene, 3840x2160, 16 spp/frame, progressive"),
+    "c5": (1920, 1080, 8, "stress", "configs[4]: stress scene 4096 spheres, 1920x1080, 8 spp/frame, progressive"),
+    "c1": (640, 360, 1, "default", "configs[0]: default scene, 640x360, 1 spp"),
+}
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PEAK_FP32_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector (counts FMA as 2)
+FLOP_PER_SPHERE_TEST = 17      # per (ray, sphere) test
+FLAG_PROGRESSIVE = 2
+
+
+def cpu_baseline(width, height, spp, budget_s=10.0):
+    """Times the checker/reference on the host cores (reported baseline, never the product path)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import Oracle, Ref
+    cores = os.cpu_count() or 1
+    if Ref.available("simd"):
+        ref = Ref.get("simd")
+        ref.set_spp(spp)
+        bb = np.zeros((height, width, 4), np.float32)
+        rays, frames, t0 = 0, 0, time.perf_counter()
+        ref.update(0.0, 0, width, height, FLAG_PROGRESSIVE)
+        ref.draw(0.0, 0, width, height, bb, FLAG_PROGRESSIVE)  # warm-up frame (threads start)
+        t0 = time.perf_counter()
+        while True:
+            ref.update(0.0, frames + 1, width, height, FLAG_PROGRESSIVE)
+            rays += ref.draw(0.0, frames + 1, width, height, bb, FLAG_PROGRESSIVE)
+            frames += 1
+            if time.perf_counter() - t0 > budget_s or frames >= 200:
+                break
+        dt = time.perf_counter() - t0
+        return dict(value=rays / dt / 1e6, unit="Mray/s", cores=cores, kind="reference",
+                    sample="%d frames of %dx%dx%dspp, pristine reference SIMD path + enkiTS (oracle/_ref/libtpt_ref.so, "
+                           "-O2 -msse4.1 -ffp-contract=off), %.1f s" % (frames, width, height, spp, dt))
+    o = Oracle.get()
+    s, m = o.default_scene()
+    cam = o.default_camera(width, height)
+    bb = np.zeros((height, width, 4), np.float32)
+    rays, frames, t0 = 0, 0, time.perf_counter()
+    while time.perf_counter() - t0 < budget_s:
+        r, _ = o.render(s, m, cam, width, height, spp, frames, backbuffer=bb)
+        rays += r
+        frames += 1
+    dt = time.perf_counter() - t0
+    return dict(value=rays / dt / 1e6, unit="Mray/s", cores=cores, kind="port",
+                sample="%d frames of %dx%dx%dspp, oracle/tpt_oracle.c (OpenMP over rows), %.1f s" % (frames, width, height, spp, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--stripe-rows", type=int, default=8)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hit-spheres", type=int, default=0, help="0 two-phase (default) 1 simple")
+    ap.add_argument("--persistent", type=int, default=1)
+    ap.add_argument("--fold", type=int, default=0, help="0 recursive (reference order, default) 1 forward")
+    ap.add_argument("--lds-scene", type=int, default=-1)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    os.environ.setdefault("TPT_DEVICE", str(local_rank))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from toypathtracer_amd import api
+    from toypathtracer_amd.sharding import ShardedFrame
+
+    width, height, spp, scene, label = WORKLOADS[args.workload]
+    api.InitializeTest()
+    api.set_samples_per_pixel(spp)
+    api.set_fold_mode(args.fold)
+    api.set_kernel_variant(args.hit_spheres, args.persistent, args.lds_scene)
+    n_spheres = 46
+    if scene == "stress":
+        from toypathtracer_amd.scenes import STRESS_CAMERA, stress_scene
+        s, m = stress_scene(4096, 64)
+        api.set_scene(s, m)
+        api.set_camera(**STRESS_CAMERA)
+        n_spheres = 4096
+    api.set_row_shard(args.stripe_rows, world, rank)
+
+    sf = ShardedFrame(width, height, args.stripe_rows, rank, world, device, dist)
+    api.set_stream(sf.render_stream.cuda_stream)
+    api.set_ray_counter(sf.ray_counter.data_ptr())
+    tile_ptr = sf.tile.data_ptr()
+
+    def step(frame):
+        api.UpdateTest(0.0, frame, width, height, FLAG_PROGRESSIVE)
+        api.draw_device(0.0, frame, width, height, tile_ptr, FLAG_PROGRESSIVE)
+        sf.exchange()
+
+    def fence():
+        sf.render_stream.synchronize()
+        sf.comm_stream.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for f in range(args.warmup):
+        step(f)
+    fence()
+    rays0 = int(sf.ray_counter.item())
+    api.timer_begin()                     # HIP events on the kernel's stream
+    t0 = time.perf_counter()
+    for f in range(args.warmup, args.warmup + args.steps):
+        step(f)
+    kernel_ms = api.timer_end()           # records + synchronises the end event on the render stream
+    fence()
+    dt = time.perf_counter() - t0
+    rays_local = int(sf.ray_counter.item()) - rays0
+    image, _total = sf.finish()
+
+    stats = torch.tensor([dt, float(rays_local), kernel_ms], dtype=torch.float64, device=device)
+    if dist is not None:
+        tmax = stats.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = stats.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt, rays_total, kernel_ms = float(tmax[0]), float(tsum[1]), float(tmax[2])
+    else:
+        rays_total = float(rays_local)
+
+    if rank == 0:
+        info = api.launch_info()
+        k_ms = kernel_ms / args.steps                      # average duration of one trace launch (this rank's rows)
+        px = width * height / world                        # pixels one launch of one rank covers
+        rays_per_launch = rays_total / args.steps / world
+        hbm_write_gbs = px * 16 / (k_ms * 1e-3) / 1e9      # 16 B written per pixel
+        valu_tflops = rays_per_launch * FLOP_PER_SPHERE_TEST * n_spheres / (k_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get(args.workload)
+        out = {
+            "metric": "Mray/s", "value": rays_total / dt / 1e6, "unit": "Mray/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": label, "width": width, "height": height, "spp": spp, "spheres": n_spheres,
+                       "seed_mode": "per_pixel", "fold": "forward" if args.fold else "recursive",
+                       "hit_spheres": "simple" if args.hit_spheres else "two_phase", "persistent": bool(args.persistent),
+                       "sharding": "none" if world == 1 else "row stripes of %d, round-robin over %d ranks, pipelined gather to rank 0" % (args.stripe_rows, world),
+                       "device": api.device_name(), "grid_blocks": info["grid_blocks"], "blocks_per_cu": info["blocks_per_cu"],
+                       "lds_bytes_per_block": info["lds_bytes"]},
+            "rays_per_step": rays_total / args.steps,
+            "kernel_ms_per_step": k_ms,
+            "kernel_Mray_s": rays_per_launch * world / (k_ms * 1e-3) / 1e6,
+            "roofline": {"bound": "hbm", "achieved": hbm_write_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": hbm_write_gbs / PEAK_HBM_GBS, "traffic": traffic,
+                         "achieved_read_plus_write": 2 * hbm_write_gbs,
+                         "note": "north_star's HBM-write roofline (W*H*16 B per frame / kernel time); the kernel is FP32-VALU bound "
+                                 "(arithmetic intensity ~440 flop/B), see roofline_valu",
+                         "kernel": "tptTraceKernel"},
+            "roofline_valu": {"bound": "valu_fp32", "achieved": valu_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                              "frac": valu_tflops / PEAK_FP32_TFLOPS,
+                              "note": "algorithmic flops = rays x 17 flop x spheres (SURVEY 8d); peak counts FMA as 2 flop and the "
+                                      "parity contract forbids FMA contraction, so the reachable ceiling is 78.6 T non-fused op/s"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(width, height, spp)
+        print(json.dumps(out), flush=True)
+
+    api.set_ray_counter(None)
+    api.set_stream(None)
+    api.ShutdownTest()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -91,6 +91,10 @@ int tptLocalRowToGlobal(int localRow);
 int tptDrawDevice(float time, int frameCount, int screenWidth, int screenHeight, float* deviceTile, unsigned testFlags);
 /* Synchronise the stream and return the monotonic total of rays traced by this context. */
 int tptRayCounterRead(int64_t* outTotalRays);
+/* Let the caller own the ray counter: `deviceU64` points to one zero-initialised 64-bit word in device
+ * memory (e.g. a torch int64 tensor) that the kernels atomically add to; NULL -> the internal counter.
+ * Lets the multi-GPU host sum-reduce the counters with RCCL without a host round trip. */
+int tptSetRayCounter(void* deviceU64);
 int tptSynchronize(void);
 /* hipEvent bracket on the context's stream, for kernel-only timing (as the reference times its
  * Dispatch with timestamp queries, TestWin.cpp:299-302). */

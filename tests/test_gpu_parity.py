@@ -1,0 +1,233 @@
+"""GPU parity of the hot path through the C ABI against the oracle and the reference's golden vectors.
+Bit-exact (float buffers compared byte for byte, ray counts equal): the kernels execute the same IEEE
+operation sequence as the reference's CPU scalar path.  BASELINE.json's 1e-4 relative tolerance is
+asserted as well where a different colour fold is selected."""
+import numpy as np
+import pytest
+
+from common import goldens, oracle_frames, rel_err
+from oracle_lib import (FLAG_ANIMATE, FLAG_PROGRESSIVE, FOLD_FORWARD, FOLD_RECURSIVE, SEED_PER_PIXEL, SEED_ROW_SERIAL,
+                        fnv1a)
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_frames(tpt, w, h, frames, flags=FLAG_PROGRESSIVE, time=0.0, bb=None):
+    if bb is None:
+        bb = np.zeros((h, w, 4), np.float32)
+    total, per = 0, []
+    for f in range(frames):
+        tpt.UpdateTest(time, f, w, h, flags)
+        r = tpt.DrawTest(time, f, w, h, bb, flags)
+        total += r
+        per.append(r)
+    return total, bb, per
+
+
+# ---- 1. the reference's golden vectors, reproduced on the GPU in the reference's own seed mode
+@pytest.mark.parametrize("case", [c for c in goldens() if c["width"] <= 640],
+                         ids=lambda c: "%dx%dx%d_f%d_fl%d" % (c["width"], c["height"], c["spp"], c["frames"], c["flags"]))
+def test_row_serial_reproduces_reference_golden_hashes(tpt_defaults, case):
+    tpt = tpt_defaults
+    tpt.set_seed_mode(SEED_ROW_SERIAL)
+    tpt.set_samples_per_pixel(case["spp"])
+    rays, bb, _ = gpu_frames(tpt, case["width"], case["height"], case["frames"], case["flags"], case["time"])
+    assert rays == case["rays"]
+    assert "%08x" % fnv1a(bb) == case["fnv"]
+    assert float(np.abs(bb[..., 3]).max()) == 0.0
+
+
+# ---- 2. production mode (per-pixel seeds) against the oracle, every kernel variant
+@pytest.mark.parametrize("persist", [1, 0], ids=["persistent", "static"])
+@pytest.mark.parametrize("hs", [0, 1], ids=["two_phase", "simple"])
+@pytest.mark.parametrize("fold", [FOLD_RECURSIVE, FOLD_FORWARD], ids=["recursive", "forward"])
+def test_per_pixel_bit_exact_all_variants(tpt_defaults, oracle, persist, hs, fold):
+    tpt = tpt_defaults
+    w, h, spp, frames = 320, 184, 4, 3
+    tpt.set_kernel_variant(hs, persist, -1)
+    tpt.set_fold_mode(fold)
+    rays, bb, per = gpu_frames(tpt, w, h, frames)
+    ro, bo, pero = oracle_frames(oracle, w, h, spp, frames, seed_mode=SEED_PER_PIXEL, fold_mode=fold)
+    assert per == pero
+    assert bb.tobytes() == bo.tobytes()
+    # and BASELINE.json's stated tolerance against the recursive (reference-order) colours
+    _, bref, _ = oracle_frames(oracle, w, h, spp, frames, seed_mode=SEED_PER_PIXEL, fold_mode=FOLD_RECURSIVE)
+    assert rel_err(bb, bref).max() <= 1e-4
+
+
+@pytest.mark.parametrize("w,h,spp", [(203, 117, 4), (64, 8, 1), (8, 8, 16), (1, 1, 4), (333, 5, 2), (17, 260, 3)])
+def test_ragged_sizes_and_spp(tpt_defaults, oracle, w, h, spp):
+    tpt = tpt_defaults
+    tpt.set_samples_per_pixel(spp)
+    rays, bb, per = gpu_frames(tpt, w, h, 2)
+    ro, bo, pero = oracle_frames(oracle, w, h, spp, 2, seed_mode=SEED_PER_PIXEL)
+    assert per == pero and bb.tobytes() == bo.tobytes()
+
+
+def test_lds_scene_off_matches(tpt_defaults, oracle):
+    tpt = tpt_defaults
+    tpt.set_kernel_variant(0, 1, 0)
+    rays, bb, per = gpu_frames(tpt, 160, 96, 2)
+    ro, bo, pero = oracle_frames(oracle, 160, 96, 4, 2, seed_mode=SEED_PER_PIXEL)
+    assert per == pero and bb.tobytes() == bo.tobytes()
+
+
+def test_flags_animate_and_no_progressive(tpt_defaults, oracle):
+    tpt = tpt_defaults
+    for flags, t in [(FLAG_PROGRESSIVE | FLAG_ANIMATE, 0.75), (0, 0.0), (FLAG_ANIMATE, 2.5)]:
+        tpt.set_scene(None)
+        rays, bb, per = gpu_frames(tpt, 160, 96, 3, flags, t)
+        ro, bo, pero = oracle_frames(oracle, 160, 96, 4, 3, flags, t, seed_mode=SEED_PER_PIXEL)
+        assert per == pero and bb.tobytes() == bo.tobytes()
+    tpt.set_scene(None)
+
+
+def test_alpha_untouched_and_prev_is_read(tpt_defaults, oracle):
+    """DrawTest contract: RGB blended in place with the previous contents, alpha never written."""
+    tpt = tpt_defaults
+    w, h = 96, 64
+    rng = np.random.default_rng(0)
+    bb = rng.uniform(0, 1, (h, w, 4)).astype(np.float32)
+    bo = bb.copy()
+    alpha = bb[..., 3].copy()
+    tpt.UpdateTest(0.0, 5, w, h, FLAG_PROGRESSIVE)
+    rays = tpt.DrawTest(0.0, 5, w, h, bb, FLAG_PROGRESSIVE)
+    s, m = oracle.default_scene()
+    ro, _ = oracle.render(s, m, oracle.default_camera(w, h), w, h, 4, 5, seed_mode=SEED_PER_PIXEL, backbuffer=bo)
+    assert rays == ro and bb.tobytes() == bo.tobytes()
+    assert np.array_equal(bb[..., 3], alpha)
+
+
+def test_custom_scene_camera_stress(tpt_defaults, oracle):
+    """BASELINE.json config 5 at test size: 4096 random spheres, 4 lights (64-sphere chunk loop, LDS budget)."""
+    from toypathtracer_amd.scenes import STRESS_CAMERA, stress_scene
+    tpt = tpt_defaults
+    s, m = stress_scene(4096, 64)
+    w, h, spp = 96, 54, 2
+    tpt.set_scene(s, m)
+    tpt.set_camera(**STRESS_CAMERA)
+    tpt.set_samples_per_pixel(spp)
+    rays, bb, per = gpu_frames(tpt, w, h, 2)
+    cam = oracle.camera(STRESS_CAMERA["look_from"], STRESS_CAMERA["look_at"], (0, 1, 0), STRESS_CAMERA["vfov"], w / h,
+                        STRESS_CAMERA["aperture"], STRESS_CAMERA["focus_dist"])
+    ro, bo, pero = oracle_frames(oracle, w, h, spp, 2, spheres=s, mats=m, cam=cam, seed_mode=SEED_PER_PIXEL)
+    assert per == pero and bb.tobytes() == bo.tobytes()
+    # scene export round trip (GetSceneDesc, Test.cpp:377-384)
+    s2, m2, cam2, em = tpt.GetSceneDesc()
+    assert m2.tobytes() == m.tobytes() and list(em) == [1, 2, 3, 4] and cam2.tobytes() == cam.tobytes()
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 63, 64, 65, 129])
+def test_sphere_count_edges(tpt_defaults, oracle, n):
+    from toypathtracer_amd.scenes import stress_scene
+    tpt = tpt_defaults
+    s, m = stress_scene(max(n, 6), 8)
+    s, m = s[:n].copy(), m[:n].copy()
+    tpt.set_scene(s, m)
+    tpt.set_camera((0, 3, 9), (0, 0, 0), 60.0, 0.02, 9.0)
+    rays, bb, per = gpu_frames(tpt, 80, 48, 1)
+    cam = oracle.camera((0, 3, 9), (0, 0, 0), (0, 1, 0), 60.0, 80 / 48, 0.02, 9.0)
+    ro, bo = oracle.render(s, m, cam, 80, 48, 4, 0, seed_mode=SEED_PER_PIXEL)
+    assert rays == ro and bb.tobytes() == bo.tobytes()
+
+
+def test_hit_spheres_kernel_vs_oracle(tpt_defaults, oracle):
+    import ctypes as C
+    tpt = tpt_defaults
+    tpt.UpdateTest(0.0, 0, 64, 64, 2)
+    rng = np.random.default_rng(5)
+    n = 20000
+    o = rng.uniform(-4, 4, (n, 3)).astype(np.float32)
+    o[:, 1] = rng.uniform(0.0, 3.0, n)
+    d = rng.normal(size=(n, 3)).astype(np.float32)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays = np.concatenate([o, d], axis=1).astype(np.float32)
+    s, m = oracle.default_scene()
+    want_id = np.empty(n, np.int32)
+    want_t = np.empty(n, np.float32)
+    t = C.c_float()
+    for i in range(n):
+        want_id[i] = oracle.lib.tpto_hit_spheres(s.ctypes.data, 46, o[i].ctypes.data, d[i].ctypes.data, 0.001, 1.0e7,
+                                                 C.byref(t), None, None)
+        want_t[i] = t.value if want_id[i] >= 0 else np.float32(1.0e7)
+    for hs in (0, 1):
+        ids, ts = tpt.test_hit_spheres(rays, hs)
+        assert np.array_equal(ids, want_id)
+        assert np.array_equal(ts.view(np.uint32), want_t.view(np.uint32))
+
+
+# ---- 3. BASELINE.json's full sizes
+def test_config2_1280x720_4spp_full_parity(tpt_defaults, oracle):
+    """configs[1]: the headline workload; the oracle finishes it in seconds, so compare everything."""
+    tpt = tpt_defaults
+    w, h, spp, frames = 1280, 720, 4, 3
+    rays, bb, per = gpu_frames(tpt, w, h, frames)
+    ro, bo, pero = oracle_frames(oracle, w, h, spp, frames, seed_mode=SEED_PER_PIXEL)
+    assert per == pero and bb.tobytes() == bo.tobytes()
+
+
+def test_config2_row_serial_golden(tpt_defaults):
+    """1280x720x4spp, 3 accumulated frames, reference seed mode: the BASELINE.md golden 16cce49a."""
+    tpt = tpt_defaults
+    tpt.set_seed_mode(SEED_ROW_SERIAL)
+    case = [c for c in goldens() if (c["width"], c["frames"]) == (1280, 3)][0]
+    rays, bb, _ = gpu_frames(tpt, 1280, 720, 3)
+    assert rays == case["rays"] and "%08x" % fnv1a(bb) == case["fnv"]
+
+
+def test_config3_3840x2160_16spp_properties(tpt_defaults, oracle):
+    """configs[2] at full size through size-independent properties + an oracle check on a band of rows."""
+    tpt = tpt_defaults
+    w, h, spp = 3840, 2160, 16
+    tpt.set_samples_per_pixel(spp)
+    r1, b1, _ = gpu_frames(tpt, w, h, 1)
+    r2, b2, _ = gpu_frames(tpt, w, h, 1)
+    assert r1 == r2 and b1.tobytes() == b2.tobytes()          # deterministic
+    assert np.isfinite(b1[..., :3]).all() and float(b1[..., 3].max()) == 0.0
+    assert 4.3 * w * h * spp < r1 < 4.8 * w * h * spp          # rays/sample = 4.56 on this scene
+    # rows [1000,1016) against the oracle (seeds are partition independent)
+    s, m = oracle.default_scene()
+    band = np.zeros((h, w, 4), np.float32)
+    oracle.render(s, m, oracle.default_camera(w, h), w, h, spp, 0, seed_mode=SEED_PER_PIXEL, backbuffer=band, y0=1000, y1=1016)
+    assert b1[1000:1016].tobytes() == band[1000:1016].tobytes()
+    # static thread-per-pixel variant gives the same frame
+    tpt.set_kernel_variant(0, 0, -1)
+    r3, b3, _ = gpu_frames(tpt, w, h, 1)
+    assert r3 == r1 and b3.tobytes() == b1.tobytes()
+
+
+# ---- 4. sharding: union of row-stripe tiles == single-GPU frame (seeds depend on global x,y only)
+@pytest.mark.parametrize("stripe,parts", [(8, 8), (4, 2), (16, 3)])
+def test_sharded_equals_unsharded(tpt_defaults, stripe, parts):
+    tpt = tpt_defaults
+    w, h, frames = 320, 180, 2
+    rays, full, _ = gpu_frames(tpt, w, h, frames)
+    acc = np.zeros((h, w, 4), np.float32)
+    total = 0
+    for f in range(frames):
+        for p in range(parts):
+            tpt.set_row_shard(stripe, parts, p)
+            tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+            total += tpt.DrawTest(0.0, f, w, h, acc, FLAG_PROGRESSIVE)
+    tpt.set_row_shard(0, 1, 0)
+    assert total == rays and acc.tobytes() == full.tobytes()
+
+
+def test_device_resident_path_with_torch_tile(tpt_defaults, oracle):
+    """tptDrawDevice on a torch-owned HBM tile and torch's stream: accumulation stays on the device."""
+    import torch
+    tpt = tpt_defaults
+    w, h, frames = 256, 144, 4
+    tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    stream = torch.cuda.Stream()
+    tpt.set_stream(stream.cuda_stream)
+    r0 = tpt.ray_counter_read()
+    with torch.cuda.stream(stream):
+        for f in range(frames):
+            tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+            tpt.draw_device(0.0, f, w, h, tile.data_ptr(), FLAG_PROGRESSIVE)
+    rays = tpt.ray_counter_read() - r0
+    stream.synchronize()
+    tpt.set_stream(None)
+    ro, bo, _ = oracle_frames(oracle, w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
+    assert rays == ro and tile.cpu().numpy().tobytes() == bo.tobytes()

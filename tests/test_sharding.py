@@ -56,7 +56,9 @@ def _worker(rank, world, port, w, h, stripe, q):
             r, _ = o.render(s, m, cam, w, h, 2, frame, seed_mode=SEED_PER_PIXEL, backbuffer=full, y0=int(y), y1=int(y) + 1, threads=1)
             rays += r
         sf.tile[: len(rows)] = torch.from_numpy(full[rows])
-        img, total = sf.gather(rays)
+        sf.ray_counter += rays          # the kernels' atomic adds (tptSetRayCounter)
+        sf.exchange()
+    img, total = sf.finish()
     if rank == 0:
         q.put((img.numpy().copy(), total))
     dist.destroy_process_group()
@@ -80,8 +82,9 @@ def test_two_rank_gather_reassembles_the_single_process_image(oracle):
     sc, m = oracle.default_scene()
     cam = oracle.default_camera(w, h)
     bb = np.zeros((h, w, 4), np.float32)
-    rays_last = 0
+    rays_sum = 0
     for frame in range(2):
-        rays_last, _ = oracle.render(sc, m, cam, w, h, 2, frame, seed_mode=SEED_PER_PIXEL, backbuffer=bb)
-    assert total == rays_last
+        r, _ = oracle.render(sc, m, cam, w, h, 2, frame, seed_mode=SEED_PER_PIXEL, backbuffer=bb)
+        rays_sum += r
+    assert total == rays_sum
     assert img.tobytes() == bb.tobytes()

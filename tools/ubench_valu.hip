@@ -1,0 +1,104 @@
+// tools/ubench_valu.hip -- VALU issue-rate microbenchmark for gfx950 (design input for the phase-1
+// sphere loop: is packed fp32 (v_pk_mul/add_f32) faster than scalar fp32 per sphere test?).
+// Build: hipcc --offload-arch=gfx950 -O3 tools/ubench_valu.hip -o tools/ubench_valu ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+#define REP8(x) x x x x x x x x
+template <int MODE>
+__global__ void __launch_bounds__(256) k(float* out, int iters)
+{
+    float a0 = threadIdx.x * 1e-3f + 1.0f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
+    float m = 1.0000001f;
+    v2f p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, p4 = {a1, a2}, p5 = {a3, a4}, p6 = {a5, a6}, p7 = {a7, a0};
+    v2f pm = {m, m};
+    double d0 = a0, d1 = a1, d2 = a2, d3 = a3, d4 = a4, d5 = a5, d6 = a6, d7 = a7, dm = 1.0000001;
+    unsigned u0 = threadIdx.x, u1 = u0 + 1, u2 = u0 + 2, u3 = u0 + 3, u4 = u0 + 4, u5 = u0 + 5, u6 = u0 + 6, u7 = u0 + 7;
+    for (int i = 0; i < iters; ++i) {
+        if (MODE == 0) { // v_mul_f32, 8 independent chains x 8
+            REP8(asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
+                              "v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));)
+        } else if (MODE == 1) { // v_pk_mul_f32
+            REP8(asm volatile("v_pk_mul_f32 %0, %0, %8\n v_pk_mul_f32 %1, %1, %8\n v_pk_mul_f32 %2, %2, %8\n v_pk_mul_f32 %3, %3, %8\n"
+                              "v_pk_mul_f32 %4, %4, %8\n v_pk_mul_f32 %5, %5, %8\n v_pk_mul_f32 %6, %6, %8\n v_pk_mul_f32 %7, %7, %8\n"
+                              : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pm));)
+        } else if (MODE == 2) { // v_fma_f32
+            REP8(asm volatile("v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %1, %1, %8, %8\n v_fma_f32 %2, %2, %8, %8\n v_fma_f32 %3, %3, %8, %8\n"
+                              "v_fma_f32 %4, %4, %8, %8\n v_fma_f32 %5, %5, %8, %8\n v_fma_f32 %6, %6, %8, %8\n v_fma_f32 %7, %7, %8, %8\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));)
+        } else if (MODE == 3) { // v_pk_fma_f32
+            REP8(asm volatile("v_pk_fma_f32 %0, %0, %8, %8\n v_pk_fma_f32 %1, %1, %8, %8\n v_pk_fma_f32 %2, %2, %8, %8\n v_pk_fma_f32 %3, %3, %8, %8\n"
+                              "v_pk_fma_f32 %4, %4, %8, %8\n v_pk_fma_f32 %5, %5, %8, %8\n v_pk_fma_f32 %6, %6, %8, %8\n v_pk_fma_f32 %7, %7, %8, %8\n"
+                              : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pm));)
+        } else if (MODE == 4) { // v_fma_f64
+            REP8(asm volatile("v_fma_f64 %0, %0, %8, %8\n v_fma_f64 %1, %1, %8, %8\n v_fma_f64 %2, %2, %8, %8\n v_fma_f64 %3, %3, %8, %8\n"
+                              "v_fma_f64 %4, %4, %8, %8\n v_fma_f64 %5, %5, %8, %8\n v_fma_f64 %6, %6, %8, %8\n v_fma_f64 %7, %7, %8, %8\n"
+                              : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3), "+v"(d4), "+v"(d5), "+v"(d6), "+v"(d7) : "v"(dm));)
+        } else if (MODE == 5) { // v_alignbit_b32
+            REP8(asm volatile("v_alignbit_b32 %0, %0, %1, 31\n v_alignbit_b32 %1, %1, %2, 31\n v_alignbit_b32 %2, %2, %3, 31\n v_alignbit_b32 %3, %3, %4, 31\n"
+                              "v_alignbit_b32 %4, %4, %5, 31\n v_alignbit_b32 %5, %5, %6, 31\n v_alignbit_b32 %6, %6, %7, 31\n v_alignbit_b32 %7, %7, %0, 31\n"
+                              : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7));)
+        } else if (MODE == 6) { // v_sqrt_f32 (transcendental unit)
+            REP8(asm volatile("v_sqrt_f32 %0, %0\n v_sqrt_f32 %1, %1\n v_sqrt_f32 %2, %2\n v_sqrt_f32 %3, %3\n"
+                              "v_sqrt_f32 %4, %4\n v_sqrt_f32 %5, %5\n v_sqrt_f32 %6, %6\n v_sqrt_f32 %7, %7\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+        } else if (MODE == 7) { // v_pk_add_f32 with an SGPR-pair operand (how the compiler feeds scene data)
+            REP8(asm volatile("v_pk_add_f32 %0, %0, %8\n v_pk_add_f32 %1, %1, %8\n v_pk_add_f32 %2, %2, %8\n v_pk_add_f32 %3, %3, %8\n"
+                              "v_pk_add_f32 %4, %4, %8\n v_pk_add_f32 %5, %5, %8\n v_pk_add_f32 %6, %6, %8\n v_pk_add_f32 %7, %7, %8\n"
+                              : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "s"(1.0000001));)
+        } else if (MODE == 8) { // mixed: v_mul_f32 + v_add_f32 dependent pairs (the scalar sphere test's shape)
+            REP8(asm volatile("v_mul_f32 %0, %0, %8\n v_add_f32 %1, %1, %0\n v_mul_f32 %2, %2, %8\n v_add_f32 %3, %3, %2\n"
+                              "v_mul_f32 %4, %4, %8\n v_add_f32 %5, %5, %4\n v_mul_f32 %6, %6, %8\n v_add_f32 %7, %7, %6\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));)
+        }
+    }
+    out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y +
+                                                 (float)(d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7) + (float)(u0 ^ u1 ^ u2 ^ u3 ^ u4 ^ u5 ^ u6 ^ u7);
+}
+
+template <int MODE>
+static void run(const char* name, int wavesPerSimd, float* out)
+{
+    hipDeviceProp_t prop;
+    hipGetDeviceProperties(&prop, 0);
+    const int cus = prop.multiProcessorCount;
+    const int iters = 4000;
+    const int blocks = cus * wavesPerSimd; // 256 threads = 4 waves = one per SIMD
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, 10);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<MODE>, dim3(blocks), dim3(256), 0, 0, out, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    double instrPerWave = (double)iters * 64;
+    double waveInstr = instrPerWave * blocks * 4;
+    double perSimdPerSec = waveInstr / (cus * 4) / (ms * 1e-3);
+    printf("%-28s waves/SIMD %d  %8.3f ms  %7.3f G wave-instr/s/SIMD  (= %.2f cycles per wave-instr at 2.4 GHz)\n", name, wavesPerSimd, ms,
+           perSimdPerSec / 1e9, 2.4e9 / perSimdPerSec);
+}
+
+int main()
+{
+    float* out;
+    hipMalloc(&out, sizeof(float) * 256 * 256 * 64);
+    for (int w : {1, 2, 4, 8}) {
+        run<0>("v_mul_f32", w, out);
+        run<1>("v_pk_mul_f32", w, out);
+        run<2>("v_fma_f32", w, out);
+        run<3>("v_pk_fma_f32", w, out);
+        run<4>("v_fma_f64", w, out);
+        run<5>("v_alignbit_b32", w, out);
+        run<6>("v_sqrt_f32", w, out);
+        run<7>("v_pk_add_f32 (sgpr src)", w, out);
+        run<8>("v_mul+v_add dependent", w, out);
+    }
+    return 0;
+}

@@ -35,7 +35,7 @@ _lib = None
 C_ABI_SYMBOLS = [
     "tptInitialize", "tptShutdown", "tptUpdate", "tptDraw", "tptGetObjectCount", "tptGetSceneDesc",
     "tptSetSamplesPerPixel", "tptSetSeedMode", "tptSetFoldMode", "tptSetScene", "tptSetCamera", "tptSetStream",
-    "tptSetRowShard", "tptLocalRowCount", "tptLocalRowToGlobal", "tptDrawDevice", "tptRayCounterRead",
+    "tptSetRowShard", "tptLocalRowCount", "tptLocalRowToGlobal", "tptDrawDevice", "tptRayCounterRead", "tptSetRayCounter",
     "tptSynchronize", "tptTimerBegin", "tptTimerEnd", "tptSetKernelVariant", "tptTestMath", "tptTestHitSpheres",
     "tptGetLaunchInfo", "tptGetLastError", "tptGetDeviceName",
 ]
@@ -68,6 +68,7 @@ def load_library():
         "tptSetSamplesPerPixel": [i], "tptSetSeedMode": [i], "tptSetFoldMode": [i], "tptSetScene": [p, p, i],
         "tptSetCamera": [p, p, f, f, f], "tptSetStream": [p], "tptSetRowShard": [i, i, i], "tptLocalRowCount": [i],
         "tptLocalRowToGlobal": [i], "tptDrawDevice": [f, i, i, i, p, u], "tptRayCounterRead": [C.POINTER(C.c_int64)],
+        "tptSetRayCounter": [p],
         "tptSynchronize": [], "tptTimerBegin": [], "tptTimerEnd": [C.POINTER(f)], "tptSetKernelVariant": [i, i, i],
         "tptTestMath": [i, p, p, p, i], "tptTestHitSpheres": [i, p, p, p, i], "tptGetLaunchInfo": [C.POINTER(i)] * 4,
     }
@@ -187,6 +188,11 @@ def ray_counter_read():
     v = C.c_int64()
     _chk(load_library().tptRayCounterRead(C.byref(v)), "tptRayCounterRead")
     return v.value
+
+
+def set_ray_counter(device_ptr):
+    """device_ptr: address of one zeroed int64 in device memory (tensor.data_ptr()), or None/0 for the internal one."""
+    _chk(load_library().tptSetRayCounter(C.c_void_p(device_ptr) if device_ptr else None), "tptSetRayCounter")
 
 
 def synchronize():

@@ -53,7 +53,8 @@ struct Context {
     int stripeRows = 0, numParts = 1, part = 0;
 
     unsigned* dWork = nullptr;
-    unsigned long long* dRays = nullptr;
+    unsigned long long* dRays = nullptr;    // the counter kernels add to (own or caller-provided)
+    unsigned long long* dRaysOwn = nullptr;
     long long lastTotal = 0;
 
     float* dFrame = nullptr; // device tile behind the host-pointer DrawTest
@@ -186,8 +187,9 @@ int tptInitialize(void)
     HIPCHK(hipEventCreate(&g.ev1));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dWork), 64));
     HIPCHK(hipMemset(g.dWork, 0, 64));
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dRays), 64));
-    HIPCHK(hipMemset(g.dRays, 0, 64));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dRaysOwn), 64));
+    HIPCHK(hipMemset(g.dRaysOwn, 0, 64));
+    g.dRays = g.dRaysOwn;
     g.lastTotal = 0;
     if (g.spheres.empty()) defaultScene(g.spheres, g.mats);
     g.sceneDirty = true;
@@ -200,9 +202,9 @@ int tptShutdown(void)
     if (!g.inited) return 0;
     hipStreamSynchronize(g.stream);
     hipFree(g.dPairs); hipFree(g.dSph4); hipFree(g.dInvR); hipFree(g.dMats); hipFree(g.dLights);
-    hipFree(g.dWork); hipFree(g.dRays); hipFree(g.dFrame);
+    hipFree(g.dWork); hipFree(g.dRaysOwn); hipFree(g.dFrame);
     g.dPairs = nullptr; g.dSph4 = nullptr; g.dInvR = nullptr; g.dMats = nullptr; g.dLights = nullptr;
-    g.dWork = nullptr; g.dRays = nullptr; g.dFrame = nullptr;
+    g.dWork = nullptr; g.dRays = nullptr; g.dRaysOwn = nullptr; g.dFrame = nullptr;
     g.frameCap = 0;
     caps = ScenePtrCaps();
     hipEventDestroy(g.ev0); hipEventDestroy(g.ev1);
@@ -392,6 +394,18 @@ int tptRayCounterRead(int64_t* outTotalRays)
     HIPCHK(hipMemcpyAsync(&v, g.dRays, sizeof(v), hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     if (outTotalRays) *outTotalRays = (int64_t)v;
+    return 0;
+}
+
+int tptSetRayCounter(void* deviceU64)
+{
+    if (requireInit()) return -1;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    g.dRays = deviceU64 ? static_cast<unsigned long long*>(deviceU64) : g.dRaysOwn;
+    int64_t total = 0;
+    int rc = tptRayCounterRead(&total);
+    if (rc) return rc;
+    g.lastTotal = total; // DrawTest reports per-frame differences of the active counter
     return 0;
 }
 

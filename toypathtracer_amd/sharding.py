@@ -8,8 +8,13 @@ rank renders its stripes into a compact tile that stays resident in its HBM, and
 8-byte sum-reduce of the ray counters.  Seeds depend on global (x, y) only, so the assembled image
 is bit-identical to a 1-GPU render.
 
-Pure index logic (mirrors tptLocalRowCount / tptLocalRowToGlobal in tpt_host.cpp) so the CPU test
-suite can exercise it with gloo.
+The exchange is software-pipelined against rendering: frame f's tile is snapshotted into one of two
+send buffers on the render stream and gathered on a communication stream while frame f+1 renders
+(the accumulation tile itself is read-modify-written in place by the kernel, so it cannot be the
+gather source).  With CPU tensors (gloo, the CPU test suite) the same code runs without streams.
+
+Pure index logic (mirrors tptLocalRowCount / tptLocalRowToGlobal in tpt_host.cpp) is kept in plain
+numpy so the CPU test suite can exercise it.
 """
 import numpy as np
 
@@ -40,10 +45,9 @@ def padded_rows(height, stripe_rows, num_parts):
     return max(local_row_count(height, stripe_rows, num_parts, p) for p in range(num_parts))
 
 
-def assemble(tiles, height, stripe_rows, num_parts, out=None):
-    """tiles[p]: [>=local_rows(p), width, 4] array/tensor of rank p -> full [height, width, 4] image.
-    Works on numpy arrays and torch tensors alike (index assignment)."""
-    import torch  # local import: plumbing only
+def assemble(tiles, height, stripe_rows, num_parts, out=None, row_index=None):
+    """tiles[p]: [>=local_rows(p), width, 4] array/tensor of rank p -> full [height, width, 4] image."""
+    import torch  # plumbing only
 
     first = tiles[0]
     is_torch = isinstance(first, torch.Tensor)
@@ -51,41 +55,89 @@ def assemble(tiles, height, stripe_rows, num_parts, out=None):
         shape = (height,) + tuple(first.shape[1:])
         out = torch.empty(shape, dtype=first.dtype, device=first.device) if is_torch else np.empty(shape, first.dtype)
     for p in range(num_parts):
-        rows = local_to_global_rows(height, stripe_rows, num_parts, p)
-        idx = torch.as_tensor(rows, device=first.device) if is_torch else rows
-        out[idx] = tiles[p][: len(rows)]
+        if row_index is not None:
+            idx = row_index[p]
+        else:
+            rows = local_to_global_rows(height, stripe_rows, num_parts, p)
+            idx = torch.as_tensor(rows, device=first.device) if is_torch else rows
+        out[idx] = tiles[p][: len(idx)]
     return out
 
 
 class ShardedFrame:
-    """One process per GPU.  `render_tile(frame)` must (asynchronously) render this rank's tile into
-    `self.tile`; `gather()` performs the exchange step and returns (image on rank 0 | None, total rays | None)."""
+    """One process per GPU.  The caller renders this rank's rows into `self.tile` (on `render_stream` when
+    on a GPU) and then calls `exchange()`; `finish()` drains the pipeline and returns what rank 0 holds."""
 
     def __init__(self, width, height, stripe_rows, rank, world, device, dist=None):
         import torch
 
-        self.torch = torch
-        self.dist = dist
+        self.torch, self.dist = torch, dist
         self.width, self.height, self.stripe_rows = width, height, stripe_rows
         self.rank, self.world = rank, world
+        self.device = torch.device(device)
+        self.on_gpu = self.device.type == "cuda"
         self.rows = local_row_count(height, stripe_rows, world, rank)
         self.pad_rows = padded_rows(height, stripe_rows, world)
-        self.tile = torch.zeros((self.pad_rows, width, 4), dtype=torch.float32, device=device)
-        self.gather_list = None
-        if rank == 0 and world > 1:
-            self.gather_list = [torch.empty_like(self.tile) for _ in range(world)]
-        self.image = torch.zeros((height, width, 4), dtype=torch.float32, device=device) if rank == 0 else None
-        self.rays = torch.zeros(1, dtype=torch.int64, device=device)
+        z = dict(dtype=torch.float32, device=self.device)
+        self.tile = torch.zeros((self.pad_rows, width, 4), **z)      # accumulation tile, resident across frames
+        self.ray_counter = torch.zeros(1, dtype=torch.int64, device=self.device)  # kernels add to it (tptSetRayCounter)
+        self.image = torch.zeros((height, width, 4), **z) if rank == 0 else None
+        self.total_rays = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.steps = 0
+        if world > 1:
+            self.send = [torch.zeros_like(self.tile) for _ in range(2)]
+            self.send_rays = [torch.zeros(1, dtype=torch.int64, device=self.device) for _ in range(2)]
+            self.recv = [[torch.empty_like(self.tile) for _ in range(world)] for _ in range(2)] if rank == 0 else None
+            self.row_index = [torch.as_tensor(local_to_global_rows(height, stripe_rows, world, p), device=self.device)
+                              for p in range(world)] if rank == 0 else None
+        if self.on_gpu:
+            self.render_stream = torch.cuda.Stream(device=self.device)
+            self.comm_stream = torch.cuda.Stream(device=self.device)
+            self.ev_ready = [torch.cuda.Event() for _ in range(2)]   # send buffer filled (render stream)
+            self.ev_free = [torch.cuda.Event() for _ in range(2)]    # send buffer consumed (comm stream)
+        else:
+            self.render_stream = self.comm_stream = None
 
-    def gather(self, local_rays):
+    def exchange(self):
+        """Call after this frame's render has been enqueued on render_stream."""
         torch, dist = self.torch, self.dist
+        k = self.steps & 1
+        self.steps += 1
         if self.world <= 1:
-            self.image[:] = self.tile[: self.height]
-            return self.image, int(local_rays)
-        self.rays[0] = int(local_rays)
-        dist.gather(self.tile, self.gather_list, dst=0)        # the one exchange step: tiles -> rank 0
-        dist.reduce(self.rays, dst=0, op=dist.ReduceOp.SUM)    # exact integer ray count
+            return
+        if self.on_gpu:
+            with torch.cuda.stream(self.render_stream):
+                if self.steps > 2:
+                    self.render_stream.wait_event(self.ev_free[k])    # gather of frame f-2 has read this buffer
+                self.send[k].copy_(self.tile, non_blocking=True)
+                self.send_rays[k].copy_(self.ray_counter, non_blocking=True)
+                self.ev_ready[k].record(self.render_stream)
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(self.ev_ready[k])
+                self._collect(k)
+                self.ev_free[k].record(self.comm_stream)
+        else:
+            self.send[k].copy_(self.tile)
+            self.send_rays[k].copy_(self.ray_counter)
+            self._collect(k)
+
+    def _collect(self, k):
+        dist = self.dist
+        dist.gather(self.send[k], self.recv[k] if self.rank == 0 else None, dst=0)  # the one exchange step
+        dist.reduce(self.send_rays[k], dst=0, op=dist.ReduceOp.SUM)                 # exact integer ray count
+        if self.rank == 0:
+            assemble(self.recv[k], self.height, self.stripe_rows, self.world, out=self.image, row_index=self.row_index)
+            self.total_rays.copy_(self.send_rays[k])
+
+    def finish(self):
+        """Drain both streams.  Returns (image, cumulative rays over all ranks) on rank 0, (None, None) elsewhere."""
+        torch = self.torch
+        if self.on_gpu:
+            self.render_stream.synchronize()
+            self.comm_stream.synchronize()
+        if self.world <= 1:
+            self.image.copy_(self.tile[: self.height])
+            self.total_rays.copy_(self.ray_counter)
         if self.rank != 0:
             return None, None
-        assemble(self.gather_list, self.height, self.stripe_rows, self.world, out=self.image)
-        return self.image, int(self.rays.item())
+        return self.image, int(self.total_rays.item())

@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--persistent", type=int, default=1)
     ap.add_argument("--fold", type=int, default=0, help="0 recursive (reference order, default) 1 forward")
     ap.add_argument("--lds-scene", type=int, default=-1)
+    ap.add_argument("--overlap", type=int, default=2, help="trace kernels of this many consecutive frames may be in flight")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -125,6 +126,7 @@ def main():
     api.set_samples_per_pixel(spp)
     api.set_fold_mode(args.fold)
     api.set_kernel_variant(args.hit_spheres, args.persistent, args.lds_scene)
+    api.set_frame_overlap(args.overlap)
     n_spheres = 46
     if scene == "stress":
         from toypathtracer_amd.scenes import STRESS_CAMERA, stress_scene
@@ -156,29 +158,36 @@ def main():
         step(f)
     fence()
     rays0 = int(sf.ray_counter.item())
-    api.timer_begin()                     # HIP events on the kernel's stream
+    api.kernel_timing_begin(args.steps)   # a HIP event pair around every trace launch, on the stream it is launched on
+    api.timer_begin()                     # + one pair around the whole timed region on the context's stream
     t0 = time.perf_counter()
     for f in range(args.warmup, args.warmup + args.steps):
         step(f)
-    kernel_ms = api.timer_end()           # records + synchronises the end event on the render stream
+    pipeline_ms = api.timer_end()         # records + synchronises the end event on the render stream
     fence()
     dt = time.perf_counter() - t0
+    launch_ms_sum, launches = api.kernel_timing_end()
+    kernel_ms = launch_ms_sum / max(launches, 1) * args.steps  # = steps x average duration of one trace launch
     rays_local = int(sf.ray_counter.item()) - rays0
     image, _total = sf.finish()
 
-    stats = torch.tensor([dt, float(rays_local), kernel_ms], dtype=torch.float64, device=device)
+    stats = torch.tensor([dt, float(rays_local), kernel_ms, pipeline_ms], dtype=torch.float64, device=device)
     if dist is not None:
         tmax = stats.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = stats.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        dt, rays_total, kernel_ms = float(tmax[0]), float(tsum[1]), float(tmax[2])
+        dt, rays_total, kernel_ms, pipeline_ms = float(tmax[0]), float(tsum[1]), float(tmax[2]), float(tmax[3])
     else:
         rays_total = float(rays_local)
 
     if rank == 0:
         info = api.launch_info()
-        k_ms = kernel_ms / args.steps                      # average duration of one trace launch (this rank's rows)
+        k_ms = kernel_ms / args.steps                      # average duration of one trace launch (this rank's rows),
+        #                                                    what a rocprofv3 kernel trace reports per dispatch; with
+        #                                                    frame overlap two launches share the GPU, so k_ms ~ 2 x the
+        #                                                    pipeline time per frame (p_ms)
+        p_ms = pipeline_ms / args.steps
         px = width * height / world                        # pixels one launch of one rank covers
         rays_per_launch = rays_total / args.steps / world
         hbm_write_gbs = px * 16 / (k_ms * 1e-3) / 1e9      # 16 B written per pixel
@@ -193,21 +202,25 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "width": width, "height": height, "spp": spp, "spheres": n_spheres,
                        "seed_mode": "per_pixel", "fold": "forward" if args.fold else "recursive",
-                       "hit_spheres": "simple" if args.hit_spheres else "two_phase", "persistent": bool(args.persistent),
+                       "hit_spheres": "simple" if args.hit_spheres else "two_phase", "persistent": bool(args.persistent), "frame_overlap": args.overlap,
                        "sharding": "none" if world == 1 else "row stripes of %d, round-robin over %d ranks, pipelined gather to rank 0" % (args.stripe_rows, world),
                        "device": api.device_name(), "grid_blocks": info["grid_blocks"], "blocks_per_cu": info["blocks_per_cu"],
                        "lds_bytes_per_block": info["lds_bytes"]},
             "rays_per_step": rays_total / args.steps,
-            "kernel_ms_per_step": k_ms,
-            "kernel_Mray_s": rays_per_launch * world / (k_ms * 1e-3) / 1e6,
+            "trace_launch_ms_avg": k_ms,
+            "pipeline_ms_per_step": p_ms,
+            "pipeline_Mray_s": rays_per_launch * world / (p_ms * 1e-3) / 1e6,
             "roofline": {"bound": "hbm", "achieved": hbm_write_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": hbm_write_gbs / PEAK_HBM_GBS, "traffic": traffic,
                          "achieved_read_plus_write": 2 * hbm_write_gbs,
+                         "achieved_per_pipeline_slot": hbm_write_gbs * k_ms / p_ms, "launch_ms_avg": k_ms, "launches": launches,
                          "note": "north_star's HBM-write roofline (W*H*16 B per frame / kernel time); the kernel is FP32-VALU bound "
                                  "(arithmetic intensity ~440 flop/B), see roofline_valu",
                          "kernel": "tptTraceKernel"},
             "roofline_valu": {"bound": "valu_fp32", "achieved": valu_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                               "frac": valu_tflops / PEAK_FP32_TFLOPS,
+                              "achieved_per_pipeline_slot": valu_tflops * k_ms / p_ms,
+                              "frac_per_pipeline_slot": valu_tflops * k_ms / p_ms / PEAK_FP32_TFLOPS,
                               "note": "algorithmic flops = rays x 17 flop x spheres (SURVEY 8d); peak counts FMA as 2 flop and the "
                                       "parity contract forbids FMA contraction, so the reachable ceiling is 78.6 T non-fused op/s"},
         }

@@ -89,6 +89,12 @@ int tptLocalRowToGlobal(int localRow);
  * accumulation buffer stays resident in HBM across frames.  Enqueued on the context's stream;
  * returns immediately.  Ray counts accumulate in a device counter (tptRayCounterRead). */
 int tptDrawDevice(float time, int frameCount, int screenWidth, int screenHeight, float* deviceTile, unsigned testFlags);
+/* Frame pipelining of the asynchronous path: the trace kernels of up to `frames` consecutive tptDrawDevice
+ * calls may be in flight at once (each on its own internal stream, writing its own per-frame colour
+ * buffer); the progressive blend into the tile (Test.cpp:293-295) is a separate, ordered kernel on the
+ * context's stream, so results are bit-identical to frames=1.  Default 2: the tail of frame f (a few long
+ * paths) overlaps the head of frame f+1. */
+int tptSetFrameOverlap(int frames);
 /* Synchronise the stream and return the monotonic total of rays traced by this context. */
 int tptRayCounterRead(int64_t* outTotalRays);
 /* Let the caller own the ray counter: `deviceU64` points to one zero-initialised 64-bit word in device
@@ -100,6 +106,13 @@ int tptSynchronize(void);
  * Dispatch with timestamp queries, TestWin.cpp:299-302). */
 int tptTimerBegin(void);
 int tptTimerEnd(float* outMilliseconds); /* synchronises */
+
+/* Per-launch timing of the trace kernel: between Begin and End every tptDrawDevice brackets its trace
+ * launch with a hipEvent pair recorded on the stream that launch goes to (the internal trace streams when
+ * frames overlap).  End synchronises and returns the SUM of the individual launch durations and their
+ * number -- the same per-dispatch durations a rocprofv3 kernel trace reports. */
+int tptKernelTimingBegin(int maxLaunches);
+int tptKernelTimingEnd(float* outSumMilliseconds, int* outLaunches);
 
 /* ================= 4. tuning / test hooks ================= */
 
@@ -113,6 +126,9 @@ int tptTestMath(int op, const float* a, const float* b, float* out, int n);
 int tptTestHitSpheres(int hitSpheres, const float* rays, int* outId, float* outT, int n);
 /* kernel resource facts for DESIGN/bench: occupancy (blocks/CU), LDS bytes/block, grid size of the last launch */
 int tptGetLaunchInfo(int* outBlocksPerCU, int* outLdsBytes, int* outGridBlocks, int* outNumCUs);
+/* profiling builds only (-DTPT_STATS): 64 counters, wave-level entries [i] / lane counts [32+i] of the
+ * state machine's blocks (enum ST_* in tpt_trace.h); the shipped build returns an error. */
+int tptDebugStats(unsigned long long* out64, int reset);
 const char* tptGetLastError(void);
 const char* tptGetDeviceName(void);
 

@@ -14,8 +14,19 @@ using namespace tpt;
 extern "C" {
 
 // spheres/mats: reference layouts (20 B / 36 B).  cam: 88 B.  Returns ray count.
+int64_t emu_render_ex(const void* spheres, const void* mats, int count, const void* cam, int w, int h, int y0, int y1,
+                      int spp, int frame, unsigned flags, int seedMode, int hs, int fold, float* backbuffer, int* perPixelRays);
+
 int64_t emu_render(const void* spheres, const void* mats, int count, const void* cam, int w, int h, int y0, int y1,
                    int spp, int frame, unsigned flags, int seedMode, int hs, int fold, float* backbuffer)
+{
+    return emu_render_ex(spheres, mats, count, cam, w, h, y0, y1, spp, frame, flags, seedMode, hs, fold, backbuffer, nullptr);
+}
+
+// perPixelRays (optional, w*h ints): number of laneStep calls (= rays) each pixel took -- used by tools/ to model
+// wave scheduling on the CPU.
+int64_t emu_render_ex(const void* spheres, const void* mats, int count, const void* cam, int w, int h, int y0, int y1,
+                      int spp, int frame, unsigned flags, int seedMode, int hs, int fold, float* backbuffer, int* perPixelRays)
 {
     std::vector<SpherePOD> S((const SpherePOD*)spheres, (const SpherePOD*)spheres + count);
     std::vector<MaterialPOD> M((const MaterialPOD*)mats, (const MaterialPOD*)mats + count);
@@ -36,7 +47,7 @@ int64_t emu_render(const void* spheres, const void* mats, int count, const void*
         L.active = false;
         for (int x = 0; x < w; ++x) {
             laneBeginPixel(L, fc, x, y, y * w + x, seedMode == SEED_PER_PIXEL || x == 0);
-            L.prev = ld3(backbuffer + (size_t)L.pix * 4);
+            const uint32_t raysBefore = L.rays;
             for (;;) {
                 bool done;
                 if (hs == HS_SIMPLE)
@@ -47,7 +58,12 @@ int64_t emu_render(const void* spheres, const void* mats, int count, const void*
                                                 : laneStep<HS_TWO_PHASE, FOLD_RECURSIVE>(L, sv, fc, stack);
                 if (done) break;
             }
-            laneStorePixel(L, fc, backbuffer);
+            {
+                float* px = backbuffer + (size_t)L.pix * 4;
+                f3 c = blendPixel(ld3(px), lanePixelColour(L, fc), fc.lerpFac);
+                px[0] = c.x; px[1] = c.y; px[2] = c.z;
+            }
+            if (perPixelRays) perPixelRays[y * w + x] = (int)(L.rays - raysBefore);
         }
         rays += L.rays;
     }

@@ -1,0 +1,44 @@
+"""The drop-in boundary itself: a C++ host that knows only the reference's Test API, linked against the
+library; DrawTest's host-pointer contract; error behaviour."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle_lib import ROOT, FLAG_PROGRESSIVE, SEED_PER_PIXEL, fnv1a
+
+pytestmark = pytest.mark.gpu
+
+
+def test_cxx_host_links_and_matches_oracle(oracle, tmp_path):
+    exe = str(tmp_path / "headless_host")
+    libdir = os.path.join(ROOT, "toypathtracer_amd", "lib")
+    subprocess.check_call(["g++", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "headless_host.cpp"),
+                           "-L", libdir, "-ltoypathtracer_hip", "-Wl,-rpath," + libdir, "-o", exe])
+    out = subprocess.check_output([exe, "320", "180", "3"], stderr=subprocess.STDOUT).decode()
+    m = re.search(r"(\d+) rays.*fnv ([0-9a-f]{8})", out)
+    assert m, out
+    ro, bo = oracle.render_frames(320, 180, 4, 3, seed_mode=SEED_PER_PIXEL)
+    assert int(m.group(1)) == ro and m.group(2) == "%08x" % fnv1a(bo)
+    assert "46 spheres, sizeof(Sphere)=20 sizeof(Material)=36 sizeof(Camera)=88" in out
+
+
+def test_draw_before_update_and_bad_args_fail_cleanly(tpt_defaults):
+    tpt = tpt_defaults
+    with pytest.raises(tpt.TptError):
+        tpt.set_samples_per_pixel(0)
+    with pytest.raises(tpt.TptError):
+        tpt.set_seed_mode(7)
+    with pytest.raises(tpt.TptError):
+        tpt.draw_device(0.0, 0, 64, 64, 0, FLAG_PROGRESSIVE)
+
+
+def test_scene_desc_round_trip(tpt_defaults, oracle):
+    tpt = tpt_defaults
+    tpt.UpdateTest(0.0, 0, 640, 360, FLAG_PROGRESSIVE)
+    s, m, cam, em = tpt.GetSceneDesc()
+    so, mo = oracle.default_scene()
+    assert s.tobytes() == so.tobytes() and m.tobytes() == mo.tobytes() and list(em) == [8, 45]
+    assert cam.tobytes() == oracle.default_camera(640, 360).tobytes()

@@ -231,3 +231,24 @@ def test_device_resident_path_with_torch_tile(tpt_defaults, oracle):
     tpt.set_stream(None)
     ro, bo, _ = oracle_frames(oracle, w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
     assert rays == ro and tile.cpu().numpy().tobytes() == bo.tobytes()
+
+
+@pytest.mark.parametrize("overlap", [1, 2, 4])
+def test_frame_overlap_is_bit_identical(tpt_defaults, oracle, overlap):
+    """Pipelined frames (trace kernels of consecutive frames in flight at once) == strictly serial frames."""
+    import torch
+    tpt = tpt_defaults
+    tpt.set_frame_overlap(overlap)
+    w, h, frames = 192, 128, 7
+    tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    r0 = tpt.ray_counter_read()
+    tpt.kernel_timing_begin(frames)
+    for f in range(frames):
+        tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+        tpt.draw_device(0.0, f, w, h, tile.data_ptr(), FLAG_PROGRESSIVE)
+    ms, n = tpt.kernel_timing_end()
+    rays = tpt.ray_counter_read() - r0
+    assert n == frames and ms > 0
+    ro, bo, _ = oracle_frames(oracle, w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
+    assert rays == ro and tile.cpu().numpy().tobytes() == bo.tobytes()
+    tpt.set_frame_overlap(2)

@@ -1,0 +1,33 @@
+"""Block-entry statistics of the trace kernel (profiling build, TPT_LIB=tools/_stats/libtoypathtracer_hip.so)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["TPT_LIB"] = os.path.join(ROOT, "tools", "_stats", "libtoypathtracer_hip.so")
+import numpy as np
+import torch
+from toypathtracer_amd import api
+NAMES = ["step", "phase2", "camera", "shadow", "sky", "hit", "lambert", "metal", "dielectric", "lightgen", "bounce", "finish",
+         "refill", "chunk", "pixeldone", "diskloop", "sphereloop"]
+api.InitializeTest()
+for (w, h, spp, persist) in [(1280, 720, 4, 1), (1280, 720, 4, 0), (3840, 2160, 16, 1)]:
+    api.set_samples_per_pixel(spp)
+    api.set_kernel_variant(0, persist, -1)
+    import torch
+    tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    api.UpdateTest(0.0, 0, w, h, 2)
+    api.debug_stats(True)
+    r0 = api.ray_counter_read()
+    api.draw_device(0.0, 0, w, h, tile.data_ptr(), 2)
+    rays = api.ray_counter_read() - r0
+    st = api.debug_stats(True)
+    print("== %dx%dx%d persist=%d rays=%d" % (w, h, spp, persist, rays))
+    steps_w, steps_l = int(st[0]), int(st[32])
+    print("  wave-steps %d lane-steps %d  lane utilisation %.3f  (rays/64 = %d)" % (steps_w, steps_l, steps_l / (64.0 * steps_w), rays // 64))
+    waves = int(st[27])
+    if waves:
+        span = (int(st[26]) - int(st[25])) * 10e-9
+        print("  waves %d  kernel span %.3f ms  mean wave lifetime %.3f ms  longest %.3f ms" % (waves, span * 1e3, int(st[24]) / waves * 10e-6, int(st[28]) * 10e-6))
+    for i, n in enumerate(NAMES):
+        if st[i]:
+            print("  %-10s wave-entries %10d (%.3f per step)  lanes %12d (%.2f per entry)" % (n, st[i], st[i] / steps_w, st[32 + i], st[32 + i] / st[i]))
+api.ShutdownTest()

@@ -35,9 +35,9 @@ _lib = None
 C_ABI_SYMBOLS = [
     "tptInitialize", "tptShutdown", "tptUpdate", "tptDraw", "tptGetObjectCount", "tptGetSceneDesc",
     "tptSetSamplesPerPixel", "tptSetSeedMode", "tptSetFoldMode", "tptSetScene", "tptSetCamera", "tptSetStream",
-    "tptSetRowShard", "tptLocalRowCount", "tptLocalRowToGlobal", "tptDrawDevice", "tptRayCounterRead", "tptSetRayCounter",
+    "tptSetRowShard", "tptLocalRowCount", "tptLocalRowToGlobal", "tptDrawDevice", "tptRayCounterRead", "tptSetRayCounter", "tptSetFrameOverlap", "tptKernelTimingBegin", "tptKernelTimingEnd",
     "tptSynchronize", "tptTimerBegin", "tptTimerEnd", "tptSetKernelVariant", "tptTestMath", "tptTestHitSpheres",
-    "tptGetLaunchInfo", "tptGetLastError", "tptGetDeviceName",
+    "tptGetLaunchInfo", "tptGetLastError", "tptGetDeviceName", "tptDebugStats",
 ]
 # the reference's own C++ symbols (nm of the compiled Test.cpp), exported for link-level drop-in
 CXX_ABI_SYMBOLS = [
@@ -47,7 +47,8 @@ CXX_ABI_SYMBOLS = [
 
 
 def library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtoypathtracer_hip.so")
+    # TPT_LIB selects an alternative BUILD OF THE SAME HIP LIBRARY (e.g. the -DTPT_STATS profiling build)
+    return os.environ.get("TPT_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtoypathtracer_hip.so")
 
 
 def load_library():
@@ -55,6 +56,10 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    try:  # torch ships its own HIP runtime: load it first so both sides share one libamdhip64 in the process
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     path = library_path()
     if not os.path.exists(path):
         raise TptError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -68,9 +73,10 @@ def load_library():
         "tptSetSamplesPerPixel": [i], "tptSetSeedMode": [i], "tptSetFoldMode": [i], "tptSetScene": [p, p, i],
         "tptSetCamera": [p, p, f, f, f], "tptSetStream": [p], "tptSetRowShard": [i, i, i], "tptLocalRowCount": [i],
         "tptLocalRowToGlobal": [i], "tptDrawDevice": [f, i, i, i, p, u], "tptRayCounterRead": [C.POINTER(C.c_int64)],
-        "tptSetRayCounter": [p],
+        "tptSetRayCounter": [p], "tptSetFrameOverlap": [i], "tptKernelTimingBegin": [i],
+        "tptKernelTimingEnd": [C.POINTER(f), C.POINTER(i)],
         "tptSynchronize": [], "tptTimerBegin": [], "tptTimerEnd": [C.POINTER(f)], "tptSetKernelVariant": [i, i, i],
-        "tptTestMath": [i, p, p, p, i], "tptTestHitSpheres": [i, p, p, p, i], "tptGetLaunchInfo": [C.POINTER(i)] * 4,
+        "tptDebugStats": [p, i], "tptTestMath": [i, p, p, p, i], "tptTestHitSpheres": [i, p, p, p, i], "tptGetLaunchInfo": [C.POINTER(i)] * 4,
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -190,6 +196,10 @@ def ray_counter_read():
     return v.value
 
 
+def set_frame_overlap(frames):
+    _chk(load_library().tptSetFrameOverlap(frames), "tptSetFrameOverlap")
+
+
 def set_ray_counter(device_ptr):
     """device_ptr: address of one zeroed int64 in device memory (tensor.data_ptr()), or None/0 for the internal one."""
     _chk(load_library().tptSetRayCounter(C.c_void_p(device_ptr) if device_ptr else None), "tptSetRayCounter")
@@ -209,10 +219,28 @@ def timer_end():
     return ms.value
 
 
+def kernel_timing_begin(max_launches):
+    _chk(load_library().tptKernelTimingBegin(max_launches), "tptKernelTimingBegin")
+
+
+def kernel_timing_end():
+    """-> (sum of the individual trace-launch durations in ms, number of launches)"""
+    ms, n = C.c_float(), C.c_int()
+    _chk(load_library().tptKernelTimingEnd(C.byref(ms), C.byref(n)), "tptKernelTimingEnd")
+    return ms.value, n.value
+
+
 def launch_info():
     v = [C.c_int() for _ in range(4)]
     load_library().tptGetLaunchInfo(*[C.byref(x) for x in v])
     return dict(blocks_per_cu=v[0].value, lds_bytes=v[1].value, grid_blocks=v[2].value, num_cus=v[3].value)
+
+
+def debug_stats(reset=True):
+    """profiling build only (TPT_LIB=... built with -DTPT_STATS)"""
+    out = np.zeros(64, np.uint64)
+    _chk(load_library().tptDebugStats(out.ctypes.data, 1 if reset else 0), "tptDebugStats")
+    return out
 
 
 def device_name():

@@ -2,7 +2,9 @@
 #pragma once
 #include "tpt_trace.h"
 
-#define TPT_BLOCK 256        // 4 waves per workgroup
+#ifndef TPT_BLOCK
+#define TPT_BLOCK 64         // threads per workgroup: one wave, so a finished wave frees its LDS/VGPRs at once
+#endif
 #define TPT_CHUNK_PIXELS 256 // pixels a persistent wave pulls per atomic (4 tiles of 8x8)
 
 namespace tpt {
@@ -10,7 +12,8 @@ namespace tpt {
 struct KernelArgs {
     SceneView scene;
     FrameConsts fc;
-    float* backbuffer; // device, [nLocalRows][width][4] floats: the rows this GPU owns, compact
+    f4* frameColour;   // device, [nLocalRows][width] f4: THIS frame's colour per pixel (xyz; w unused), written once
+                       // per pixel by the trace kernel and blended into the accumulation tile by tptResolveKernel
     // row sharding: local row ly <-> image row (ly / stripeRows) * stripeStride + stripeOffset + ly % stripeRows
     int nLocalRows, stripeRows, stripeStride, stripeOffset;
     int tilesX;     // 8x8 tiles per row of tiles
@@ -26,5 +29,8 @@ struct KernelArgs {
 size_t tptLdsBytes(const tpt::KernelArgs& a, int fold, bool ldsScene);
 hipError_t tptLaunchTrace(const tpt::KernelArgs& a, int hs, int fold, bool persist, bool ldsScene, int blocks, size_t lds, hipStream_t stream);
 int tptTraceOccupancy(int hs, int fold, bool persist, bool ldsScene, size_t lds);
+hipError_t tptLaunchResolve(float* tile, const tpt::f4* frameColour, int nPixels, float lerpFac, hipStream_t stream);
 hipError_t tptLaunchMathTest(int op, const float* a, const float* b, float* out, int n, hipStream_t stream);
 hipError_t tptLaunchHitTest(const tpt::KernelArgs& a, int hs, const float* rays, int* outId, float* outT, int n, hipStream_t stream);
+int tptReadStats(unsigned long long* out64);  // profiling build (-DTPT_STATS) only, else -1
+int tptResetStats();

@@ -51,6 +51,7 @@ struct Context {
     int foldMode = FOLD_RECURSIVE;
     int hs = HS_TWO_PHASE, persist = 1, ldsScene = -1;
     int stripeRows = 0, numParts = 1, part = 0;
+    int maxBlocksPerCU = 0, chunkOverride = 0; // tuning knobs (env TPT_MAX_BLOCKS_PER_CU, TPT_CHUNK)
 
     unsigned* dWork = nullptr;
     unsigned long long* dRays = nullptr;    // the counter kernels add to (own or caller-provided)
@@ -59,6 +60,22 @@ struct Context {
 
     float* dFrame = nullptr; // device tile behind the host-pointer DrawTest
     size_t frameCap = 0;
+
+    // frame pipelining: trace kernels of consecutive frames run on alternating internal streams and write
+    // their own per-frame colour buffer; the (ordered) resolve kernels run on g.stream
+    static const int kMaxOverlap = 4;
+    int overlap = 2;
+    hipStream_t traceStream[kMaxOverlap] = {};
+    hipEvent_t evTrace[kMaxOverlap] = {}, evResolve[kMaxOverlap] = {};
+    bool resolveRecorded[kMaxOverlap] = {};
+    f4* dColour[kMaxOverlap] = {};
+    size_t colourCap[kMaxOverlap] = {};
+    unsigned long long frameSeq = 0;
+
+    // per-launch timing of the trace kernel: hipEvent pairs on the stream each launch goes to
+    bool kernelTiming = false;
+    std::vector<hipEvent_t> ktStart, ktStop;
+    size_t ktUsed = 0;
 
     std::map<int, int> occCache;
     int lastBlocksPerCU = 0, lastLds = 0, lastGrid = 0;
@@ -125,7 +142,9 @@ int uploadSceneTracked()
     if ((rc = ensureDev(g.dInvR, caps.invR, P.nPairs * 2))) return rc;
     if ((rc = ensureDev(g.dMats, caps.mats, P.nSpheres * 3))) return rc;
     if ((rc = ensureDev(g.dLights, caps.lights, P.nLights * 2 + 2))) return rc;
-    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream)); // resolves wait on every trace kernel -> nothing reads the scene any more
+    for (int k = 0; k < Context::kMaxOverlap; ++k)
+        if (g.traceStream[k]) HIPCHK(hipStreamSynchronize(g.traceStream[k]));
     HIPCHK(hipMemcpy(g.dPairs, P.pairs.data(), P.pairs.size() * sizeof(float), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(g.dSph4, P.sph4.data(), P.sph4.size() * sizeof(f4), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(g.dInvR, P.invR.data(), P.invR.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -185,13 +204,22 @@ int tptInitialize(void)
     g.stream = g.ownStream;
     HIPCHK(hipEventCreate(&g.ev0));
     HIPCHK(hipEventCreate(&g.ev1));
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dWork), 64));
-    HIPCHK(hipMemset(g.dWork, 0, 64));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dWork), 64 * Context::kMaxOverlap));
+    HIPCHK(hipMemset(g.dWork, 0, 64 * Context::kMaxOverlap));
+    for (int k = 0; k < Context::kMaxOverlap; ++k) {
+        HIPCHK(hipStreamCreateWithFlags(&g.traceStream[k], hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&g.evTrace[k], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&g.evResolve[k], hipEventDisableTiming));
+        g.resolveRecorded[k] = false;
+    }
+    g.frameSeq = 0;
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dRaysOwn), 64));
     HIPCHK(hipMemset(g.dRaysOwn, 0, 64));
     g.dRays = g.dRaysOwn;
     g.lastTotal = 0;
     if (g.spheres.empty()) defaultScene(g.spheres, g.mats);
+    if (const char* e1 = getenv("TPT_MAX_BLOCKS_PER_CU")) g.maxBlocksPerCU = atoi(e1);
+    if (const char* e2 = getenv("TPT_CHUNK")) g.chunkOverride = atoi(e2);
     g.sceneDirty = true;
     g.inited = true;
     return 0;
@@ -207,6 +235,15 @@ int tptShutdown(void)
     g.dWork = nullptr; g.dRays = nullptr; g.dRaysOwn = nullptr; g.dFrame = nullptr;
     g.frameCap = 0;
     caps = ScenePtrCaps();
+    for (size_t i = 0; i < g.ktStart.size(); ++i) { hipEventDestroy(g.ktStart[i]); hipEventDestroy(g.ktStop[i]); }
+    g.ktStart.clear(); g.ktStop.clear(); g.ktUsed = 0; g.kernelTiming = false;
+    for (int k = 0; k < Context::kMaxOverlap; ++k) {
+        if (g.traceStream[k]) { hipStreamSynchronize(g.traceStream[k]); hipStreamDestroy(g.traceStream[k]); }
+        if (g.evTrace[k]) hipEventDestroy(g.evTrace[k]);
+        if (g.evResolve[k]) hipEventDestroy(g.evResolve[k]);
+        hipFree(g.dColour[k]);
+        g.traceStream[k] = nullptr; g.evTrace[k] = nullptr; g.evResolve[k] = nullptr; g.dColour[k] = nullptr; g.colourCap[k] = 0;
+    }
     hipEventDestroy(g.ev0); hipEventDestroy(g.ev1);
     hipStreamDestroy(g.ownStream);
     g.ownStream = g.stream = nullptr;
@@ -242,6 +279,54 @@ int tptSetFoldMode(int mode)
     g.foldMode = mode;
     return 0;
 }
+int tptKernelTimingBegin(int maxLaunches)
+{
+    if (requireInit()) return -1;
+    if (maxLaunches < 1) maxLaunches = 1;
+    while ((int)g.ktStart.size() < maxLaunches) {
+        hipEvent_t a = nullptr, b = nullptr;
+        HIPCHK(hipEventCreate(&a));
+        HIPCHK(hipEventCreate(&b));
+        g.ktStart.push_back(a);
+        g.ktStop.push_back(b);
+    }
+    g.ktUsed = 0;
+    g.kernelTiming = true;
+    return 0;
+}
+
+int tptKernelTimingEnd(float* outSumMs, int* outLaunches)
+{
+    if (requireInit()) return -1;
+    g.kernelTiming = false;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    double sum = 0;
+    for (size_t i = 0; i < g.ktUsed; ++i) {
+        HIPCHK(hipEventSynchronize(g.ktStop[i]));
+        float ms = 0;
+        HIPCHK(hipEventElapsedTime(&ms, g.ktStart[i], g.ktStop[i]));
+        sum += ms;
+    }
+    if (outSumMs) *outSumMs = (float)sum;
+    if (outLaunches) *outLaunches = (int)g.ktUsed;
+    g.ktUsed = 0;
+    return 0;
+}
+
+int tptSetFrameOverlap(int frames)
+{
+    if (frames < 1 || frames > Context::kMaxOverlap) return fail("tptSetFrameOverlap: 1..4");
+    if (g.inited) {
+        HIPCHK(hipStreamSynchronize(g.stream));
+        for (int k = 0; k < Context::kMaxOverlap; ++k)
+            if (g.traceStream[k]) HIPCHK(hipStreamSynchronize(g.traceStream[k]));
+    }
+    g.overlap = frames;
+    g.frameSeq = 0;
+    for (int k = 0; k < Context::kMaxOverlap; ++k) g.resolveRecorded[k] = false;
+    return 0;
+}
+
 int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene)
 {
     g.hs = hitSpheres ? HS_SIMPLE : HS_TWO_PHASE;
@@ -327,7 +412,6 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
     KernelArgs a;
     a.scene = deviceView();
     a.fc = makeFrameConsts(g.cam, w, h, g.spp, frameCount, testFlags, g.seedMode);
-    a.backbuffer = deviceTile;
     a.nLocalRows = localRows(h);
     if (g.numParts > 1 && g.stripeRows > 0) {
         a.stripeRows = g.stripeRows;
@@ -343,7 +427,20 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
     const int tilesY = (a.nLocalRows + 7) / 8;
     const bool rowSerial = g.seedMode == SEED_ROW_SERIAL;
     a.numItems = rowSerial ? a.nLocalRows : a.tilesX * tilesY * 64;
-    a.work = g.dWork;
+    const int nOverlap = g.overlap < 1 ? 1 : (g.overlap > Context::kMaxOverlap ? Context::kMaxOverlap : g.overlap);
+    const int slot = (int)(g.frameSeq % (unsigned long long)nOverlap);
+    g.frameSeq++;
+    const size_t colourBytes = (size_t)a.nLocalRows * w * sizeof(f4);
+    if (colourBytes > g.colourCap[slot]) {
+        HIPCHK(hipStreamSynchronize(g.stream));
+        HIPCHK(hipStreamSynchronize(g.traceStream[slot]));
+        if (g.dColour[slot]) HIPCHK(hipFree(g.dColour[slot]));
+        g.dColour[slot] = nullptr;
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dColour[slot]), colourBytes));
+        g.colourCap[slot] = colourBytes;
+    }
+    a.frameColour = g.dColour[slot];
+    a.work = g.dWork + 16 * slot;
     a.rayCounter = g.dRays;
 
     // LDS scene staging: default when {centre,r^2}+1/r (20 B/sphere) + lights + bounce stack fit in 64 KB
@@ -363,11 +460,14 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
     }
     int blocks;
     if (g.persist) {
-        const int resident = g.numCUs * occ; // workgroups that can be co-resident
+        int occUse = occ;
+        if (g.maxBlocksPerCU > 0 && g.maxBlocksPerCU < occUse) occUse = g.maxBlocksPerCU;
+        const int resident = g.numCUs * occUse; // workgroups that can be co-resident
         const int wavesPerBlock = TPT_BLOCK / 64;
         int chunk = rowSerial ? 1 : TPT_CHUNK_PIXELS;
         // small frames: hand out single 8x8 tiles so every resident wave gets several chunks
         if (!rowSerial && a.numItems / TPT_CHUNK_PIXELS < 8 * resident * wavesPerBlock) chunk = 64;
+        if (!rowSerial && g.chunkOverride >= 64) chunk = g.chunkOverride & ~63;
         a.chunkSize = chunk;
         a.numChunks = (a.numItems + chunk - 1) / chunk;
         blocks = (a.numChunks + wavesPerBlock - 1) / wavesPerBlock;
@@ -383,7 +483,25 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
     g.lastBlocksPerCU = occ;
     g.lastLds = (int)lds;
     g.lastGrid = blocks;
-    HIPCHK(tptLaunchTrace(a, g.hs, g.foldMode, g.persist != 0, ldsScene, blocks, lds, g.stream));
+    // trace(f) on its own stream (no dependency on the previous frame), then the ordered blend on g.stream
+    hipStream_t ts = nOverlap > 1 ? g.traceStream[slot] : g.stream;
+    if (nOverlap > 1 && g.resolveRecorded[slot]) HIPCHK(hipStreamWaitEvent(ts, g.evResolve[slot], 0)); // colour buffer free again
+    const bool timeIt = g.kernelTiming && g.ktUsed < g.ktStart.size();
+    if (timeIt) HIPCHK(hipEventRecord(g.ktStart[g.ktUsed], ts));
+    HIPCHK(tptLaunchTrace(a, g.hs, g.foldMode, g.persist != 0, ldsScene, blocks, lds, ts));
+    if (timeIt) {
+        HIPCHK(hipEventRecord(g.ktStop[g.ktUsed], ts));
+        g.ktUsed++;
+    }
+    if (nOverlap > 1) {
+        HIPCHK(hipEventRecord(g.evTrace[slot], ts));
+        HIPCHK(hipStreamWaitEvent(g.stream, g.evTrace[slot], 0));
+    }
+    HIPCHK(tptLaunchResolve(deviceTile, a.frameColour, a.nLocalRows * w, a.fc.lerpFac, g.stream));
+    if (nOverlap > 1) {
+        HIPCHK(hipEventRecord(g.evResolve[slot], g.stream));
+        g.resolveRecorded[slot] = true;
+    }
     return 0;
 }
 
@@ -508,6 +626,17 @@ int tptGetLaunchInfo(int* outBlocksPerCU, int* outLdsBytes, int* outGridBlocks, 
     if (outLdsBytes) *outLdsBytes = g.lastLds;
     if (outGridBlocks) *outGridBlocks = g.lastGrid;
     if (outNumCUs) *outNumCUs = g.numCUs;
+    return 0;
+}
+
+int tptDebugStats(unsigned long long* out64, int reset)
+{
+    if (requireInit()) return -1;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    int rc = out64 ? tptReadStats(out64) : 0;
+    if (rc == -1) return fail("tptDebugStats: library not built with -DTPT_STATS (profiling build, tools/build_stats.sh)");
+    if (rc) return fail("tptDebugStats: hipMemcpyFromSymbol failed");
+    if (reset && tptResetStats()) return fail("tptDebugStats: reset failed");
     return 0;
 }
 

@@ -49,6 +49,29 @@ __device__ __forceinline__ int localRowToGlobal(const KernelArgs& a, int ly)
     return (ly / a.stripeRows) * a.stripeStride + a.stripeOffset + (ly % a.stripeRows);
 }
 
+__device__ __forceinline__ void storeColour(const KernelArgs& a, const Lane& L)
+{
+    f3 c = lanePixelColour(L, a.fc);
+    f4 v;
+    v.x = c.x; v.y = c.y; v.z = c.z; v.w = 0.0f;
+    a.frameColour[L.pix] = v; // one 16-B store per pixel
+}
+
+// Progressive accumulation, Test.cpp:293-295: tile.rgb = tile.rgb*lerpFac + colour*(1-lerpFac); alpha kept.
+// Separate from the trace kernel so that consecutive frames' trace kernels carry no dependency on each
+// other and can overlap on the device (the tail of frame f runs beside the head of frame f+1).  HBM-bound:
+// 48 B per pixel (read tile + colour, write tile).
+__global__ void __launch_bounds__(256) tptResolveKernel(float* __restrict__ tile, const f4* __restrict__ colour, int nPixels, float lerpFac)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nPixels) return;
+    f4 t = reinterpret_cast<const f4*>(tile)[i];
+    f4 c = colour[i];
+    f3 r = blendPixel(mk3(t.x, t.y, t.z), mk3(c.x, c.y, c.z), lerpFac);
+    t.x = r.x; t.y = r.y; t.z = r.z;
+    reinterpret_cast<f4*>(tile)[i] = t;
+}
+
 template <int HS, int FOLD, bool PERSIST, bool LDS_SCENE>
 __global__ void __launch_bounds__(TPT_BLOCK) tptTraceKernel(const KernelArgs a)
 {
@@ -82,6 +105,9 @@ __global__ void __launch_bounds__(TPT_BLOCK) tptTraceKernel(const KernelArgs a)
 
     const FrameConsts& fc = a.fc;
     const bool rowSerial = fc.seedMode == SEED_ROW_SERIAL;
+#if defined(TPT_STATS)
+    const unsigned long long statT0 = wall_clock64(); // 100 MHz
+#endif
     Lane L;
     L.active = false;
     L.rays = 0;
@@ -92,15 +118,13 @@ __global__ void __launch_bounds__(TPT_BLOCK) tptTraceKernel(const KernelArgs a)
         int x, ly;
         if (idx < a.numItems && mapItem(a, idx, x, ly)) {
             laneBeginPixel(L, fc, x, localRowToGlobal(a, ly), ly * fc.width + x, true);
-            L.prev = ld3(a.backbuffer + (size_t)L.pix * 4);
         }
         while (L.active) {
             if (laneStep<HS, FOLD>(L, sv, fc, stack)) {
-                laneStorePixel(L, fc, a.backbuffer);
+                storeColour(a, L);
                 if (rowSerial && L.x + 1 < fc.width) {
                     laneBeginPixel(L, fc, L.x + 1, L.y, L.pix + 1, false);
-                    L.prev = ld3(a.backbuffer + (size_t)L.pix * 4);
-                } else {
+                        } else {
                     L.active = false;
                 }
             }
@@ -116,8 +140,10 @@ __global__ void __launch_bounds__(TPT_BLOCK) tptTraceKernel(const KernelArgs a)
             for (;;) {
                 unsigned long long needMask = __ballot(need);
                 if (needMask == 0ull) break;
+                TPT_STAT(ST_REFILL);
                 if (chunkNext >= chunkEnd) {
                     if (noMoreWork) break;
+                    TPT_STAT(ST_CHUNK);
                     int c = 0;
                     if (lane == 0) c = (int)atomicAdd(&a.work[0], 1u);
                     c = __builtin_amdgcn_readfirstlane(c);
@@ -137,8 +163,7 @@ __global__ void __launch_bounds__(TPT_BLOCK) tptTraceKernel(const KernelArgs a)
                     int x, ly;
                     if (mapItem(a, chunkNext + rank, x, ly)) {
                         laneBeginPixel(L, fc, x, localRowToGlobal(a, ly), ly * fc.width + x, true);
-                        L.prev = ld3(a.backbuffer + (size_t)L.pix * 4);
-                        need = false;
+                                    need = false;
                     }
                 }
                 chunkNext += take;
@@ -146,11 +171,10 @@ __global__ void __launch_bounds__(TPT_BLOCK) tptTraceKernel(const KernelArgs a)
             if (__ballot(L.active) == 0ull) break;
             if (L.active) {
                 if (laneStep<HS, FOLD>(L, sv, fc, stack)) {
-                    laneStorePixel(L, fc, a.backbuffer);
+                    storeColour(a, L);
                     if (rowSerial && L.x + 1 < fc.width) {
                         laneBeginPixel(L, fc, L.x + 1, L.y, L.pix + 1, false);
-                        L.prev = ld3(a.backbuffer + (size_t)L.pix * 4);
-                    } else {
+                                } else {
                         L.active = false;
                     }
                 }
@@ -160,6 +184,16 @@ __global__ void __launch_bounds__(TPT_BLOCK) tptTraceKernel(const KernelArgs a)
 
     // ---- ray counter: one atomic per wave (Test.cpp:299 does one per task)
     unsigned waveRays = waveReduceAdd(L.rays);
+#if defined(TPT_STATS)
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned long long statT1 = wall_clock64();
+        atomicAdd(&g_tptStats[24], statT1 - statT0);  // sum of wave lifetimes (10 ns ticks)
+        atomicMin(&g_tptStats[25], statT0);           // first wave start
+        atomicMax(&g_tptStats[26], statT1);           // last wave end
+        atomicAdd(&g_tptStats[27], 1ull);             // waves
+        atomicMax(&g_tptStats[28], statT1 - statT0);  // longest wave
+    }
+#endif
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(a.rayCounter, (unsigned long long)waveRays);
         if (PERSIST) {
@@ -215,6 +249,26 @@ __global__ void tptHitTestKernel(const KernelArgs a, const float* __restrict__ r
 
 // ---------------------------------------------------------------- launch glue (called from tpt_host.cpp)
 using namespace tpt;
+
+int tptReadStats(unsigned long long* out64)
+{
+#if defined(TPT_STATS)
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_tptStats), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -2;
+#else
+    (void)out64;
+    return -1;
+#endif
+}
+int tptResetStats()
+{
+#if defined(TPT_STATS)
+    unsigned long long z[64] = {0};
+    z[25] = ~0ull;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_tptStats), z, sizeof(z)) == hipSuccess ? 0 : -2;
+#else
+    return -1;
+#endif
+}
 
 size_t tptLdsBytes(const KernelArgs& a, int fold, bool ldsScene)
 {
@@ -277,6 +331,12 @@ hipError_t tptLaunchTrace(const KernelArgs& a, int hs, int fold, bool persist, b
 int tptTraceOccupancy(int hs, int fold, bool persist, bool ldsScene, size_t lds)
 {
     TPT_DISPATCH(occupancyOne, lds);
+}
+
+hipError_t tptLaunchResolve(float* tile, const f4* frameColour, int nPixels, float lerpFac, hipStream_t stream)
+{
+    hipLaunchKernelGGL(tptResolveKernel, dim3((nPixels + 255) / 256), dim3(256), 0, stream, tile, frameColour, nPixels, lerpFac);
+    return hipGetLastError();
 }
 
 hipError_t tptLaunchMathTest(int op, const float* a, const float* b, float* out, int n, hipStream_t stream)

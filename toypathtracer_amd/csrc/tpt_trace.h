@@ -76,6 +76,28 @@ struct FrameConsts {
 
 TPT_HD f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 
+// Profiling build only (-DTPT_STATS, tools/): wave-level entry counts [i] and lane counts [32+i] per block.
+#if defined(__HIPCC__) && defined(TPT_STATS)
+__device__ unsigned long long g_tptStats[64];
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && defined(TPT_STATS)
+#define TPT_STAT(i)                                                                  \
+    do {                                                                             \
+        unsigned long long m_ = __ballot(1);                                         \
+        if ((int)__ffsll((long long)m_) - 1 == (int)(threadIdx.x & 63)) {            \
+            atomicAdd(&g_tptStats[i], 1ull);                                         \
+            atomicAdd(&g_tptStats[32 + (i)], (unsigned long long)__popcll(m_));      \
+        }                                                                            \
+    } while (0)
+#else
+#define TPT_STAT(i) \
+    do {            \
+    } while (0)
+#endif
+enum { ST_STEP = 0, ST_PHASE2 = 1, ST_CAMERA = 2, ST_SHADOW = 3, ST_SKY = 4, ST_HIT = 5, ST_LAMBERT = 6, ST_METAL = 7,
+       ST_DIELECTRIC = 8, ST_LIGHTGEN = 9, ST_BOUNCE = 10, ST_FINISH = 11, ST_REFILL = 12, ST_CHUNK = 13, ST_PIXELDONE = 14,
+       ST_DISKLOOP = 15, ST_SPHERELOOP = 16 };
+
 TPT_HD uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -152,6 +174,7 @@ TPT_HD int hitSpheresTwoPhase(const SceneView& sv, f3 o, f3 d, float tMin, float
             int k = __builtin_clzll(cand);
             cand &= ~(0x8000000000000000ull >> k);
             int i = pb * 2 + k;
+            TPT_STAT(ST_PHASE2);
             testSphere(sv.sph4[i], i, o, d, tMin, hitT, id);
         }
     }
@@ -194,7 +217,6 @@ struct Lane {
     f3 sdir, nl, albedo, lightE, matE;         // Lambert light-loop context (Test.cpp:89-134)
     float cosAMax;
     f3 col;                                    // sum over samples (Test.cpp:283-290)
-    f3 prev;                                   // previous frame's RGB of this pixel (loaded early by the caller)
     f3 radiance, throughput;                   // FOLD_FORWARD
     int sp;                                    // FOLD_RECURSIVE: entries on the bounce stack
     uint32_t rays;
@@ -239,7 +261,9 @@ template <int HS, int FOLD>
 TPT_HD bool laneStep(Lane& L, const SceneView& sv, const FrameConsts& fc, const BounceStack& stack)
 {
     // ---- new sample: camera ray (Test.cpp:286-289)
+    TPT_STAT(ST_STEP);
     if (L.needCamera) {
+        TPT_STAT(ST_CAMERA);
         float u = ((float)L.x + rnd01(L.rng)) * fc.invWidth;
         float v = ((float)L.y + rnd01(L.rng)) * fc.invHeight;
         cameraGetRay(fc.cam, u, v, L.rng, L.orig, L.dir);
@@ -266,6 +290,7 @@ TPT_HD bool laneStep(Lane& L, const SceneView& sv, const FrameConsts& fc, const 
 
     if (L.kind == KIND_SHADOW) {
         // ---- shadow ray came back (Test.cpp:123-132)
+        TPT_STAT(ST_SHADOW);
         f4 l0 = sv.lights[L.j * 2], l1 = sv.lights[L.j * 2 + 1];
         if (id == (int)f2u(l1.w)) {
             float omega = 2 * TPT_PI * (1 - L.cosAMax);
@@ -277,10 +302,12 @@ TPT_HD bool laneStep(Lane& L, const SceneView& sv, const FrameConsts& fc, const 
         L.j++;
         lightLoop = true;
     } else if (id < 0) {
+        TPT_STAT(ST_SKY);
         term = sky(L.dir); // Test.cpp:229-231
         finish = true;
     } else {
         // ---- hit: finish HitSpheres (Maths.cpp:195-197), then Scatter (Test.cpp:83-193)
+        TPT_STAT(ST_HIT);
         f4 s = sv.sph4[id];
         f3 pos = L.orig + L.dir * t;
         f3 normal = (pos - mk3(s.x, s.y, s.z)) * sv.invR[id];
@@ -291,6 +318,7 @@ TPT_HD bool laneStep(Lane& L, const SceneView& sv, const FrameConsts& fc, const 
             term = matE;
             finish = true;
         } else if (type == MAT_LAMBERT) { // Test.cpp:86-136
+            TPT_STAT(ST_LAMBERT);
             f3 target = pos + normal + randomUnitVector(L.rng);
             L.sdir = normalize(target - pos);
             L.albedo = albedo;
@@ -302,6 +330,7 @@ TPT_HD bool laneStep(Lane& L, const SceneView& sv, const FrameConsts& fc, const 
             L.orig = pos;
             lightLoop = true;
         } else if (type == MAT_METAL) { // Test.cpp:137-150
+            TPT_STAT(ST_METAL);
             f3 refl = reflect(L.dir, normal);
             newDir = normalize(refl + m1.w * randomInUnitSphere(L.rng));
             if (dot(newDir, normal) > 0) {
@@ -315,6 +344,7 @@ TPT_HD bool laneStep(Lane& L, const SceneView& sv, const FrameConsts& fc, const 
                 finish = true;
             }
         } else if (type == MAT_DIELECTRIC) { // Test.cpp:151-186
+            TPT_STAT(ST_DIELECTRIC);
             float ri = sv.mats[id * 3 + 2].x;
             f3 rdir = L.dir;
             f3 refl = reflect(rdir, normal);
@@ -354,6 +384,7 @@ TPT_HD bool laneStep(Lane& L, const SceneView& sv, const FrameConsts& fc, const 
     if (lightLoop) {
         while (L.j < sv.nLights && (int)f2u(sv.lights[L.j * 2 + 1].w) == L.hitId) L.j++; // skip self (:100)
         if (L.j < sv.nLights) {
+            TPT_STAT(ST_LIGHTGEN);
             f4 l0 = sv.lights[L.j * 2];
             f3 sc = mk3(l0.x, l0.y, l0.z);
             f3 sw = normalize(sc - L.orig);
@@ -380,6 +411,7 @@ TPT_HD bool laneStep(Lane& L, const SceneView& sv, const FrameConsts& fc, const 
 
     // ---- Scatter succeeded: Test.cpp:210-216
     if (bounce) {
+        TPT_STAT(ST_BOUNCE);
         if (L.hitType == MAT_LAMBERT) bounceE = bounceE + L.lightE; // matE + lightE (lightE == 0 otherwise)
         L.doMatE = (L.hitType != MAT_LAMBERT);
         if (FOLD == FOLD_FORWARD) {
@@ -396,6 +428,7 @@ TPT_HD bool laneStep(Lane& L, const SceneView& sv, const FrameConsts& fc, const 
 
     // ---- path ended: fold the colour, next sample or pixel done
     if (finish) {
+        TPT_STAT(ST_FINISH);
         f3 c;
         if (FOLD == FOLD_FORWARD) {
             c = L.radiance + L.throughput * term;
@@ -422,16 +455,12 @@ TPT_HD bool laneStep(Lane& L, const SceneView& sv, const FrameConsts& fc, const 
     return false;
 }
 
-// Blend with the previous frame (L.prev, read when the pixel was started: the reference reads it even when
-// lerpFac == 0, Test.cpp:293) and store RGB; alpha is never written (Test.cpp:291-296, Maths.h:38).
-TPT_HD void laneStorePixel(const Lane& L, const FrameConsts& fc, float* backbuffer)
-{
-    f3 col = L.col * fc.invSpp;
-    float* p = backbuffer + (size_t)L.pix * 4;
-    col = L.prev * fc.lerpFac + col * (1 - fc.lerpFac);
-    p[0] = col.x;
-    p[1] = col.y;
-    p[2] = col.z;
-}
+// Pixel complete: the frame's colour of this pixel, averaged over the samples (Test.cpp:291).
+TPT_HD f3 lanePixelColour(const Lane& L, const FrameConsts& fc) { return L.col * fc.invSpp; }
+
+// Progressive accumulation (Test.cpp:293-295): blend with the previous frame's RGB.  The reference reads
+// `prev` even when lerpFac == 0 (NaN/Inf in the buffer propagate), so does this.  Alpha is never touched
+// (Maths.h:38 store() writes 3 floats).
+TPT_HD f3 blendPixel(f3 prev, f3 col, float lerpFac) { return prev * lerpFac + col * (1 - lerpFac); }
 
 } // namespace tpt

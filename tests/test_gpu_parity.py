@@ -38,12 +38,14 @@ def test_row_serial_reproduces_reference_golden_hashes(tpt_defaults, case):
 
 
 # ---- 2. production mode (per-pixel seeds) against the oracle, every kernel variant
-@pytest.mark.parametrize("persist", [1, 0], ids=["persistent", "static"])
+@pytest.mark.parametrize("persist", [2, 1, 0], ids=["sorted", "persistent", "static"])
 @pytest.mark.parametrize("hs", [0, 1], ids=["two_phase", "simple"])
 @pytest.mark.parametrize("fold", [FOLD_RECURSIVE, FOLD_FORWARD], ids=["recursive", "forward"])
 def test_per_pixel_bit_exact_all_variants(tpt_defaults, oracle, persist, hs, fold):
     tpt = tpt_defaults
     w, h, spp, frames = 320, 184, 4, 3
+    if persist == 2 and hs == 1:
+        pytest.skip("the lane-sorting kernel always uses the two-phase HitSpheres")
     tpt.set_kernel_variant(hs, persist, -1)
     tpt.set_fold_mode(fold)
     rays, bb, per = gpu_frames(tpt, w, h, frames)
@@ -252,3 +254,27 @@ def test_frame_overlap_is_bit_identical(tpt_defaults, oracle, overlap):
     ro, bo, _ = oracle_frames(oracle, w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
     assert rays == ro and tile.cpu().numpy().tobytes() == bo.tobytes()
     tpt.set_frame_overlap(2)
+
+
+@pytest.mark.parametrize("fold", [FOLD_RECURSIVE, FOLD_FORWARD], ids=["recursive", "forward"])
+def test_sorted_kernel_full_size_and_stress(tpt_defaults, oracle, fold):
+    """Lane-sorting kernel: configs[1] in full, ragged size, and the 4096-sphere scene."""
+    from toypathtracer_amd.scenes import STRESS_CAMERA, stress_scene
+    tpt = tpt_defaults
+    tpt.set_kernel_variant(0, 2, -1)
+    tpt.set_fold_mode(fold)
+    rays, bb, per = gpu_frames(tpt, 1280, 720, 2)
+    ro, bo, pero = oracle_frames(oracle, 1280, 720, 4, 2, seed_mode=SEED_PER_PIXEL, fold_mode=fold)
+    assert per == pero and bb.tobytes() == bo.tobytes()
+    rays, bb, per = gpu_frames(tpt, 203, 117, 3)
+    ro, bo, pero = oracle_frames(oracle, 203, 117, 4, 3, seed_mode=SEED_PER_PIXEL, fold_mode=fold)
+    assert per == pero and bb.tobytes() == bo.tobytes()
+    s, m = stress_scene(4096, 64)
+    tpt.set_scene(s, m)
+    tpt.set_camera(**STRESS_CAMERA)
+    tpt.set_samples_per_pixel(2)
+    rays, bb, per = gpu_frames(tpt, 96, 54, 2)
+    cam = oracle.camera(STRESS_CAMERA["look_from"], STRESS_CAMERA["look_at"], (0, 1, 0), STRESS_CAMERA["vfov"], 96 / 54,
+                        STRESS_CAMERA["aperture"], STRESS_CAMERA["focus_dist"])
+    ro, bo, pero = oracle_frames(oracle, 96, 54, 2, 2, spheres=s, mats=m, cam=cam, seed_mode=SEED_PER_PIXEL, fold_mode=fold)
+    assert per == pero and bb.tobytes() == bo.tobytes()

@@ -9,7 +9,7 @@ from toypathtracer_amd import api
 NAMES = ["step", "phase2", "camera", "shadow", "sky", "hit", "lambert", "metal", "dielectric", "lightgen", "bounce", "finish",
          "refill", "chunk", "pixeldone", "diskloop", "sphereloop"]
 api.InitializeTest()
-for (w, h, spp, persist) in [(1280, 720, 4, 1), (1280, 720, 4, 0), (3840, 2160, 16, 1)]:
+for (w, h, spp, persist) in [(1280, 720, 4, 1), (1280, 720, 4, 2), (3840, 2160, 16, 2)]:
     api.set_samples_per_pixel(spp)
     api.set_kernel_variant(0, persist, -1)
     import torch

@@ -7,7 +7,7 @@ HERE=$(cd "$(dirname "$0")" && pwd)
 OUT=${TPT_OUT_DIR:-$HERE/../lib}
 mkdir -p "$OUT"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="$TPT_EXTRA_FLAGS --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function"
+FLAGS="$TPT_EXTRA_FLAGS --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wall -Wno-unused-function"
 $HIPCC $FLAGS -c "$HERE/tpt_kernels.hip" -o "$OUT/tpt_kernels.o"
 $HIPCC $FLAGS -x hip -c "$HERE/tpt_host.cpp" -o "$OUT/tpt_host.o"
 $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT/libtoypathtracer_hip.so" "$OUT/tpt_kernels.o" "$OUT/tpt_host.o"

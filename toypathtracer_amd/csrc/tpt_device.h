@@ -5,6 +5,9 @@
 #ifndef TPT_BLOCK
 #define TPT_BLOCK 64         // threads per workgroup: one wave, so a finished wave frees its LDS/VGPRs at once
 #endif
+#ifndef TPT_SORT_WAVES
+#define TPT_SORT_WAVES 4     // waves per workgroup of the lane-sorting kernel (lanes are regrouped across these)
+#endif
 #define TPT_CHUNK_PIXELS 256 // pixels a persistent wave pulls per atomic (4 tiles of 8x8)
 
 namespace tpt {
@@ -20,7 +23,9 @@ struct KernelArgs {
     int numItems;   // pixels incl. tile padding (PER_PIXEL) or rows (ROW_SERIAL)
     int numChunks, chunkSize;
     unsigned totalWaves;
-    unsigned* work;                  // [0] next chunk, [1] finished waves (persistent variant)
+    f4* stackBuf;                    // sorted kernel, FOLD_RECURSIVE: bounce stack [TPT_MAX_DEPTH][stackStride] in global memory
+    int stackStride;                 //   (= threads of the launch; a path keeps its column while it moves between lanes)
+    unsigned* work;                  // [0] next chunk, [1] finished waves (persistent variants)
     unsigned long long* rayCounter;  // monotonic total of rays traced by this context
 };
 
@@ -29,6 +34,9 @@ struct KernelArgs {
 size_t tptLdsBytes(const tpt::KernelArgs& a, int fold, bool ldsScene);
 hipError_t tptLaunchTrace(const tpt::KernelArgs& a, int hs, int fold, bool persist, bool ldsScene, int blocks, size_t lds, hipStream_t stream);
 int tptTraceOccupancy(int hs, int fold, bool persist, bool ldsScene, size_t lds);
+size_t tptSortedLdsBytes(const tpt::KernelArgs& a, int fold, bool ldsScene);
+hipError_t tptLaunchTraceSorted(const tpt::KernelArgs& a, int fold, bool ldsScene, int blocks, size_t lds, hipStream_t stream);
+int tptTraceSortedOccupancy(int fold, bool ldsScene, size_t lds);
 hipError_t tptLaunchResolve(float* tile, const tpt::f4* frameColour, int nPixels, float lerpFac, hipStream_t stream);
 hipError_t tptLaunchMathTest(int op, const float* a, const float* b, float* out, int n, hipStream_t stream);
 hipError_t tptLaunchHitTest(const tpt::KernelArgs& a, int hs, const float* rays, int* outId, float* outT, int n, hipStream_t stream);

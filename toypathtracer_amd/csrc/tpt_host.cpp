@@ -52,12 +52,15 @@ struct Context {
     int hs = HS_TWO_PHASE, persist = 1, ldsScene = -1;
     int stripeRows = 0, numParts = 1, part = 0;
     int maxBlocksPerCU = 0, chunkOverride = 0; // tuning knobs (env TPT_MAX_BLOCKS_PER_CU, TPT_CHUNK)
+    bool globalStack = false;                   // recursive fold: bounce stack in global memory instead of LDS (env TPT_GLOBAL_STACK)
 
     unsigned* dWork = nullptr;
     unsigned long long* dRays = nullptr;    // the counter kernels add to (own or caller-provided)
     unsigned long long* dRaysOwn = nullptr;
     long long lastTotal = 0;
 
+    f4* dStack[4] = {};       // sorted kernel, recursive fold: global bounce stacks (one per in-flight frame)
+    size_t stackCap[4] = {};
     float* dFrame = nullptr; // device tile behind the host-pointer DrawTest
     size_t frameCap = 0;
 
@@ -220,6 +223,7 @@ int tptInitialize(void)
     if (g.spheres.empty()) defaultScene(g.spheres, g.mats);
     if (const char* e1 = getenv("TPT_MAX_BLOCKS_PER_CU")) g.maxBlocksPerCU = atoi(e1);
     if (const char* e2 = getenv("TPT_CHUNK")) g.chunkOverride = atoi(e2);
+    if (const char* e3 = getenv("TPT_GLOBAL_STACK")) g.globalStack = atoi(e3) != 0;
     g.sceneDirty = true;
     g.inited = true;
     return 0;
@@ -242,6 +246,7 @@ int tptShutdown(void)
         if (g.evTrace[k]) hipEventDestroy(g.evTrace[k]);
         if (g.evResolve[k]) hipEventDestroy(g.evResolve[k]);
         hipFree(g.dColour[k]);
+        hipFree(g.dStack[k]); g.dStack[k] = nullptr; g.stackCap[k] = 0;
         g.traceStream[k] = nullptr; g.evTrace[k] = nullptr; g.evResolve[k] = nullptr; g.dColour[k] = nullptr; g.colourCap[k] = 0;
     }
     hipEventDestroy(g.ev0); hipEventDestroy(g.ev1);
@@ -330,7 +335,7 @@ int tptSetFrameOverlap(int frames)
 int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene)
 {
     g.hs = hitSpheres ? HS_SIMPLE : HS_TWO_PHASE;
-    g.persist = persistent ? 1 : 0;
+    g.persist = persistent < 0 ? 0 : (persistent > 2 ? 2 : persistent);
     g.ldsScene = ldsScene < 0 ? -1 : (ldsScene ? 1 : 0);
     return 0;
 }
@@ -446,24 +451,27 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
     // LDS scene staging: default when {centre,r^2}+1/r (20 B/sphere) + lights + bounce stack fit in 64 KB
     const int nPad = a.scene.nPairs * 2;
     bool ldsScene = g.ldsScene < 0 ? ((size_t)nPad * 20 + 4096 + (g.foldMode == FOLD_RECURSIVE ? 40960 : 0) <= 65536) : (g.ldsScene != 0);
-    const size_t lds = tptLdsBytes(a, g.foldMode, ldsScene);
-    if (lds > 160 * 1024) return fail("tptDrawDevice: scene too large for LDS staging; use tptSetKernelVariant(.., .., 0)");
+    const size_t ldsV1 = tptLdsBytes(a, (g.globalStack && g.persist) ? FOLD_FORWARD : g.foldMode, ldsScene); // no LDS stack when it lives in global memory
 
-    const int key = (g.hs ? 8 : 0) | (g.foldMode ? 4 : 0) | (g.persist ? 2 : 0) | (ldsScene ? 1 : 0) | ((int)(lds / 256) << 4);
+    const bool sorted = g.persist == 2 && !rowSerial && g.hs == HS_TWO_PHASE; // lane-sorting kernel (PER_PIXEL seeds only)
+    const size_t lds = sorted ? tptSortedLdsBytes(a, g.foldMode, ldsScene) : ldsV1;
+    if (lds > 160 * 1024) return fail("tptDrawDevice: scene too large for LDS staging; use tptSetKernelVariant(.., .., 0)");
+    const int key = (sorted ? 16 : 0) | (g.hs ? 8 : 0) | (g.foldMode ? 4 : 0) | (g.persist ? 2 : 0) | (ldsScene ? 1 : 0) | ((int)(lds / 256) << 5);
     int occ;
     auto it = g.occCache.find(key);
     if (it == g.occCache.end()) {
-        occ = tptTraceOccupancy(g.hs, g.foldMode, g.persist != 0, ldsScene, lds);
+        occ = sorted ? tptTraceSortedOccupancy(g.foldMode, ldsScene, lds) : tptTraceOccupancy(g.hs, g.foldMode, g.persist != 0, ldsScene, lds);
         g.occCache[key] = occ;
     } else {
         occ = it->second;
     }
+    const int threadsPerBlock = sorted ? 64 * TPT_SORT_WAVES : TPT_BLOCK;
     int blocks;
     if (g.persist) {
         int occUse = occ;
         if (g.maxBlocksPerCU > 0 && g.maxBlocksPerCU < occUse) occUse = g.maxBlocksPerCU;
         const int resident = g.numCUs * occUse; // workgroups that can be co-resident
-        const int wavesPerBlock = TPT_BLOCK / 64;
+        const int wavesPerBlock = threadsPerBlock / 64;
         int chunk = rowSerial ? 1 : TPT_CHUNK_PIXELS;
         // small frames: hand out single 8x8 tiles so every resident wave gets several chunks
         if (!rowSerial && a.numItems / TPT_CHUNK_PIXELS < 8 * resident * wavesPerBlock) chunk = 64;
@@ -480,6 +488,21 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
         blocks = (a.numItems + TPT_BLOCK - 1) / TPT_BLOCK;
         a.totalWaves = 0;
     }
+    a.stackBuf = nullptr;
+    a.stackStride = 0;
+    if ((sorted || (g.globalStack && g.persist)) && g.foldMode == FOLD_RECURSIVE) {
+        const size_t need = (size_t)blocks * threadsPerBlock * TPT_MAX_DEPTH * sizeof(f4);
+        if (need > g.stackCap[slot]) {
+            HIPCHK(hipStreamSynchronize(g.stream));
+            HIPCHK(hipStreamSynchronize(g.traceStream[slot]));
+            if (g.dStack[slot]) HIPCHK(hipFree(g.dStack[slot]));
+            g.dStack[slot] = nullptr;
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dStack[slot]), need));
+            g.stackCap[slot] = need;
+        }
+        a.stackBuf = g.dStack[slot];
+        a.stackStride = blocks * threadsPerBlock;
+    }
     g.lastBlocksPerCU = occ;
     g.lastLds = (int)lds;
     g.lastGrid = blocks;
@@ -488,7 +511,10 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
     if (nOverlap > 1 && g.resolveRecorded[slot]) HIPCHK(hipStreamWaitEvent(ts, g.evResolve[slot], 0)); // colour buffer free again
     const bool timeIt = g.kernelTiming && g.ktUsed < g.ktStart.size();
     if (timeIt) HIPCHK(hipEventRecord(g.ktStart[g.ktUsed], ts));
-    HIPCHK(tptLaunchTrace(a, g.hs, g.foldMode, g.persist != 0, ldsScene, blocks, lds, ts));
+    if (sorted)
+        HIPCHK(tptLaunchTraceSorted(a, g.foldMode, ldsScene, blocks, lds, ts));
+    else
+        HIPCHK(tptLaunchTrace(a, g.hs, g.foldMode, g.persist != 0, ldsScene, blocks, lds, ts));
     if (timeIt) {
         HIPCHK(hipEventRecord(g.ktStop[g.ktUsed], ts));
         g.ktUsed++;
@@ -577,7 +603,10 @@ int tptDraw(float time, int frameCount, int w, int h, float* backbuffer, int* ou
                                   hipMemcpyHostToDevice, g.stream));
         }
     }
-    int rc = tptDrawDevice(time, frameCount, w, h, g.dFrame, testFlags);
+    int64_t totalBefore = 0;
+    int rc = tptRayCounterRead(&totalBefore); // rays of asynchronous tptDrawDevice calls made since must not count here
+    if (rc) return rc;
+    rc = tptDrawDevice(time, frameCount, w, h, g.dFrame, testFlags);
     if (rc) return rc;
     if (!sharded) {
         HIPCHK(hipMemcpyAsync(backbuffer, g.dFrame, rowBytes * rows, hipMemcpyDeviceToHost, g.stream));
@@ -592,7 +621,7 @@ int tptDraw(float time, int frameCount, int w, int h, float* backbuffer, int* ou
     int64_t total = 0;
     rc = tptRayCounterRead(&total); // synchronises the stream
     if (rc) return rc;
-    if (outRayCount) *outRayCount = (int)(total - g.lastTotal);
+    if (outRayCount) *outRayCount = (int)(total - totalBefore);
     g.lastTotal = total;
     return 0;
 }

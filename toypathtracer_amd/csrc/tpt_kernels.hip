@@ -100,8 +100,13 @@ __global__ void __launch_bounds__(TPT_BLOCK) tptTraceKernel(const KernelArgs a)
     __syncthreads();
 
     BounceStack stack;
-    stack.base = ldsStack + threadIdx.x;
-    stack.stride = TPT_BLOCK;
+    if (a.stackBuf) { // recursive fold with the bounce stack in global memory (one column per thread of the launch)
+        stack.base = a.stackBuf + (blockIdx.x * TPT_BLOCK + threadIdx.x);
+        stack.stride = a.stackStride;
+    } else {
+        stack.base = ldsStack + threadIdx.x;
+        stack.stride = TPT_BLOCK;
+    }
 
     const FrameConsts& fc = a.fc;
     const bool rowSerial = fc.seedMode == SEED_ROW_SERIAL;
@@ -203,6 +208,221 @@ __global__ void __launch_bounds__(TPT_BLOCK) tptTraceKernel(const KernelArgs a)
                 a.work[0] = 0u;
                 a.work[1] = 0u;
             }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- lane-sorting variant
+// Same lane logic, same results; what changes is WHICH lane holds which path.  After the (wave-uniform)
+// intersection every lane classifies its path by the block it needs next (end-of-path / dielectric / metal /
+// Lambert hit / shadow-ray return), the 4 waves of the workgroup agree on a class-sorted order through 10-bit
+// packed per-wave counters in LDS, and the whole path state (9 or 11 float4) is permuted through LDS.  Each wave
+// then executes one or two post-intersection blocks at (nearly) full lane utilisation instead of all of them at
+// ~25 % (profiles/r01/block_stats_megakernel_v1.txt).  Two workgroup barriers per step.  The FOLD_RECURSIVE bounce
+// stack moves to global memory (column = L.slot, travels with the path).
+#define TPT_SORT_T (64 * TPT_SORT_WAVES)
+template <int FOLD>
+struct SortPack {
+    static constexpr int N = FOLD == FOLD_FORWARD ? 11 : 9;
+};
+__device__ __forceinline__ f4 mk4(float x, float y, float z, float w)
+{
+    f4 v;
+    v.x = x; v.y = y; v.z = z; v.w = w;
+    return v;
+}
+template <int FOLD>
+__device__ __forceinline__ void packLane(const Lane& L, int id, float t, f4* xch, int dest)
+{
+    const uint32_t flags = ((uint32_t)L.sample & 0xffffu) | (((uint32_t)L.depth & 15u) << 16) | ((uint32_t)(L.kind & 1) << 20) |
+                           (((uint32_t)L.hitType & 3u) << 21) | ((uint32_t)L.active << 23) | ((uint32_t)L.needCamera << 24) |
+                           ((uint32_t)L.doMatE << 25) | (((uint32_t)L.sp & 15u) << 26);
+    xch[0 * TPT_SORT_T + dest] = mk4(L.orig.x, L.orig.y, L.orig.z, u2f(L.rng));
+    xch[1 * TPT_SORT_T + dest] = mk4(L.dir.x, L.dir.y, L.dir.z, t);
+    xch[2 * TPT_SORT_T + dest] = mk4(L.sdir.x, L.sdir.y, L.sdir.z, u2f((uint32_t)id));
+    xch[3 * TPT_SORT_T + dest] = mk4(L.nl.x, L.nl.y, L.nl.z, L.cosAMax);
+    xch[4 * TPT_SORT_T + dest] = mk4(L.albedo.x, L.albedo.y, L.albedo.z, u2f(flags));
+    xch[5 * TPT_SORT_T + dest] = mk4(L.lightE.x, L.lightE.y, L.lightE.z, u2f((uint32_t)L.pix));
+    xch[6 * TPT_SORT_T + dest] = mk4(L.col.x, L.col.y, L.col.z, u2f((uint32_t)L.x | ((uint32_t)L.y << 16)));
+    xch[7 * TPT_SORT_T + dest] = mk4(L.matE.x, L.matE.y, L.matE.z, u2f((uint32_t)L.hitId));
+    xch[8 * TPT_SORT_T + dest] = mk4(u2f((uint32_t)L.slot), u2f(L.rays), u2f((uint32_t)L.j), 0.0f);
+    if (FOLD == FOLD_FORWARD) {
+        xch[9 * TPT_SORT_T + dest] = mk4(L.radiance.x, L.radiance.y, L.radiance.z, L.throughput.x);
+        xch[10 * TPT_SORT_T + dest] = mk4(L.throughput.y, L.throughput.z, 0.0f, 0.0f);
+    }
+}
+template <int FOLD>
+__device__ __forceinline__ void unpackLane(Lane& L, int& id, float& t, const f4* xch, int src)
+{
+    f4 v = xch[0 * TPT_SORT_T + src];
+    L.orig = mk3(v.x, v.y, v.z); L.rng = f2u(v.w);
+    v = xch[1 * TPT_SORT_T + src];
+    L.dir = mk3(v.x, v.y, v.z); t = v.w;
+    v = xch[2 * TPT_SORT_T + src];
+    L.sdir = mk3(v.x, v.y, v.z); id = (int)f2u(v.w);
+    v = xch[3 * TPT_SORT_T + src];
+    L.nl = mk3(v.x, v.y, v.z); L.cosAMax = v.w;
+    v = xch[4 * TPT_SORT_T + src];
+    L.albedo = mk3(v.x, v.y, v.z);
+    const uint32_t flags = f2u(v.w);
+    L.sample = (int)(flags & 0xffffu);
+    L.depth = (int)((flags >> 16) & 15u);
+    L.kind = (int)((flags >> 20) & 1u);
+    L.hitType = (int)((flags >> 21) & 3u);
+    L.active = ((flags >> 23) & 1u) != 0;
+    L.needCamera = ((flags >> 24) & 1u) != 0;
+    L.doMatE = ((flags >> 25) & 1u) != 0;
+    L.sp = (int)((flags >> 26) & 15u);
+    v = xch[5 * TPT_SORT_T + src];
+    L.lightE = mk3(v.x, v.y, v.z); L.pix = (int)f2u(v.w);
+    v = xch[6 * TPT_SORT_T + src];
+    L.col = mk3(v.x, v.y, v.z);
+    L.x = (int)(f2u(v.w) & 0xffffu); L.y = (int)(f2u(v.w) >> 16);
+    v = xch[7 * TPT_SORT_T + src];
+    L.matE = mk3(v.x, v.y, v.z); L.hitId = (int)f2u(v.w);
+    v = xch[8 * TPT_SORT_T + src];
+    L.slot = (int)f2u(v.x); L.rays = f2u(v.y); L.j = (int)f2u(v.z);
+    if (FOLD == FOLD_FORWARD) {
+        v = xch[9 * TPT_SORT_T + src];
+        L.radiance = mk3(v.x, v.y, v.z);
+        float tx = v.w;
+        v = xch[10 * TPT_SORT_T + src];
+        L.throughput = mk3(tx, v.x, v.y);
+    }
+}
+
+template <int FOLD, bool LDS_SCENE>
+__global__ void __launch_bounds__(TPT_SORT_T) tptTraceSortedKernel(const KernelArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nPad = a.scene.nPairs * 2;
+    f4* ldsSph = reinterpret_cast<f4*>(smem);
+    int off = LDS_SCENE ? nPad * 16 : 0;
+    float* ldsInvR = reinterpret_cast<float*>(smem + off);
+    off += LDS_SCENE ? ((nPad * 4 + 15) & ~15) : 0;
+    f4* ldsLights = reinterpret_cast<f4*>(smem + off);
+    off += a.scene.nLights * 32;
+    f4* xch = reinterpret_cast<f4*>(smem + off);
+    off += SortPack<FOLD>::N * TPT_SORT_T * 16;
+    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(smem + off);
+
+    SceneView sv = a.scene;
+    if (LDS_SCENE) {
+        for (int i = threadIdx.x; i < nPad; i += TPT_SORT_T) {
+            ldsSph[i] = a.scene.sph4[i];
+            ldsInvR[i] = a.scene.invR[i];
+        }
+        sv.sph4 = ldsSph;
+        sv.invR = ldsInvR;
+    }
+    for (int i = threadIdx.x; i < a.scene.nLights * 2; i += TPT_SORT_T) ldsLights[i] = a.scene.lights[i];
+    sv.lights = ldsLights;
+    __syncthreads();
+
+    const FrameConsts& fc = a.fc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long laneBelow = (1ull << lane) - 1ull;
+    Lane L;
+    L.rng = 0; L.x = 0; L.y = 0; L.pix = 0; L.sample = 0; L.depth = 0; L.kind = KIND_MAIN; L.j = 0; L.hitId = 0; L.hitType = 0;
+    L.active = false; L.needCamera = false; L.doMatE = true;
+    L.orig = L.dir = L.sdir = L.nl = L.albedo = L.lightE = L.matE = L.col = L.radiance = L.throughput = mk3(0, 0, 0);
+    L.cosAMax = 0; L.sp = 0; L.rays = 0;
+    L.slot = blockIdx.x * TPT_SORT_T + tid;
+
+    int chunkNext = 0, chunkEnd = 0;
+    bool noMoreWork = false;
+    for (;;) {
+        // ---- (1) refill idle lanes from this wave's chunk pool (as in tptTraceKernel)
+        bool need = !L.active;
+        for (;;) {
+            unsigned long long needMask = __ballot(need);
+            if (needMask == 0ull) break;
+            TPT_STAT(ST_REFILL);
+            if (chunkNext >= chunkEnd) {
+                if (noMoreWork) break;
+                TPT_STAT(ST_CHUNK);
+                int c = 0;
+                if (lane == 0) c = (int)atomicAdd(&a.work[0], 1u);
+                c = __builtin_amdgcn_readfirstlane(c);
+                if (c >= a.numChunks) {
+                    noMoreWork = true;
+                    break;
+                }
+                chunkNext = c * a.chunkSize;
+                chunkEnd = chunkNext + a.chunkSize;
+                if (chunkEnd > a.numItems) chunkEnd = a.numItems;
+            }
+            int rank = __popcll(needMask & laneBelow);
+            int want = __popcll(needMask);
+            int avail = chunkEnd - chunkNext;
+            int take = want < avail ? want : avail;
+            if (need && rank < take) {
+                int x, ly;
+                if (mapItem(a, chunkNext + rank, x, ly)) {
+                    laneBeginPixel(L, fc, x, localRowToGlobal(a, ly), ly * fc.width + x, true);
+                    need = false;
+                }
+            }
+            chunkNext += take;
+        }
+        // ---- (2) camera ray for lanes starting a sample, (3) HitWorld for every live lane
+        int id = -1;
+        float t = 0.0f;
+        if (L.active) {
+            TPT_STAT(ST_STEP);
+            if (L.needCamera) laneCamera<FOLD>(L, fc);
+            id = hitSpheres<HS_TWO_PHASE>(sv, L.orig, L.dir, TPT_MIN_T, TPT_MAX_T, t);
+            L.rays++;
+        }
+        // ---- (4) classify; per-wave class histogram, 10 bits per class, one LDS word per wave
+        const int cls = laneClassify(L, id, sv);
+        unsigned long long mine = 0ull, packed = 0ull;
+#pragma unroll
+        for (int c = 0; c < CLS_COUNT; ++c) {
+            unsigned long long m = __ballot(cls == c);
+            if (cls == c) mine = m;
+            packed |= (unsigned long long)__popcll(m) << (10 * c);
+        }
+        const int rank = __popcll(mine & laneBelow);
+        if (lane == 0) cnt[wave] = packed;
+        __syncthreads(); // A: all histograms visible; every wave finished reading xch of the previous step
+        // ---- (5) destination slot in class-sorted order
+        unsigned long long total = 0ull, before = 0ull;
+#pragma unroll
+        for (int w = 0; w < TPT_SORT_WAVES; ++w) {
+            unsigned long long c = cnt[w];
+            if (w < wave) before += c;
+            total += c;
+        }
+        if ((int)((total >> (10 * CLS_IDLE)) & 1023ull) == TPT_SORT_T) break; // every lane of the workgroup is idle (uniform)
+        int base = 0;
+#pragma unroll
+        for (int c = 0; c < CLS_COUNT; ++c)
+            if (c < cls) base += (int)((total >> (10 * c)) & 1023ull);
+        const int dest = base + (int)((before >> (10 * cls)) & 1023ull) + rank;
+        // ---- (6) permute the path state through LDS, (7) read back the slot of this thread
+        packLane<FOLD>(L, id, t, xch, dest);
+        __syncthreads(); // B
+        unpackLane<FOLD>(L, id, t, xch, tid);
+        // ---- (8) post-intersection work; lanes of a wave now mostly need the same block
+        if (L.active) {
+            BounceStack stack;
+            stack.base = a.stackBuf + L.slot;
+            stack.stride = a.stackStride;
+            if (lanePost<FOLD>(L, id, t, sv, fc, stack)) {
+                storeColour(a, L);
+                L.active = false;
+            }
+        }
+    }
+
+    unsigned waveRays = waveReduceAdd(L.rays);
+    if (lane == 0) {
+        atomicAdd(a.rayCounter, (unsigned long long)waveRays);
+        unsigned done = atomicAdd(&a.work[1], 1u) + 1u;
+        if (done == a.totalWaves) {
+            a.work[0] = 0u;
+            a.work[1] = 0u;
         }
     }
 }
@@ -331,6 +551,47 @@ hipError_t tptLaunchTrace(const KernelArgs& a, int hs, int fold, bool persist, b
 int tptTraceOccupancy(int hs, int fold, bool persist, bool ldsScene, size_t lds)
 {
     TPT_DISPATCH(occupancyOne, lds);
+}
+
+size_t tptSortedLdsBytes(const KernelArgs& a, int fold, bool ldsScene)
+{
+    const int nPad = a.scene.nPairs * 2;
+    size_t bytes = 0;
+    if (ldsScene) bytes += (size_t)nPad * 16 + (((size_t)nPad * 4 + 15) & ~(size_t)15);
+    bytes += (size_t)a.scene.nLights * 32;
+    bytes += (size_t)(fold == FOLD_FORWARD ? 11 : 9) * TPT_SORT_T * 16;
+    bytes += 64;
+    return bytes;
+}
+template <int FOLD, bool LDS_SCENE>
+static hipError_t launchSortedOne(const KernelArgs& a, int blocks, size_t lds, hipStream_t stream)
+{
+    auto k = tptTraceSortedKernel<FOLD, LDS_SCENE>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(TPT_SORT_T), lds, stream, a);
+    return hipGetLastError();
+}
+template <int FOLD, bool LDS_SCENE>
+static int occupancySortedOne(size_t lds)
+{
+    int nb = 0;
+    auto k = tptTraceSortedKernel<FOLD, LDS_SCENE>;
+    if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), TPT_SORT_T, lds) != hipSuccess) nb = 1;
+    return nb < 1 ? 1 : nb;
+}
+hipError_t tptLaunchTraceSorted(const KernelArgs& a, int fold, bool ldsScene, int blocks, size_t lds, hipStream_t stream)
+{
+    if (fold == FOLD_FORWARD) return ldsScene ? launchSortedOne<FOLD_FORWARD, true>(a, blocks, lds, stream) : launchSortedOne<FOLD_FORWARD, false>(a, blocks, lds, stream);
+    return ldsScene ? launchSortedOne<FOLD_RECURSIVE, true>(a, blocks, lds, stream) : launchSortedOne<FOLD_RECURSIVE, false>(a, blocks, lds, stream);
+}
+int tptTraceSortedOccupancy(int fold, bool ldsScene, size_t lds)
+{
+    if (fold == FOLD_FORWARD) return ldsScene ? occupancySortedOne<FOLD_FORWARD, true>(lds) : occupancySortedOne<FOLD_FORWARD, false>(lds);
+    return ldsScene ? occupancySortedOne<FOLD_RECURSIVE, true>(lds) : occupancySortedOne<FOLD_RECURSIVE, false>(lds);
 }
 
 hipError_t tptLaunchResolve(float* tile, const f4* frameColour, int nPixels, float lerpFac, hipStream_t stream)

@@ -137,7 +137,27 @@ TPT_HD int hitSpheresSimple(const SceneView& sv, f3 o, f3 d, float tMin, float t
     return id;
 }
 
-TPT_HD void phase1Pair(const float* __restrict__ rec, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f dz, uint32_t& m)
+// The pair records are read-only for the whole launch and every lane reads the same address: on the device the
+// pointer is retyped to the CONSTANT address space so the compiler emits scalar loads (s_load_dwordx8/x16 into
+// SGPRs, fed to the VALU as scalar operands) instead of 64 identical vector loads.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef const float __attribute__((address_space(4))) * PairPtr;
+#else
+typedef const float* PairPtr;
+#endif
+TPT_HD PairPtr pairPtr(const float* p)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    return (PairPtr)(p);
+#pragma clang diagnostic pop
+#else
+    return p;
+#endif
+}
+
+TPT_HD void phase1Pair(PairPtr rec, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f dz, uint32_t& m)
 {
     v2f cx = {rec[0], rec[1]}, cy = {rec[2], rec[3]}, cz = {rec[4], rec[5]}, sq = {rec[6], rec[7]};
     v2f coX = cx - ox;
@@ -150,6 +170,9 @@ TPT_HD void phase1Pair(const float* __restrict__ rec, v2f ox, v2f oy, v2f oz, v2
     m = alignbit(m, f2u(discr[1]), 31);
 }
 
+// Measured alternatives (profiles/r01/run8*.log, run9*.log): scalar VOP2 arithmetic instead of packed VOP3P is
+// a wash (packed ops issue at half rate on gfx950); software-pipelining the scalar loads one 4-pair block
+// ahead costs 64 more SGPRs, spills, and is 8-15 % slower than letting 3-4 waves per SIMD hide the latency.
 TPT_HD int hitSpheresTwoPhase(const SceneView& sv, f3 o, f3 d, float tMin, float tMax, float& outT)
 {
     float hitT = tMax;
@@ -160,7 +183,7 @@ TPT_HD int hitSpheresTwoPhase(const SceneView& sv, f3 o, f3 d, float tMin, float
         int cnt = sv.nPairs - pb;
         if (cnt > 32) cnt = 32;
         const int c0 = cnt < 16 ? cnt : 16, c1 = cnt - c0;
-        const float* __restrict__ rec = sv.pairs + (size_t)pb * 8;
+        const PairPtr rec = pairPtr(sv.pairs + (size_t)pb * 8);
         uint32_t m0 = 0, m1 = 0;
 #pragma unroll 4
         for (int p = 0; p < c0; ++p) phase1Pair(rec + p * 8, ox, oy, oz, dx, dy, dz, m0);
@@ -219,6 +242,7 @@ struct Lane {
     f3 col;                                    // sum over samples (Test.cpp:283-290)
     f3 radiance, throughput;                   // FOLD_FORWARD
     int sp;                                    // FOLD_RECURSIVE: entries on the bounce stack
+    int slot;                                  // sorted kernel: which bounce-stack column this path owns (travels with the path)
     uint32_t rays;
 };
 
@@ -255,35 +279,44 @@ TPT_HD void laneBeginPixel(Lane& L, const FrameConsts& fc, int x, int y, int pix
     L.active = true;
 }
 
-// One step: intersect one ray, advance the path.  Returns true when the lane's pixel is complete
-// (L.col then holds the sum over spp samples; the caller blends and stores).
-template <int HS, int FOLD>
-TPT_HD bool laneStep(Lane& L, const SceneView& sv, const FrameConsts& fc, const BounceStack& stack)
+// New sample: camera ray (Test.cpp:286-289).
+template <int FOLD>
+TPT_HD void laneCamera(Lane& L, const FrameConsts& fc)
 {
-    // ---- new sample: camera ray (Test.cpp:286-289)
-    TPT_STAT(ST_STEP);
-    if (L.needCamera) {
-        TPT_STAT(ST_CAMERA);
-        float u = ((float)L.x + rnd01(L.rng)) * fc.invWidth;
-        float v = ((float)L.y + rnd01(L.rng)) * fc.invHeight;
-        cameraGetRay(fc.cam, u, v, L.rng, L.orig, L.dir);
-        L.depth = 0;
-        L.doMatE = true;
-        L.kind = KIND_MAIN;
-        L.needCamera = false;
-        if (FOLD == FOLD_FORWARD) {
-            L.radiance = mk3(0, 0, 0);
-            L.throughput = mk3(1, 1, 1);
-        } else {
-            L.sp = 0;
-        }
+    TPT_STAT(ST_CAMERA);
+    float u = ((float)L.x + rnd01(L.rng)) * fc.invWidth;
+    float v = ((float)L.y + rnd01(L.rng)) * fc.invHeight;
+    cameraGetRay(fc.cam, u, v, L.rng, L.orig, L.dir);
+    L.depth = 0;
+    L.doMatE = true;
+    L.kind = KIND_MAIN;
+    L.needCamera = false;
+    if (FOLD == FOLD_FORWARD) {
+        L.radiance = mk3(0, 0, 0);
+        L.throughput = mk3(1, 1, 1);
+    } else {
+        L.sp = 0;
     }
+}
 
-    // ---- HitWorld (Test.cpp:76; counted at Test.cpp:122 and :199)
-    float t;
-    const int id = hitSpheres<HS>(sv, L.orig, L.dir, TPT_MIN_T, TPT_MAX_T, t);
-    L.rays++;
+// Which post-intersection block a lane needs next (used by the sorted kernel to regroup lanes so that a wave
+// executes one or two blocks at full lane utilisation instead of all of them at ~25 %).  Order chosen so that
+// classes sharing code sit next to each other (LAMBERT and SHADOW both run the light-sampling block).
+enum { CLS_END = 0, CLS_DIEL = 1, CLS_METAL = 2, CLS_LAMBERT = 3, CLS_SHADOW = 4, CLS_IDLE = 5, CLS_COUNT = 6 };
+TPT_HD int laneClassify(const Lane& L, int id, const SceneView& sv)
+{
+    if (!L.active) return CLS_IDLE;
+    if (L.kind == KIND_SHADOW) return CLS_SHADOW;
+    if (id < 0 || L.depth >= TPT_MAX_DEPTH) return CLS_END;
+    int type = (int)f2u(sv.mats[id * 3].w);
+    return type == MAT_LAMBERT ? CLS_LAMBERT : type == MAT_METAL ? CLS_METAL : type == MAT_DIELECTRIC ? CLS_DIEL : CLS_END;
+}
 
+// Everything after HitWorld for one ray of this lane: Scatter / light sampling / bounce / fold.
+// Returns true when the lane's pixel is complete (L.col then holds the sum over spp samples).
+template <int FOLD>
+TPT_HD bool lanePost(Lane& L, const int id, const float t, const SceneView& sv, const FrameConsts& fc, const BounceStack& stack)
+{
     bool lightLoop = false, finish = false, bounce = false;
     f3 term = mk3(0, 0, 0), newDir = mk3(0, 0, 0), bounceE = mk3(0, 0, 0), atten = mk3(1, 1, 1);
     int attId = -1;
@@ -453,6 +486,19 @@ TPT_HD bool laneStep(Lane& L, const SceneView& sv, const FrameConsts& fc, const 
             return true;
     }
     return false;
+}
+
+// One step: intersect one ray, advance the path (camera ray if a new sample starts, HitWorld, lanePost).
+template <int HS, int FOLD>
+TPT_HD bool laneStep(Lane& L, const SceneView& sv, const FrameConsts& fc, const BounceStack& stack)
+{
+    TPT_STAT(ST_STEP);
+    if (L.needCamera) laneCamera<FOLD>(L, fc);
+    // ---- HitWorld (Test.cpp:76; counted at Test.cpp:122 and :199)
+    float t;
+    const int id = hitSpheres<HS>(sv, L.orig, L.dir, TPT_MIN_T, TPT_MAX_T, t);
+    L.rays++;
+    return lanePost<FOLD>(L, id, t, sv, fc, stack);
 }
 
 // Pixel complete: the frame's colour of this pixel, averaged over the samples (Test.cpp:291).

@@ -93,7 +93,7 @@ def main():
     ap.add_argument("--stripe-rows", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hit-spheres", type=int, default=0, help="0 two-phase (default) 1 simple")
-    ap.add_argument("--persistent", type=int, default=1)
+    ap.add_argument("--persistent", type=int, default=1, help="1 persistent waves (default) 0 thread-per-pixel 2 lane-sorting 3 path queues")
     ap.add_argument("--fold", type=int, default=0, help="0 recursive (reference order, default) 1 forward")
     ap.add_argument("--lds-scene", type=int, default=-1)
     ap.add_argument("--overlap", type=int, default=2, help="trace kernels of this many consecutive frames may be in flight")
@@ -202,7 +202,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "width": width, "height": height, "spp": spp, "spheres": n_spheres,
                        "seed_mode": "per_pixel", "fold": "forward" if args.fold else "recursive",
-                       "hit_spheres": "simple" if args.hit_spheres else "two_phase", "persistent": bool(args.persistent), "frame_overlap": args.overlap,
+                       "hit_spheres": "simple" if args.hit_spheres else "two_phase", "kernel": ["thread_per_pixel", "persistent_waves", "lane_sorting", "path_queues"][args.persistent], "frame_overlap": args.overlap,
                        "sharding": "none" if world == 1 else "row stripes of %d, round-robin over %d ranks, pipelined gather to rank 0" % (args.stripe_rows, world),
                        "device": api.device_name(), "grid_blocks": info["grid_blocks"], "blocks_per_cu": info["blocks_per_cu"],
                        "lds_bytes_per_block": info["lds_bytes"]},

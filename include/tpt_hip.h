@@ -117,8 +117,9 @@ int tptKernelTimingEnd(float* outSumMilliseconds, int* outLaunches);
 /* ================= 4. tuning / test hooks ================= */
 
 /* hitSpheres: 0 = two-phase (default), 1 = simple loop.  persistent: 1 = persistent waves with lane
- * refill (default), 0 = one thread per pixel.  ldsScene: 1 = stage sphere records in LDS (default
- * when they fit), 0 = read them from global memory, -1 = auto. */
+ * refill (default), 0 = one thread per pixel, 2 = lane-sorting workgroups (experimental), 3 = path queues in
+ * LDS (experimental; recursive fold only).  ldsScene: 1 = stage sphere records and materials in LDS (default
+ * when they fit), 0 = read them from global memory, -1 = auto.  All variants produce identical bits. */
 int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene);
 /* device math unit tests: op 0 sqrt 1 div 2 sin 3 cos 4 pow5 5 rnd01^16 6 schlick 7 normalize.x; host arrays */
 int tptTestMath(int op, const float* a, const float* b, float* out, int n);

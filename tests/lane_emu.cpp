@@ -40,6 +40,9 @@ int64_t emu_render_ex(const void* spheres, const void* mats, int count, const vo
     BounceStack stack;
     stack.base = stackMem;
     stack.stride = 1;
+    stack.spill = stackMem + 3; // exercise the two-level stack: levels 0-2 "fast", 3-9 "spill"
+    stack.spillStride = 1;
+    stack.fastLevels = 3;
     int64_t rays = 0;
     for (int y = y0; y < y1; ++y) {
         Lane L;

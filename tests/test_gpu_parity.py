@@ -38,14 +38,16 @@ def test_row_serial_reproduces_reference_golden_hashes(tpt_defaults, case):
 
 
 # ---- 2. production mode (per-pixel seeds) against the oracle, every kernel variant
-@pytest.mark.parametrize("persist", [2, 1, 0], ids=["sorted", "persistent", "static"])
+@pytest.mark.parametrize("persist", [3, 2, 1, 0], ids=["path_queues", "sorted", "persistent", "static"])
 @pytest.mark.parametrize("hs", [0, 1], ids=["two_phase", "simple"])
 @pytest.mark.parametrize("fold", [FOLD_RECURSIVE, FOLD_FORWARD], ids=["recursive", "forward"])
 def test_per_pixel_bit_exact_all_variants(tpt_defaults, oracle, persist, hs, fold):
     tpt = tpt_defaults
     w, h, spp, frames = 320, 184, 4, 3
-    if persist == 2 and hs == 1:
-        pytest.skip("the lane-sorting kernel always uses the two-phase HitSpheres")
+    if persist >= 2 and hs == 1:
+        pytest.skip("the lane-sorting / path-queue kernels always use the two-phase HitSpheres")
+    if persist == 3 and fold == FOLD_FORWARD:
+        pytest.skip("the path-queue kernel implements the recursive (reference-order) fold only")
     tpt.set_kernel_variant(hs, persist, -1)
     tpt.set_fold_mode(fold)
     rays, bb, per = gpu_frames(tpt, w, h, frames)
@@ -256,12 +258,13 @@ def test_frame_overlap_is_bit_identical(tpt_defaults, oracle, overlap):
     tpt.set_frame_overlap(2)
 
 
-@pytest.mark.parametrize("fold", [FOLD_RECURSIVE, FOLD_FORWARD], ids=["recursive", "forward"])
-def test_sorted_kernel_full_size_and_stress(tpt_defaults, oracle, fold):
-    """Lane-sorting kernel: configs[1] in full, ragged size, and the 4096-sphere scene."""
+@pytest.mark.parametrize("variant,fold", [(2, FOLD_RECURSIVE), (2, FOLD_FORWARD), (3, FOLD_RECURSIVE)],
+                         ids=["sorted-recursive", "sorted-forward", "path_queues-recursive"])
+def test_experimental_kernels_full_size_and_stress(tpt_defaults, oracle, variant, fold):
+    """Lane-sorting and path-queue kernels: configs[1] in full, ragged size, and the 4096-sphere scene."""
     from toypathtracer_amd.scenes import STRESS_CAMERA, stress_scene
     tpt = tpt_defaults
-    tpt.set_kernel_variant(0, 2, -1)
+    tpt.set_kernel_variant(0, variant, -1)
     tpt.set_fold_mode(fold)
     rays, bb, per = gpu_frames(tpt, 1280, 720, 2)
     ro, bo, pero = oracle_frames(oracle, 1280, 720, 4, 2, seed_mode=SEED_PER_PIXEL, fold_mode=fold)

@@ -9,7 +9,7 @@ from toypathtracer_amd import api
 NAMES = ["step", "phase2", "camera", "shadow", "sky", "hit", "lambert", "metal", "dielectric", "lightgen", "bounce", "finish",
          "refill", "chunk", "pixeldone", "diskloop", "sphereloop"]
 api.InitializeTest()
-for (w, h, spp, persist) in [(1280, 720, 4, 1), (1280, 720, 4, 2), (3840, 2160, 16, 2)]:
+for (w, h, spp, persist) in [(1280, 720, 4, 3), (3840, 2160, 16, 3)]:
     api.set_samples_per_pixel(spp)
     api.set_kernel_variant(0, persist, -1)
     import torch
@@ -27,6 +27,10 @@ for (w, h, spp, persist) in [(1280, 720, 4, 1), (1280, 720, 4, 2), (3840, 2160, 
     if waves:
         span = (int(st[26]) - int(st[25])) * 10e-9
         print("  waves %d  kernel span %.3f ms  mean wave lifetime %.3f ms  longest %.3f ms" % (waves, span * 1e3, int(st[24]) / waves * 10e-6, int(st[28]) * 10e-6))
+    QN = ["FREE", "INT", "END", "DIEL", "METAL", "LAMBERT", "SHADOW"]
+    for c, n in enumerate(QN):
+        if st[16 + c]:
+            print("  queue %-8s batches %9d  paths %11d  fill %.1f / 64" % (n, st[16 + c], st[48 + c], st[48 + c] / st[16 + c]))
     for i, n in enumerate(NAMES):
         if st[i]:
             print("  %-10s wave-entries %10d (%.3f per step)  lanes %12d (%.2f per entry)" % (n, st[i], st[i] / steps_w, st[32 + i], st[32 + i] / st[i]))

@@ -23,20 +23,29 @@ struct KernelArgs {
     int numItems;   // pixels incl. tile padding (PER_PIXEL) or rows (ROW_SERIAL)
     int numChunks, chunkSize;
     unsigned totalWaves;
-    f4* stackBuf;                    // sorted kernel, FOLD_RECURSIVE: bounce stack [TPT_MAX_DEPTH][stackStride] in global memory
-    int stackStride;                 //   (= threads of the launch; a path keeps its column while it moves between lanes)
+    // FOLD_RECURSIVE bounce stack: the first ldsStackLevels levels live in LDS (per thread), deeper ones in
+    // stackBuf [TPT_MAX_DEPTH - ldsStackLevels][stackStride] (global, one column per thread of the launch).
+    // The lane-sorting kernel uses ldsStackLevels = 0: a path keeps its column while it moves between lanes.
+    f4* stackBuf;
+    int stackStride;
+    int ldsStackLevels;
+    f4* pathBuf;                     // path-queue kernel: cold path state [workgroups][paths][4] f4 (global, L2-resident)
     unsigned* work;                  // [0] next chunk, [1] finished waves (persistent variants)
     unsigned long long* rayCounter;  // monotonic total of rays traced by this context
 };
 
 } // namespace tpt
 
-size_t tptLdsBytes(const tpt::KernelArgs& a, int fold, bool ldsScene);
+size_t tptLdsBytes(const tpt::KernelArgs& a, int fold, bool ldsScene); // uses a.ldsStackLevels
 hipError_t tptLaunchTrace(const tpt::KernelArgs& a, int hs, int fold, bool persist, bool ldsScene, int blocks, size_t lds, hipStream_t stream);
 int tptTraceOccupancy(int hs, int fold, bool persist, bool ldsScene, size_t lds);
 size_t tptSortedLdsBytes(const tpt::KernelArgs& a, int fold, bool ldsScene);
 hipError_t tptLaunchTraceSorted(const tpt::KernelArgs& a, int fold, bool ldsScene, int blocks, size_t lds, hipStream_t stream);
 int tptTraceSortedOccupancy(int fold, bool ldsScene, size_t lds);
+size_t tptQueueLdsBytes(const tpt::KernelArgs& a, bool ldsScene);
+hipError_t tptLaunchTraceQueue(const tpt::KernelArgs& a, bool ldsScene, int blocks, size_t lds, hipStream_t stream);
+int tptQueuePathsPerBlock();
+int tptQueueThreadsPerBlock();
 hipError_t tptLaunchResolve(float* tile, const tpt::f4* frameColour, int nPixels, float lerpFac, hipStream_t stream);
 hipError_t tptLaunchMathTest(int op, const float* a, const float* b, float* out, int n, hipStream_t stream);
 hipError_t tptLaunchHitTest(const tpt::KernelArgs& a, int hs, const float* rays, int* outId, float* outT, int n, hipStream_t stream);

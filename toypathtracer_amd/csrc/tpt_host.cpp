@@ -52,15 +52,17 @@ struct Context {
     int hs = HS_TWO_PHASE, persist = 1, ldsScene = -1;
     int stripeRows = 0, numParts = 1, part = 0;
     int maxBlocksPerCU = 0, chunkOverride = 0; // tuning knobs (env TPT_MAX_BLOCKS_PER_CU, TPT_CHUNK)
-    bool globalStack = false;                   // recursive fold: bounce stack in global memory instead of LDS (env TPT_GLOBAL_STACK)
+    int ldsStackLevels = 6;                     // recursive fold: bounce-stack levels kept in LDS (env TPT_LDS_STACK_LEVELS)
 
     unsigned* dWork = nullptr;
     unsigned long long* dRays = nullptr;    // the counter kernels add to (own or caller-provided)
     unsigned long long* dRaysOwn = nullptr;
     long long lastTotal = 0;
 
-    f4* dStack[4] = {};       // sorted kernel, recursive fold: global bounce stacks (one per in-flight frame)
+    f4* dStack[4] = {};       // recursive fold: global bounce stacks / spill levels (one per in-flight frame)
     size_t stackCap[4] = {};
+    f4* dPath[4] = {};        // path-queue kernel: cold path state (one per in-flight frame)
+    size_t pathCap[4] = {};
     float* dFrame = nullptr; // device tile behind the host-pointer DrawTest
     size_t frameCap = 0;
 
@@ -223,7 +225,11 @@ int tptInitialize(void)
     if (g.spheres.empty()) defaultScene(g.spheres, g.mats);
     if (const char* e1 = getenv("TPT_MAX_BLOCKS_PER_CU")) g.maxBlocksPerCU = atoi(e1);
     if (const char* e2 = getenv("TPT_CHUNK")) g.chunkOverride = atoi(e2);
-    if (const char* e3 = getenv("TPT_GLOBAL_STACK")) g.globalStack = atoi(e3) != 0;
+    if (const char* e3 = getenv("TPT_LDS_STACK_LEVELS")) {
+        g.ldsStackLevels = atoi(e3);
+        if (g.ldsStackLevels < 0) g.ldsStackLevels = 0;
+        if (g.ldsStackLevels > TPT_MAX_DEPTH) g.ldsStackLevels = TPT_MAX_DEPTH;
+    }
     g.sceneDirty = true;
     g.inited = true;
     return 0;
@@ -247,6 +253,7 @@ int tptShutdown(void)
         if (g.evResolve[k]) hipEventDestroy(g.evResolve[k]);
         hipFree(g.dColour[k]);
         hipFree(g.dStack[k]); g.dStack[k] = nullptr; g.stackCap[k] = 0;
+        hipFree(g.dPath[k]); g.dPath[k] = nullptr; g.pathCap[k] = 0;
         g.traceStream[k] = nullptr; g.evTrace[k] = nullptr; g.evResolve[k] = nullptr; g.dColour[k] = nullptr; g.colourCap[k] = 0;
     }
     hipEventDestroy(g.ev0); hipEventDestroy(g.ev1);
@@ -335,7 +342,7 @@ int tptSetFrameOverlap(int frames)
 int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene)
 {
     g.hs = hitSpheres ? HS_SIMPLE : HS_TWO_PHASE;
-    g.persist = persistent < 0 ? 0 : (persistent > 2 ? 2 : persistent);
+    g.persist = persistent < 0 ? 0 : (persistent > 3 ? 3 : persistent);
     g.ldsScene = ldsScene < 0 ? -1 : (ldsScene ? 1 : 0);
     return 0;
 }
@@ -450,22 +457,28 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
 
     // LDS scene staging: default when {centre,r^2}+1/r (20 B/sphere) + lights + bounce stack fit in 64 KB
     const int nPad = a.scene.nPairs * 2;
-    bool ldsScene = g.ldsScene < 0 ? ((size_t)nPad * 20 + 4096 + (g.foldMode == FOLD_RECURSIVE ? 40960 : 0) <= 65536) : (g.ldsScene != 0);
-    const size_t ldsV1 = tptLdsBytes(a, (g.globalStack && g.persist) ? FOLD_FORWARD : g.foldMode, ldsScene); // no LDS stack when it lives in global memory
+    // (20 B per padded sphere + 48 B of material per sphere; 46 spheres: 3.2 KB, fits up to ~600 spheres in 40 KB)
+    bool ldsScene = g.ldsScene < 0 ? ((size_t)nPad * 20 + (size_t)a.scene.nSpheres * 48 <= 40960) : (g.ldsScene != 0);
+    // bounce stack: persistent kernel keeps the first levels in LDS and spills the rare deep ones to global memory;
+    // the thread-per-pixel kernel (huge grids) keeps all of it in LDS
+    a.ldsStackLevels = (g.persist && g.foldMode == FOLD_RECURSIVE) ? g.ldsStackLevels : TPT_MAX_DEPTH;
+    const size_t ldsV1 = tptLdsBytes(a, g.foldMode, ldsScene);
 
     const bool sorted = g.persist == 2 && !rowSerial && g.hs == HS_TWO_PHASE; // lane-sorting kernel (PER_PIXEL seeds only)
-    const size_t lds = sorted ? tptSortedLdsBytes(a, g.foldMode, ldsScene) : ldsV1;
+    // path-queue kernel: PER_PIXEL seeds, recursive fold, two-phase HitSpheres
+    const bool queued = g.persist == 3 && !rowSerial && g.hs == HS_TWO_PHASE && g.foldMode == FOLD_RECURSIVE;
+    const size_t lds = queued ? tptQueueLdsBytes(a, ldsScene) : sorted ? tptSortedLdsBytes(a, g.foldMode, ldsScene) : ldsV1;
     if (lds > 160 * 1024) return fail("tptDrawDevice: scene too large for LDS staging; use tptSetKernelVariant(.., .., 0)");
-    const int key = (sorted ? 16 : 0) | (g.hs ? 8 : 0) | (g.foldMode ? 4 : 0) | (g.persist ? 2 : 0) | (ldsScene ? 1 : 0) | ((int)(lds / 256) << 5);
+    const int key = (queued ? (1 << 30) : 0) | (sorted ? 16 : 0) | (g.hs ? 8 : 0) | (g.foldMode ? 4 : 0) | (g.persist ? 2 : 0) | (ldsScene ? 1 : 0) | ((int)(lds / 256) << 5);
     int occ;
     auto it = g.occCache.find(key);
     if (it == g.occCache.end()) {
-        occ = sorted ? tptTraceSortedOccupancy(g.foldMode, ldsScene, lds) : tptTraceOccupancy(g.hs, g.foldMode, g.persist != 0, ldsScene, lds);
+        occ = queued ? (int)(160 * 1024 / (lds + 256)) : sorted ? tptTraceSortedOccupancy(g.foldMode, ldsScene, lds) : tptTraceOccupancy(g.hs, g.foldMode, g.persist != 0, ldsScene, lds);
         g.occCache[key] = occ;
     } else {
         occ = it->second;
     }
-    const int threadsPerBlock = sorted ? 64 * TPT_SORT_WAVES : TPT_BLOCK;
+    const int threadsPerBlock = queued ? tptQueueThreadsPerBlock() : sorted ? 64 * TPT_SORT_WAVES : TPT_BLOCK;
     int blocks;
     if (g.persist) {
         int occUse = occ;
@@ -476,6 +489,7 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
         // small frames: hand out single 8x8 tiles so every resident wave gets several chunks
         if (!rowSerial && a.numItems / TPT_CHUNK_PIXELS < 8 * resident * wavesPerBlock) chunk = 64;
         if (!rowSerial && g.chunkOverride >= 64) chunk = g.chunkOverride & ~63;
+        if (queued) chunk = 64; // the path-queue kernel accounts its pixel pools in 64-pixel chunks
         a.chunkSize = chunk;
         a.numChunks = (a.numItems + chunk - 1) / chunk;
         blocks = (a.numChunks + wavesPerBlock - 1) / wavesPerBlock;
@@ -490,8 +504,10 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
     }
     a.stackBuf = nullptr;
     a.stackStride = 0;
-    if ((sorted || (g.globalStack && g.persist)) && g.foldMode == FOLD_RECURSIVE) {
-        const size_t need = (size_t)blocks * threadsPerBlock * TPT_MAX_DEPTH * sizeof(f4);
+    if (sorted || queued) a.ldsStackLevels = 0;
+    const int stackColumns = queued ? blocks * tptQueuePathsPerBlock() : blocks * threadsPerBlock;
+    if (g.persist && g.foldMode == FOLD_RECURSIVE && a.ldsStackLevels < TPT_MAX_DEPTH) {
+        const size_t need = (size_t)stackColumns * (TPT_MAX_DEPTH - a.ldsStackLevels) * sizeof(f4);
         if (need > g.stackCap[slot]) {
             HIPCHK(hipStreamSynchronize(g.stream));
             HIPCHK(hipStreamSynchronize(g.traceStream[slot]));
@@ -501,7 +517,20 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
             g.stackCap[slot] = need;
         }
         a.stackBuf = g.dStack[slot];
-        a.stackStride = blocks * threadsPerBlock;
+        a.stackStride = stackColumns;
+    }
+    a.pathBuf = nullptr;
+    if (queued) {
+        const size_t need = (size_t)blocks * tptQueuePathsPerBlock() * 4 * sizeof(f4);
+        if (need > g.pathCap[slot]) {
+            HIPCHK(hipStreamSynchronize(g.stream));
+            HIPCHK(hipStreamSynchronize(g.traceStream[slot]));
+            if (g.dPath[slot]) HIPCHK(hipFree(g.dPath[slot]));
+            g.dPath[slot] = nullptr;
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dPath[slot]), need));
+            g.pathCap[slot] = need;
+        }
+        a.pathBuf = g.dPath[slot];
     }
     g.lastBlocksPerCU = occ;
     g.lastLds = (int)lds;
@@ -511,7 +540,9 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
     if (nOverlap > 1 && g.resolveRecorded[slot]) HIPCHK(hipStreamWaitEvent(ts, g.evResolve[slot], 0)); // colour buffer free again
     const bool timeIt = g.kernelTiming && g.ktUsed < g.ktStart.size();
     if (timeIt) HIPCHK(hipEventRecord(g.ktStart[g.ktUsed], ts));
-    if (sorted)
+    if (queued)
+        HIPCHK(tptLaunchTraceQueue(a, ldsScene, blocks, lds, ts));
+    else if (sorted)
         HIPCHK(tptLaunchTraceSorted(a, g.foldMode, ldsScene, blocks, lds, ts));
     else
         HIPCHK(tptLaunchTrace(a, g.hs, g.foldMode, g.persist != 0, ldsScene, blocks, lds, ts));

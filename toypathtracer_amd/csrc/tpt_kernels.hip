@@ -72,8 +72,11 @@ __global__ void __launch_bounds__(256) tptResolveKernel(float* __restrict__ tile
     reinterpret_cast<f4*>(tile)[i] = t;
 }
 
+#ifndef TPT_MIN_WAVES_PER_SIMD
+#define TPT_MIN_WAVES_PER_SIMD 1
+#endif
 template <int HS, int FOLD, bool PERSIST, bool LDS_SCENE>
-__global__ void __launch_bounds__(TPT_BLOCK) tptTraceKernel(const KernelArgs a)
+__global__ void __launch_bounds__(TPT_BLOCK, TPT_MIN_WAVES_PER_SIMD) tptTraceKernel(const KernelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // ---- carve LDS (every offset a multiple of 16)
@@ -84,6 +87,8 @@ __global__ void __launch_bounds__(TPT_BLOCK) tptTraceKernel(const KernelArgs a)
     off += LDS_SCENE ? ((nPad * 4 + 15) & ~15) : 0;
     f4* ldsLights = reinterpret_cast<f4*>(smem + off);
     off += a.scene.nLights * 32;
+    f4* ldsMats = reinterpret_cast<f4*>(smem + off);
+    off += LDS_SCENE ? a.scene.nSpheres * 48 : 0;
     f4* ldsStack = reinterpret_cast<f4*>(smem + off);
 
     SceneView sv = a.scene;
@@ -92,21 +97,21 @@ __global__ void __launch_bounds__(TPT_BLOCK) tptTraceKernel(const KernelArgs a)
             ldsSph[i] = a.scene.sph4[i];
             ldsInvR[i] = a.scene.invR[i];
         }
+        for (int i = threadIdx.x; i < a.scene.nSpheres * 3; i += TPT_BLOCK) ldsMats[i] = a.scene.mats[i];
         sv.sph4 = ldsSph;
         sv.invR = ldsInvR;
+        sv.mats = ldsMats; // materials are read on every hit and every fold level: LDS latency instead of L2
     }
     for (int i = threadIdx.x; i < a.scene.nLights * 2; i += TPT_BLOCK) ldsLights[i] = a.scene.lights[i];
     sv.lights = ldsLights;
     __syncthreads();
 
     BounceStack stack;
-    if (a.stackBuf) { // recursive fold with the bounce stack in global memory (one column per thread of the launch)
-        stack.base = a.stackBuf + (blockIdx.x * TPT_BLOCK + threadIdx.x);
-        stack.stride = a.stackStride;
-    } else {
-        stack.base = ldsStack + threadIdx.x;
-        stack.stride = TPT_BLOCK;
-    }
+    stack.base = ldsStack + threadIdx.x;
+    stack.stride = TPT_BLOCK;
+    stack.fastLevels = a.ldsStackLevels;
+    stack.spill = a.stackBuf + (blockIdx.x * TPT_BLOCK + threadIdx.x);
+    stack.spillStride = a.stackStride;
 
     const FrameConsts& fc = a.fc;
     const bool rowSerial = fc.seedMode == SEED_ROW_SERIAL;
@@ -221,6 +226,7 @@ __global__ void __launch_bounds__(TPT_BLOCK) tptTraceKernel(const KernelArgs a)
 // ~25 % (profiles/r01/block_stats_megakernel_v1.txt).  Two workgroup barriers per step.  The FOLD_RECURSIVE bounce
 // stack moves to global memory (column = L.slot, travels with the path).
 #define TPT_SORT_T (64 * TPT_SORT_WAVES)
+static_assert(TPT_SORT_T < 1024, "per-class counters are 10-bit fields: a workgroup of 1024 lanes would overflow them");
 template <int FOLD>
 struct SortPack {
     static constexpr int N = FOLD == FOLD_FORWARD ? 11 : 9;
@@ -302,6 +308,8 @@ __global__ void __launch_bounds__(TPT_SORT_T) tptTraceSortedKernel(const KernelA
     off += LDS_SCENE ? ((nPad * 4 + 15) & ~15) : 0;
     f4* ldsLights = reinterpret_cast<f4*>(smem + off);
     off += a.scene.nLights * 32;
+    f4* ldsMats = reinterpret_cast<f4*>(smem + off);
+    off += LDS_SCENE ? a.scene.nSpheres * 48 : 0;
     f4* xch = reinterpret_cast<f4*>(smem + off);
     off += SortPack<FOLD>::N * TPT_SORT_T * 16;
     unsigned long long* cnt = reinterpret_cast<unsigned long long*>(smem + off);
@@ -312,8 +320,10 @@ __global__ void __launch_bounds__(TPT_SORT_T) tptTraceSortedKernel(const KernelA
             ldsSph[i] = a.scene.sph4[i];
             ldsInvR[i] = a.scene.invR[i];
         }
+        for (int i = threadIdx.x; i < a.scene.nSpheres * 3; i += TPT_SORT_T) ldsMats[i] = a.scene.mats[i];
         sv.sph4 = ldsSph;
         sv.invR = ldsInvR;
+        sv.mats = ldsMats;
     }
     for (int i = threadIdx.x; i < a.scene.nLights * 2; i += TPT_SORT_T) ldsLights[i] = a.scene.lights[i];
     sv.lights = ldsLights;
@@ -407,8 +417,11 @@ __global__ void __launch_bounds__(TPT_SORT_T) tptTraceSortedKernel(const KernelA
         // ---- (8) post-intersection work; lanes of a wave now mostly need the same block
         if (L.active) {
             BounceStack stack;
-            stack.base = a.stackBuf + L.slot;
-            stack.stride = a.stackStride;
+            stack.base = nullptr;
+            stack.stride = 0;
+            stack.fastLevels = 0;
+            stack.spill = a.stackBuf + L.slot;
+            stack.spillStride = a.stackStride;
             if (lanePost<FOLD>(L, id, t, sv, fc, stack)) {
                 storeColour(a, L);
                 L.active = false;
@@ -417,6 +430,381 @@ __global__ void __launch_bounds__(TPT_SORT_T) tptTraceSortedKernel(const KernelA
     }
 
     unsigned waveRays = waveReduceAdd(L.rays);
+    if (lane == 0) {
+        atomicAdd(a.rayCounter, (unsigned long long)waveRays);
+        unsigned done = atomicAdd(&a.work[1], 1u) + 1u;
+        if (done == a.totalWaves) {
+            a.work[0] = 0u;
+            a.work[1] = 0u;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- path-queue variant
+// A workgroup of 8 waves owns a pool of 1024 paths (2 per lane, so the queues below stay deep enough to hand out
+// full batches); two such workgroups fit on a CU, so consecutive frames still overlap.  Waves are interchangeable
+// workers that pop batches of up to 64 path ids from per-operation queues in LDS:
+//   FREE -> [start: assign a pixel, camera ray] -> INT -> [HitWorld, classify] -> END | DIEL | METAL | LAMBERT | SHADOW
+//        -> [lanePost for that class, + fold / next sample's camera ray] -> INT ... or FREE when the pixel is done.
+// A batch holds paths that all need the same code, so the post-intersection blocks run at (nearly) full lane
+// utilisation instead of ~25 %, and a lane never idles because "its" pixel ended: any wave picks up any path.
+// No barriers: the queues are multi-producer / multi-consumer rings (reserve with an LDS atomic, publish by
+// overwriting a 0xFFFF sentinel).  Path state: the 48 B every operation needs (ray, rng, flags, hit) live in LDS;
+// the light-sampling context (48 B) and the pixel's colour sum (16 B) are only touched by some classes and live in
+// global memory (L2-resident: 64 B x 1024 paths x 512 workgroups = 32 MB).  FOLD_RECURSIVE only; the bounce stack
+// is in global memory, one column per path.
+#ifndef TPT_Q_WAVES
+#define TPT_Q_WAVES 8
+#endif
+#define TPT_Q_T (64 * TPT_Q_WAVES)
+#ifndef TPT_Q_P
+#define TPT_Q_P 1024 // paths per workgroup (power of two)
+#endif
+#define TPT_Q_NF4 3
+enum { Q_FREE = 0, Q_INT = 1, Q_END = 2, Q_DIEL = 3, Q_METAL = 4, Q_LAMBERT = 5, Q_SHADOW = 6, Q_COUNT = 7 };
+struct QueueCtl {
+    unsigned head[8];
+    unsigned tail[8];
+    unsigned poolTotal;       // pixels sitting in the private chunk pools of this workgroup's waves (+ fetches in flight)
+    unsigned globalExhausted; // some wave saw the global chunk counter run out
+};
+
+__device__ __forceinline__ void qPush(volatile unsigned short* q, unsigned* tail, bool want, int pathId, int lane)
+{
+    const unsigned long long m = __ballot(want);
+    if (m == 0ull) return;
+    const int leader = (int)__ffsll((long long)m) - 1;
+    unsigned pos = 0;
+    if (lane == leader) pos = atomicAdd(tail, (unsigned)__popcll(m));
+    pos = (unsigned)__builtin_amdgcn_readlane((int)pos, leader);
+    if (want) q[(pos + (unsigned)__popcll(m & ((1ull << lane) - 1ull))) & (TPT_Q_P - 1)] = (unsigned short)pathId;
+}
+// Push every lane's path id to the queue of its class `cls` (Q_FREE..Q_SHADOW, or -1 for none) with ONE LDS atomic
+// instruction: lane c reserves the slots of class c, the bases come back through readlane.
+__device__ __forceinline__ void qPushByClass(volatile unsigned short* q, QueueCtl* ctl, int cls, int pathId, int lane)
+{
+    unsigned long long mine = 0ull;
+    unsigned myCount = 0;
+#pragma unroll
+    for (int c = 0; c < Q_COUNT; ++c) {
+        const unsigned long long m = __ballot(cls == c);
+        if (cls == c) mine = m;
+        if (lane == c) myCount = (unsigned)__popcll(m);
+    }
+    unsigned pos = 0;
+    if (lane < Q_COUNT && myCount != 0u) pos = atomicAdd(&ctl->tail[lane], myCount);
+    unsigned base = 0;
+#pragma unroll
+    for (int c = 0; c < Q_COUNT; ++c) {
+        const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)pos, c);
+        if (cls == c) base = b;
+    }
+    if (cls >= 0) q[cls * TPT_Q_P + ((base + (unsigned)__popcll(mine & ((1ull << lane) - 1ull))) & (TPT_Q_P - 1))] = (unsigned short)pathId;
+}
+// Pops up to 64 ids (uniform count returned); lanes < count receive a path id.
+__device__ __forceinline__ int qPop(volatile unsigned short* q, unsigned* head, unsigned* tail, int lane, int& pathId)
+{
+    unsigned h = 0, n = 0;
+    if (lane == 0) {
+        for (;;) {
+            h = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned t = __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned avail = t - h;
+            n = avail < 64u ? avail : 64u;
+            if (n == 0u) break;
+            if (atomicCAS(head, h, h + n) == h) break;
+        }
+    }
+    h = (unsigned)__builtin_amdgcn_readfirstlane((int)h);
+    n = (unsigned)__builtin_amdgcn_readfirstlane((int)n);
+    pathId = 0;
+    if ((unsigned)lane < n) {
+        const unsigned slot = (h + (unsigned)lane) & (TPT_Q_P - 1);
+        unsigned v;
+        do {
+            v = q[slot]; // the producer reserved this slot; wait until it has written the id
+        } while (v == 0xFFFFu);
+        q[slot] = 0xFFFFu;
+        pathId = (int)v;
+    }
+    return (int)n;
+}
+
+__device__ __forceinline__ uint32_t qFlags(const Lane& L)
+{
+    return ((uint32_t)L.sample & 0xffffu) | (((uint32_t)L.depth & 15u) << 16) | ((uint32_t)(L.kind & 1) << 20) |
+           (((uint32_t)L.hitType & 3u) << 21) | ((uint32_t)L.active << 23) | ((uint32_t)L.needCamera << 24) |
+           ((uint32_t)L.doMatE << 25) | (((uint32_t)L.sp & 15u) << 26);
+}
+__device__ __forceinline__ void qUnflags(Lane& L, uint32_t flags)
+{
+    L.sample = (int)(flags & 0xffffu);
+    L.depth = (int)((flags >> 16) & 15u);
+    L.kind = (int)((flags >> 20) & 1u);
+    L.hitType = (int)((flags >> 21) & 3u);
+    L.active = ((flags >> 23) & 1u) != 0;
+    L.needCamera = ((flags >> 24) & 1u) != 0;
+    L.doMatE = ((flags >> 25) & 1u) != 0;
+    L.sp = (int)((flags >> 26) & 15u);
+}
+// hot state (LDS): [0] orig.xyz rng  [1] dir.xyz t  [2] flags, id, pix, hitId | j << 20
+__device__ __forceinline__ void qStoreHot(const Lane& L, f4* st, int p)
+{
+    st[0 * TPT_Q_P + p] = mk4(L.orig.x, L.orig.y, L.orig.z, u2f(L.rng));
+    st[1 * TPT_Q_P + p] = mk4(L.dir.x, L.dir.y, L.dir.z, 0.0f);
+    st[2 * TPT_Q_P + p] = mk4(u2f(qFlags(L)), 0.0f, u2f((uint32_t)L.pix), u2f((uint32_t)L.hitId | ((uint32_t)L.j << 20)));
+}
+__device__ __forceinline__ void qLoadHot(Lane& L, int& id, float& t, const f4* st, int p)
+{
+    f4 v = st[0 * TPT_Q_P + p];
+    L.orig = mk3(v.x, v.y, v.z); L.rng = f2u(v.w);
+    v = st[1 * TPT_Q_P + p];
+    L.dir = mk3(v.x, v.y, v.z); t = v.w;
+    v = st[2 * TPT_Q_P + p];
+    qUnflags(L, f2u(v.x));
+    id = (int)f2u(v.y);
+    L.pix = (int)f2u(v.z);
+    L.hitId = (int)(f2u(v.w) & 0xfffffu);
+    L.j = (int)(f2u(v.w) >> 20);
+}
+// cold state (global, per path): [0] sdir.xyz cosAMax  [1] nl.xyz -  [2] lightE.xyz -  [3] col.xyz x|y<<16
+
+template <bool LDS_SCENE>
+__global__ void __launch_bounds__(TPT_Q_T) tptTraceQueueKernel(const KernelArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int nPad = a.scene.nPairs * 2;
+    f4* ldsSph = reinterpret_cast<f4*>(smem);
+    int off = LDS_SCENE ? nPad * 16 : 0;
+    float* ldsInvR = reinterpret_cast<float*>(smem + off);
+    off += LDS_SCENE ? ((nPad * 4 + 15) & ~15) : 0;
+    f4* ldsLights = reinterpret_cast<f4*>(smem + off);
+    off += a.scene.nLights * 32;
+    f4* ldsMats = reinterpret_cast<f4*>(smem + off);
+    off += LDS_SCENE ? a.scene.nSpheres * 48 : 0;
+    f4* st = reinterpret_cast<f4*>(smem + off);
+    off += TPT_Q_NF4 * TPT_Q_P * 16;
+    volatile unsigned short* q = reinterpret_cast<volatile unsigned short*>(smem + off);
+    off += Q_COUNT * TPT_Q_P * 2;
+    QueueCtl* ctl = reinterpret_cast<QueueCtl*>(smem + off);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    SceneView sv = a.scene;
+    if (LDS_SCENE) {
+        for (int i = tid; i < nPad; i += TPT_Q_T) {
+            ldsSph[i] = a.scene.sph4[i];
+            ldsInvR[i] = a.scene.invR[i];
+        }
+        for (int i = tid; i < a.scene.nSpheres * 3; i += TPT_Q_T) ldsMats[i] = a.scene.mats[i];
+        sv.sph4 = ldsSph;
+        sv.invR = ldsInvR;
+        sv.mats = ldsMats;
+    }
+    for (int i = tid; i < a.scene.nLights * 2; i += TPT_Q_T) ldsLights[i] = a.scene.lights[i];
+    sv.lights = ldsLights;
+    // every path starts in the FREE queue; all other queues empty (sentinel everywhere)
+    for (int i = tid; i < Q_COUNT * TPT_Q_P; i += TPT_Q_T) q[i] = (unsigned short)(i < TPT_Q_P ? i : 0xFFFF);
+    if (tid < 8) {
+        ctl->head[tid] = 0u;
+        ctl->tail[tid] = tid == Q_FREE ? (unsigned)TPT_Q_P : 0u;
+    }
+    if (tid == 0) {
+        ctl->poolTotal = 0u;
+        ctl->globalExhausted = 0u;
+    }
+    __syncthreads();
+
+    const FrameConsts& fc = a.fc;
+    const unsigned long long laneBelow = (1ull << lane) - 1ull;
+    f4* cold = a.pathBuf + (size_t)blockIdx.x * TPT_Q_P * 4; // this workgroup's [P][4] f4
+    int chunkNext = 0, chunkEnd = 0; // this wave's private pixel pool
+    bool noMoreChunks = false;
+    unsigned waveRays = 0;
+
+    for (;;) {
+        // ---- what is waiting?  lanes 0..6 read one queue each, broadcast through readlane
+        unsigned myAvail = 0;
+        if (lane < Q_COUNT)
+            myAvail = __hip_atomic_load(&ctl->tail[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) -
+                      __hip_atomic_load(&ctl->head[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        unsigned avail[Q_COUNT];
+#pragma unroll
+        for (int c = 0; c < Q_COUNT; ++c) avail[c] = (unsigned)__builtin_amdgcn_readlane((int)myAvail, c);
+        const bool canStart = (chunkEnd > chunkNext) || !noMoreChunks;
+        int pick = -1;
+        unsigned best = 0;
+        // full batches first (the fullest queue), FREE preferred so the pool of live paths stays full
+        if (canStart && avail[Q_FREE] >= 64u) pick = Q_FREE;
+        if (pick < 0) {
+#pragma unroll
+            for (int c = 1; c < Q_COUNT; ++c)
+                if (avail[c] >= 64u && avail[c] > best) {
+                    best = avail[c];
+                    pick = c;
+                }
+        }
+        if (pick < 0) { // no full batch anywhere: take the largest partial one
+#pragma unroll
+            for (int c = 0; c < Q_COUNT; ++c)
+                if ((c != Q_FREE || canStart) && avail[c] > best) {
+                    best = avail[c];
+                    pick = c;
+                }
+        }
+        if (pick < 0) {
+            // nothing to do for this wave right now: done if every path is free and no pixel is left anywhere
+            const unsigned pool = __hip_atomic_load(&ctl->poolTotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned exhausted = __hip_atomic_load(&ctl->globalExhausted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (avail[Q_FREE] == (unsigned)TPT_Q_P && pool == 0u && exhausted != 0u && !canStart) break;
+            if (exhausted != 0u && pool == 0u) noMoreChunks = true;
+            TPT_STAT(ST_REFILL); // idle polls
+            __builtin_amdgcn_s_sleep(4);
+            continue;
+        }
+        int p = 0;
+        const int n = qPop(q + pick * TPT_Q_P, &ctl->head[pick], &ctl->tail[pick], lane, p);
+        if (n == 0) continue;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const bool mine = lane < n;
+#if defined(TPT_STATS)
+        if (mine) { TPT_STAT(16 + pick); } // [16+pick] batches popped per queue, [48+pick] paths in them
+#endif
+
+        if (pick == Q_FREE) {
+            // ---- start pixels on free paths (this wave's chunk pool, refilled from the global counter)
+            Lane L;
+            L.active = false;
+            bool need = mine;
+            for (;;) {
+                const unsigned long long needMask = __ballot(need);
+                if (needMask == 0ull) break;
+                if (chunkNext >= chunkEnd) {
+                    if (noMoreChunks) break;
+                    int c = 0;
+                    if (lane == 0) {
+                        atomicAdd(&ctl->poolTotal, 64u); // optimistic: keeps "pixels left" non-zero while the fetch is in flight
+                        c = (int)atomicAdd(&a.work[0], 1u);
+                    }
+                    c = __builtin_amdgcn_readfirstlane(c);
+                    if (c >= a.numChunks) {
+                        if (lane == 0) {
+                            atomicSub(&ctl->poolTotal, 64u);
+                            __hip_atomic_store(&ctl->globalExhausted, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                        noMoreChunks = true;
+                        break;
+                    }
+                    chunkNext = c * a.chunkSize;
+                    chunkEnd = chunkNext + a.chunkSize;
+                    if (chunkEnd > a.numItems) chunkEnd = a.numItems;
+                    if (lane == 0 && chunkEnd - chunkNext != 64) atomicSub(&ctl->poolTotal, (unsigned)(64 - (chunkEnd - chunkNext)));
+                }
+                const int rank = __popcll(needMask & laneBelow);
+                const int want = __popcll(needMask);
+                const int availPx = chunkEnd - chunkNext;
+                const int take = want < availPx ? want : availPx;
+                if (need && rank < take) {
+                    int x, ly;
+                    if (mapItem(a, chunkNext + rank, x, ly)) {
+                        laneBeginPixel(L, fc, x, localRowToGlobal(a, ly), ly * fc.width + x, true);
+                        need = false;
+                    }
+                }
+                chunkNext += take;
+                if (lane == 0) atomicSub(&ctl->poolTotal, (unsigned)take);
+            }
+            if (mine && L.active) {
+                L.hitType = 0; L.j = 0; L.hitId = 0;
+                laneCamera<FOLD_RECURSIVE>(L, fc);
+                qStoreHot(L, st, p);
+                cold[p * 4 + 3] = mk4(0.0f, 0.0f, 0.0f, u2f((uint32_t)L.x | ((uint32_t)L.y << 16))); // colour sum = 0
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            qPushByClass(q, ctl, mine ? (L.active ? Q_INT : Q_FREE) : -1, p, lane); // FREE again: no pixel left for these
+        } else if (pick == Q_INT) {
+            // ---- HitWorld for a batch of rays (camera, bounce and shadow rays alike), then classify
+            int cls = -1;
+            if (mine) {
+                TPT_STAT(ST_STEP);
+                const f4 v0 = st[0 * TPT_Q_P + p], v1 = st[1 * TPT_Q_P + p];
+                const uint32_t flags = f2u(st[2 * TPT_Q_P + p].x);
+                float t;
+                const int id = hitSpheres<HS_TWO_PHASE>(sv, mk3(v0.x, v0.y, v0.z), mk3(v1.x, v1.y, v1.z), TPT_MIN_T, TPT_MAX_T, t);
+                reinterpret_cast<float*>(&st[1 * TPT_Q_P + p])[3] = t;
+                reinterpret_cast<float*>(&st[2 * TPT_Q_P + p])[1] = u2f((uint32_t)id);
+                const int kind = (int)((flags >> 20) & 1u), depth = (int)((flags >> 16) & 15u);
+                if (kind == KIND_SHADOW)
+                    cls = Q_SHADOW;
+                else if (id < 0 || depth >= TPT_MAX_DEPTH)
+                    cls = Q_END;
+                else {
+                    const int type = (int)f2u(sv.mats[id * 3].w);
+                    cls = type == MAT_LAMBERT ? Q_LAMBERT : type == MAT_METAL ? Q_METAL : type == MAT_DIELECTRIC ? Q_DIEL : Q_END;
+                }
+            }
+            waveRays += (unsigned)n;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            qPushByClass(q, ctl, cls, p, lane);
+        } else {
+            // ---- post-intersection work of one class, at full lane utilisation
+            bool toInt = false, toFree = false;
+            if (mine) {
+                Lane L;
+                int id;
+                float t;
+                qLoadHot(L, id, t, st, p);
+                L.sdir = L.nl = L.lightE = L.albedo = L.matE = mk3(0, 0, 0);
+                L.cosAMax = 0.0f;
+                if (pick == Q_SHADOW) { // light-sampling context of the surface this shadow ray belongs to
+                    const f4 c0 = cold[p * 4 + 0], c1 = cold[p * 4 + 1], c2 = cold[p * 4 + 2];
+                    L.sdir = mk3(c0.x, c0.y, c0.z); L.cosAMax = c0.w;
+                    L.nl = mk3(c1.x, c1.y, c1.z);
+                    L.lightE = mk3(c2.x, c2.y, c2.z);
+                    const f4 m0 = sv.mats[L.hitId * 3], m1 = sv.mats[L.hitId * 3 + 1];
+                    L.albedo = mk3(m0.x, m0.y, m0.z);
+                    if (L.doMatE) L.matE = mk3(m1.x, m1.y, m1.z); // Test.cpp:210, decided when the surface was hit
+                }
+                BounceStack stack;
+                stack.base = nullptr;
+                stack.stride = 0;
+                stack.fastLevels = 0;
+                stack.spill = a.stackBuf + ((size_t)blockIdx.x * TPT_Q_P + p);
+                stack.spillStride = a.stackStride;
+                L.col = mk3(0, 0, 0); // colour of the sample that ends in this step, if one does (0 + c == c)
+                L.x = 0; L.y = 0;
+                const int sampleBefore = L.sample;
+                const bool pixelDone = lanePost<FOLD_RECURSIVE>(L, id, t, sv, fc, stack);
+                if (L.sample != sampleBefore) {
+                    // a sample ended: add it to the pixel's running sum (same order of additions as Test.cpp:289)
+                    const f4 c3 = cold[p * 4 + 3];
+                    L.col = mk3(c3.x, c3.y, c3.z) + L.col;
+                    L.x = (int)(f2u(c3.w) & 0xffffu);
+                    L.y = (int)(f2u(c3.w) >> 16);
+                    if (pixelDone) {
+                        storeColour(a, L);
+                        toFree = true;
+                    } else {
+                        cold[p * 4 + 3] = mk4(L.col.x, L.col.y, L.col.z, c3.w);
+                        laneCamera<FOLD_RECURSIVE>(L, fc); // needCamera is set: next sample of the same pixel
+                    }
+                } else if (L.kind == KIND_SHADOW) {
+                    // in the light loop (Lambert hit or next light): keep the context for the shadow ray's return
+                    cold[p * 4 + 0] = mk4(L.sdir.x, L.sdir.y, L.sdir.z, L.cosAMax);
+                    if (pick != Q_SHADOW) cold[p * 4 + 1] = mk4(L.nl.x, L.nl.y, L.nl.z, 0.0f); // unchanged between lights
+                    cold[p * 4 + 2] = mk4(L.lightE.x, L.lightE.y, L.lightE.z, 0.0f);
+                }
+                if (!toFree) {
+                    qStoreHot(L, st, p);
+                    toInt = true;
+                }
+            }
+            // (the cold state is global memory, but every wave that can pop this path runs on this CU and shares its L1:
+            //  the workgroup-scope release orders the stores before the queue entry becomes visible)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            qPushByClass(q, ctl, toInt ? Q_INT : toFree ? Q_FREE : -1, p, lane);
+        }
+    }
+
     if (lane == 0) {
         atomicAdd(a.rayCounter, (unsigned long long)waveRays);
         unsigned done = atomicAdd(&a.work[1], 1u) + 1u;
@@ -496,7 +884,8 @@ size_t tptLdsBytes(const KernelArgs& a, int fold, bool ldsScene)
     size_t bytes = 0;
     if (ldsScene) bytes += (size_t)nPad * 16 + (((size_t)nPad * 4 + 15) & ~(size_t)15);
     bytes += (size_t)a.scene.nLights * 32;
-    if (fold == FOLD_RECURSIVE) bytes += (size_t)TPT_MAX_DEPTH * TPT_BLOCK * 16;
+    if (ldsScene) bytes += (size_t)a.scene.nSpheres * 48;
+    if (fold == FOLD_RECURSIVE) bytes += (size_t)a.ldsStackLevels * TPT_BLOCK * 16;
     return bytes;
 }
 
@@ -559,6 +948,7 @@ size_t tptSortedLdsBytes(const KernelArgs& a, int fold, bool ldsScene)
     size_t bytes = 0;
     if (ldsScene) bytes += (size_t)nPad * 16 + (((size_t)nPad * 4 + 15) & ~(size_t)15);
     bytes += (size_t)a.scene.nLights * 32;
+    if (ldsScene) bytes += (size_t)a.scene.nSpheres * 48;
     bytes += (size_t)(fold == FOLD_FORWARD ? 11 : 9) * TPT_SORT_T * 16;
     bytes += 64;
     return bytes;
@@ -593,6 +983,33 @@ int tptTraceSortedOccupancy(int fold, bool ldsScene, size_t lds)
     if (fold == FOLD_FORWARD) return ldsScene ? occupancySortedOne<FOLD_FORWARD, true>(lds) : occupancySortedOne<FOLD_FORWARD, false>(lds);
     return ldsScene ? occupancySortedOne<FOLD_RECURSIVE, true>(lds) : occupancySortedOne<FOLD_RECURSIVE, false>(lds);
 }
+
+size_t tptQueueLdsBytes(const KernelArgs& a, bool ldsScene)
+{
+    const int nPad = a.scene.nPairs * 2;
+    size_t bytes = 0;
+    if (ldsScene) bytes += (size_t)nPad * 16 + (((size_t)nPad * 4 + 15) & ~(size_t)15) + (size_t)a.scene.nSpheres * 48;
+    bytes += (size_t)a.scene.nLights * 32;
+    bytes += (size_t)TPT_Q_NF4 * TPT_Q_P * 16 + (size_t)Q_COUNT * TPT_Q_P * 2 + sizeof(QueueCtl) + 64;
+    return bytes;
+}
+hipError_t tptLaunchTraceQueue(const KernelArgs& a, bool ldsScene, int blocks, size_t lds, hipStream_t stream)
+{
+    if (ldsScene) {
+        auto k = tptTraceQueueKernel<true>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(TPT_Q_T), lds, stream, a);
+    } else {
+        auto k = tptTraceQueueKernel<false>;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(TPT_Q_T), lds, stream, a);
+    }
+    return hipGetLastError();
+}
+int tptQueuePathsPerBlock() { return TPT_Q_P; }
+int tptQueueThreadsPerBlock() { return TPT_Q_T; }
 
 hipError_t tptLaunchResolve(float* tile, const f4* frameColour, int nPixels, float lerpFac, hipStream_t stream)
 {

@@ -193,6 +193,31 @@ TPT_HD int hitSpheresTwoPhase(const SceneView& sv, f3 o, f3 d, float tMin, float
         uint32_t cand0 = ~m0 << (32 - 2 * c0);
         uint32_t cand1 = c1 ? (~m1 << (32 - 2 * c1)) : 0u;
         uint64_t cand = ((uint64_t)cand0 << 32) | cand1;
+#if defined(TPT_PHASE2_PREFETCH)
+        // software pipeline: the {centre, r^2} record of the NEXT candidate is fetched while this one is tested
+        if (cand) {
+            int k = __builtin_clzll(cand);
+            cand &= ~(0x8000000000000000ull >> k);
+            int i = pb * 2 + k;
+            f4 rec = sv.sph4[i];
+            for (;;) {
+                int iNext = i;
+                f4 recNext = rec;
+                const bool more = cand != 0;
+                if (more) {
+                    int kn = __builtin_clzll(cand);
+                    cand &= ~(0x8000000000000000ull >> kn);
+                    iNext = pb * 2 + kn;
+                    recNext = sv.sph4[iNext];
+                }
+                TPT_STAT(ST_PHASE2);
+                testSphere(rec, i, o, d, tMin, hitT, id);
+                if (!more) break;
+                i = iNext;
+                rec = recNext;
+            }
+        }
+#else
         while (cand) {
             int k = __builtin_clzll(cand);
             cand &= ~(0x8000000000000000ull >> k);
@@ -200,6 +225,7 @@ TPT_HD int hitSpheresTwoPhase(const SceneView& sv, f3 o, f3 d, float tMin, float
             TPT_STAT(ST_PHASE2);
             testSphere(sv.sph4[i], i, o, d, tMin, hitT, id);
         }
+#endif
     }
     outT = hitT;
     return id;
@@ -250,15 +276,25 @@ struct Lane {
 // attenuation = albedo of material attId, -1 -> (1,1,1) (dielectric, Test.cpp:158).
 // Device: LDS, laid out [level][thread]; host test: plain array.
 struct BounceStack {
-    f4* base;
-    int stride; // elements between consecutive levels
+    f4* base;       // levels [0, fastLevels): LDS on the device (host test: plain array)
+    int stride;     // elements between consecutive levels
+    f4* spill;      // levels [fastLevels, TPT_MAX_DEPTH): global memory (only ~3 % of the samples get there)
+    int spillStride;
+    int fastLevels;
     TPT_HD void push(int level, f3 e, int attId) const
     {
         f4 v;
         v.x = e.x; v.y = e.y; v.z = e.z; v.w = u2f((uint32_t)attId);
-        base[level * stride] = v;
+        if (level < fastLevels)
+            base[level * stride] = v;
+        else
+            spill[(level - fastLevels) * spillStride] = v;
     }
-    TPT_HD f4 get(int level) const { return base[level * stride]; }
+    TPT_HD f4 get(int level) const
+    {
+        if (level < fastLevels) return base[level * stride];
+        return spill[(level - fastLevels) * spillStride];
+    }
 };
 
 TPT_HD uint32_t pixelSeed(int seedMode, int x, int y, int frame)

@@ -130,6 +130,9 @@ int tptGetLaunchInfo(int* outBlocksPerCU, int* outLdsBytes, int* outGridBlocks, 
 /* profiling builds only (-DTPT_STATS): 64 counters, wave-level entries [i] / lane counts [32+i] of the
  * state machine's blocks (enum ST_* in tpt_trace.h); the shipped build returns an error. */
 int tptDebugStats(unsigned long long* out64, int reset);
+/* per-chunk accumulated ray counts and the chunk order table of the last launch (cost-ordered work distribution
+ * of the persistent kernel); either pointer may be NULL; returns the number of chunks copied */
+int tptDebugChunkOrder(unsigned* outCost, unsigned* outOrder, int capacity);
 const char* tptGetLastError(void);
 const char* tptGetDeviceName(void);
 

@@ -281,3 +281,24 @@ def test_experimental_kernels_full_size_and_stress(tpt_defaults, oracle, variant
                         STRESS_CAMERA["aperture"], STRESS_CAMERA["focus_dist"])
     ro, bo, pero = oracle_frames(oracle, 96, 54, 2, 2, spheres=s, mats=m, cam=cam, seed_mode=SEED_PER_PIXEL, fold_mode=fold)
     assert per == pero and bb.tobytes() == bo.tobytes()
+
+
+def test_cost_ordered_chunks_table_is_a_permutation_and_image_unchanged(tpt_defaults, oracle):
+    """The persistent kernel hands out 8x8 tiles expensive-first from the previous frames' ray counts; the order table
+    is rebuilt while other frames are in flight and must stay a permutation (every tile rendered exactly once)."""
+    import torch
+    tpt = tpt_defaults
+    w, h, frames = 640, 360, 20
+    tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    r0 = tpt.ray_counter_read()
+    for f in range(frames):
+        tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+        tpt.draw_device(0.0, f, w, h, tile.data_ptr(), FLAG_PROGRESSIVE)
+        if f in (3, 9, 19):
+            cost, order = tpt.debug_chunk_order()
+            assert len(order) == (w // 8) * (h // 8)
+            assert np.array_equal(np.sort(order), np.arange(len(order), dtype=np.uint32))
+            assert cost[order[0]] >= cost[order[-1]] and cost.min() > 0
+    rays = tpt.ray_counter_read() - r0
+    ro, bo, _ = oracle_frames(oracle, w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
+    assert rays == ro and tile.cpu().numpy().tobytes() == bo.tobytes()

@@ -51,3 +51,23 @@ def simulate(nwaves, chunk, order=None):
 for nw, ch in [(3072, 64), (3072, 256), (2048, 64), (1024, 64), (4096, 64)]:
     u, steps, end = simulate(nw, ch)
     print("waves %d chunk %d: lane utilisation %.3f wave-steps %d makespan(steps) %d ideal %d" % (nw, ch, u, steps, end, tiles.sum() // 64 // nw))
+# what would cost-sorted chunk order buy (longest-processing-time first, costs known from the previous frame)?
+chunk_cost = tiles.reshape(-1, 64).sum(axis=1)
+chunk_max = tiles.reshape(-1, 64).max(axis=1)
+for name, order in [("by chunk sum desc", np.argsort(-chunk_cost)), ("by chunk max desc", np.argsort(-chunk_max))]:
+    u, steps, end = simulate(4096, 64, order)
+    print("%s: lane utilisation %.3f wave-steps %d makespan %d" % (name, u, steps, end))
+u, steps, end = simulate(4096, 64)
+print("image order (bottom-up): lane utilisation %.3f wave-steps %d makespan %d" % (u, steps, end))
+# realistic version: order from the PREVIOUS frame's per-chunk statistics, applied to this frame
+bb2 = np.zeros((h, w, 4), np.float32); pp2 = np.zeros((h, w), np.int32)
+emu.emu_render_ex(s.ctypes.data, m.ctypes.data, 46, cam.ctypes.data, w, h, 0, h, spp, 1, 2, 1, 0, 0, bb2.ctypes.data, pp2.ctypes.data)
+tiles_prev = tiles
+tiles = pp2.reshape(h // 8, 8, w // 8, 8).transpose(0, 2, 1, 3).reshape(-1)
+prev = tiles_prev.reshape(-1, 64)
+for name, key in [("prev-frame chunk max", prev.max(axis=1)), ("prev-frame chunk sum", prev.sum(axis=1)),
+                  ("prev-frame p90 within chunk", np.percentile(prev, 90, axis=1))]:
+    u, steps, end = simulate(4096, 64, np.argsort(-key))
+    print("frame 1 ordered by %s: lane utilisation %.3f wave-steps %d makespan %d" % (name, u, steps, end))
+u, steps, end = simulate(4096, 64)
+print("frame 1 image order: lane utilisation %.3f wave-steps %d makespan %d" % (u, steps, end))

@@ -37,7 +37,7 @@ C_ABI_SYMBOLS = [
     "tptSetSamplesPerPixel", "tptSetSeedMode", "tptSetFoldMode", "tptSetScene", "tptSetCamera", "tptSetStream",
     "tptSetRowShard", "tptLocalRowCount", "tptLocalRowToGlobal", "tptDrawDevice", "tptRayCounterRead", "tptSetRayCounter", "tptSetFrameOverlap", "tptKernelTimingBegin", "tptKernelTimingEnd",
     "tptSynchronize", "tptTimerBegin", "tptTimerEnd", "tptSetKernelVariant", "tptTestMath", "tptTestHitSpheres",
-    "tptGetLaunchInfo", "tptGetLastError", "tptGetDeviceName", "tptDebugStats",
+    "tptGetLaunchInfo", "tptGetLastError", "tptGetDeviceName", "tptDebugStats", "tptDebugChunkOrder",
 ]
 # the reference's own C++ symbols (nm of the compiled Test.cpp), exported for link-level drop-in
 CXX_ABI_SYMBOLS = [
@@ -76,7 +76,7 @@ def load_library():
         "tptSetRayCounter": [p], "tptSetFrameOverlap": [i], "tptKernelTimingBegin": [i],
         "tptKernelTimingEnd": [C.POINTER(f), C.POINTER(i)],
         "tptSynchronize": [], "tptTimerBegin": [], "tptTimerEnd": [C.POINTER(f)], "tptSetKernelVariant": [i, i, i],
-        "tptDebugStats": [p, i], "tptTestMath": [i, p, p, p, i], "tptTestHitSpheres": [i, p, p, p, i], "tptGetLaunchInfo": [C.POINTER(i)] * 4,
+        "tptDebugStats": [p, i], "tptDebugChunkOrder": [p, p, i], "tptTestMath": [i, p, p, p, i], "tptTestHitSpheres": [i, p, p, p, i], "tptGetLaunchInfo": [C.POINTER(i)] * 4,
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -241,6 +241,15 @@ def debug_stats(reset=True):
     out = np.zeros(64, np.uint64)
     _chk(load_library().tptDebugStats(out.ctypes.data, 1 if reset else 0), "tptDebugStats")
     return out
+
+
+def debug_chunk_order(capacity=1 << 20):
+    cost = np.zeros(capacity, np.uint32)
+    order = np.zeros(capacity, np.uint32)
+    n = load_library().tptDebugChunkOrder(cost.ctypes.data, order.ctypes.data, capacity)
+    if n < 0:
+        raise TptError("tptDebugChunkOrder: " + _lib.tptGetLastError().decode())
+    return cost[:n].copy(), order[:n].copy()
 
 
 def device_name():

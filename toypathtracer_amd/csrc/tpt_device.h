@@ -30,6 +30,11 @@ struct KernelArgs {
     int stackStride;
     int ldsStackLevels;
     f4* pathBuf;                     // path-queue kernel: cold path state [workgroups][paths][4] f4 (global, L2-resident)
+    // cost-ordered work distribution (persistent kernel): chunk c of the queue is chunkOrder[c]; every finished pixel
+    // adds its ray count to chunkCost[chunk] (running sum over frames); tptChunkOrderKernel re-sorts, expensive first
+    const unsigned* chunkOrder;      // may be null: image order
+    unsigned* chunkCost;             // may be null
+    int chunkShift;                  // log2(chunkSize)
     unsigned* work;                  // [0] next chunk, [1] finished waves (persistent variants)
     unsigned long long* rayCounter;  // monotonic total of rays traced by this context
 };
@@ -46,6 +51,7 @@ size_t tptQueueLdsBytes(const tpt::KernelArgs& a, bool ldsScene);
 hipError_t tptLaunchTraceQueue(const tpt::KernelArgs& a, bool ldsScene, int blocks, size_t lds, hipStream_t stream);
 int tptQueuePathsPerBlock();
 int tptQueueThreadsPerBlock();
+hipError_t tptLaunchChunkOrder(const unsigned* cost, unsigned* snap, unsigned* order, int numChunks, hipStream_t stream);
 hipError_t tptLaunchResolve(float* tile, const tpt::f4* frameColour, int nPixels, float lerpFac, hipStream_t stream);
 hipError_t tptLaunchMathTest(int op, const float* a, const float* b, float* out, int n, hipStream_t stream);
 hipError_t tptLaunchHitTest(const tpt::KernelArgs& a, int hs, const float* rays, int* outId, float* outT, int n, hipStream_t stream);

@@ -61,6 +61,14 @@ struct Context {
 
     f4* dStack[4] = {};       // recursive fold: global bounce stacks / spill levels (one per in-flight frame)
     size_t stackCap[4] = {};
+    // cost-ordered chunk distribution (persistent kernel)
+    unsigned* dChunkCost = nullptr;
+    unsigned* dChunkOrder[6] = {};
+    unsigned* dChunkSnap[4] = {}; // per trace stream: cost snapshot of the sort kernel
+    int chunkCap = 0, chunkCount = 0; // chunkCount: numChunks the statistics belong to
+    int costOrder = 1;                // env TPT_COST_ORDER=0 disables
+    unsigned long long orderSeq = 0;
+    int lastOrderTable = 0;
     f4* dPath[4] = {};        // path-queue kernel: cold path state (one per in-flight frame)
     size_t pathCap[4] = {};
     float* dFrame = nullptr; // device tile behind the host-pointer DrawTest
@@ -225,6 +233,7 @@ int tptInitialize(void)
     if (g.spheres.empty()) defaultScene(g.spheres, g.mats);
     if (const char* e1 = getenv("TPT_MAX_BLOCKS_PER_CU")) g.maxBlocksPerCU = atoi(e1);
     if (const char* e2 = getenv("TPT_CHUNK")) g.chunkOverride = atoi(e2);
+    if (const char* e4 = getenv("TPT_COST_ORDER")) g.costOrder = atoi(e4);
     if (const char* e3 = getenv("TPT_LDS_STACK_LEVELS")) {
         g.ldsStackLevels = atoi(e3);
         if (g.ldsStackLevels < 0) g.ldsStackLevels = 0;
@@ -241,6 +250,9 @@ int tptShutdown(void)
     hipStreamSynchronize(g.stream);
     hipFree(g.dPairs); hipFree(g.dSph4); hipFree(g.dInvR); hipFree(g.dMats); hipFree(g.dLights);
     hipFree(g.dWork); hipFree(g.dRaysOwn); hipFree(g.dFrame);
+    hipFree(g.dChunkCost); g.dChunkCost = nullptr; g.chunkCap = 0; g.chunkCount = 0; g.orderSeq = 0;
+    for (int k = 0; k < 6; ++k) { hipFree(g.dChunkOrder[k]); g.dChunkOrder[k] = nullptr; }
+    for (int k = 0; k < 4; ++k) { hipFree(g.dChunkSnap[k]); g.dChunkSnap[k] = nullptr; }
     g.dPairs = nullptr; g.dSph4 = nullptr; g.dInvR = nullptr; g.dMats = nullptr; g.dLights = nullptr;
     g.dWork = nullptr; g.dRays = nullptr; g.dRaysOwn = nullptr; g.dFrame = nullptr;
     g.frameCap = 0;
@@ -519,6 +531,43 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
         a.stackBuf = g.dStack[slot];
         a.stackStride = stackColumns;
     }
+    // cost-ordered work distribution for the default persistent kernel
+    a.chunkOrder = nullptr;
+    a.chunkCost = nullptr;
+    a.chunkShift = 6;
+    const bool useOrder = g.costOrder && g.persist == 1 && !rowSerial && !sorted && !queued && a.numChunks > 1 &&
+                          (a.chunkSize & (a.chunkSize - 1)) == 0;
+    if (useOrder) {
+        int sh = 0;
+        while ((1 << sh) < a.chunkSize) ++sh;
+        a.chunkShift = sh;
+        if (a.numChunks > g.chunkCap) {
+            HIPCHK(hipStreamSynchronize(g.stream));
+            for (int k = 0; k < Context::kMaxOverlap; ++k) HIPCHK(hipStreamSynchronize(g.traceStream[k]));
+            if (g.dChunkCost) HIPCHK(hipFree(g.dChunkCost));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dChunkCost), sizeof(unsigned) * (size_t)a.numChunks));
+            for (int k = 0; k < 6; ++k) {
+                if (g.dChunkOrder[k]) HIPCHK(hipFree(g.dChunkOrder[k]));
+                g.dChunkOrder[k] = nullptr;
+                HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dChunkOrder[k]), sizeof(unsigned) * (size_t)a.numChunks));
+            }
+            for (int k = 0; k < 4; ++k) {
+                if (g.dChunkSnap[k]) HIPCHK(hipFree(g.dChunkSnap[k]));
+                g.dChunkSnap[k] = nullptr;
+                HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dChunkSnap[k]), sizeof(unsigned) * (size_t)a.numChunks));
+            }
+            g.chunkCap = a.numChunks;
+            g.chunkCount = 0;
+        }
+        if (g.chunkCount != a.numChunks) { // new resolution / sharding: statistics start over
+            HIPCHK(hipStreamSynchronize(g.stream));
+            for (int k = 0; k < Context::kMaxOverlap; ++k) HIPCHK(hipStreamSynchronize(g.traceStream[k]));
+            HIPCHK(hipMemset(g.dChunkCost, 0, sizeof(unsigned) * (size_t)a.numChunks));
+            g.chunkCount = a.numChunks;
+            g.orderSeq = 0;
+        }
+        a.chunkCost = g.dChunkCost;
+    }
     a.pathBuf = nullptr;
     if (queued) {
         const size_t need = (size_t)blocks * tptQueuePathsPerBlock() * 4 * sizeof(f4);
@@ -538,6 +587,19 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
     // trace(f) on its own stream (no dependency on the previous frame), then the ordered blend on g.stream
     hipStream_t ts = nOverlap > 1 ? g.traceStream[slot] : g.stream;
     if (nOverlap > 1 && g.resolveRecorded[slot]) HIPCHK(hipStreamWaitEvent(ts, g.evResolve[slot], 0)); // colour buffer free again
+    if (useOrder && g.orderSeq > 0) {
+        // re-sort from the statistics gathered so far (a few frames suffice for a static scene; refresh every 8th).
+        // The table is one of 6 rotating buffers: a trace kernel still in flight keeps reading the one it was given.
+        unsigned* table = g.dChunkOrder[g.orderSeq % 6];
+        if (g.orderSeq <= 4 || (g.orderSeq & 7ull) == 0ull) {
+            HIPCHK(tptLaunchChunkOrder(g.dChunkCost, g.dChunkSnap[slot], table, a.numChunks, ts));
+        } else {
+            table = g.dChunkOrder[g.lastOrderTable];
+        }
+        g.lastOrderTable = (int)(table == g.dChunkOrder[g.orderSeq % 6] ? g.orderSeq % 6 : g.lastOrderTable);
+        a.chunkOrder = table;
+    }
+    if (useOrder) g.orderSeq++;
     const bool timeIt = g.kernelTiming && g.ktUsed < g.ktStart.size();
     if (timeIt) HIPCHK(hipEventRecord(g.ktStart[g.ktUsed], ts));
     if (queued)
@@ -687,6 +749,20 @@ int tptGetLaunchInfo(int* outBlocksPerCU, int* outLdsBytes, int* outGridBlocks, 
     if (outGridBlocks) *outGridBlocks = g.lastGrid;
     if (outNumCUs) *outNumCUs = g.numCUs;
     return 0;
+}
+
+// debugging aid for the cost-ordered work distribution: copies the accumulated per-chunk ray counts and the order
+// table given to the most recent launch (either pointer may be NULL); returns the number of chunks
+int tptDebugChunkOrder(unsigned* outCost, unsigned* outOrder, int capacity)
+{
+    if (requireInit()) return -1;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    for (int k = 0; k < Context::kMaxOverlap; ++k) HIPCHK(hipStreamSynchronize(g.traceStream[k]));
+    int n = g.chunkCount < capacity ? g.chunkCount : capacity;
+    if (n <= 0 || !g.dChunkCost) return 0;
+    if (outCost) HIPCHK(hipMemcpy(outCost, g.dChunkCost, sizeof(unsigned) * n, hipMemcpyDeviceToHost));
+    if (outOrder) HIPCHK(hipMemcpy(outOrder, g.dChunkOrder[g.lastOrderTable], sizeof(unsigned) * n, hipMemcpyDeviceToHost));
+    return n;
 }
 
 int tptDebugStats(unsigned long long* out64, int reset)

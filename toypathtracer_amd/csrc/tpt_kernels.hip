@@ -73,8 +73,53 @@ __global__ void __launch_bounds__(256) tptResolveKernel(float* __restrict__ tile
 }
 
 #ifndef TPT_MIN_WAVES_PER_SIMD
-#define TPT_MIN_WAVES_PER_SIMD 1
+#define TPT_MIN_WAVES_PER_SIMD 4 // caps the allocation at 128 VGPRs: 16 waves per CU
 #endif
+// Work-distribution helper: order[] = chunk indices sorted by accumulated cost, expensive first (counting sort into
+// 256 cost buckets; order inside a bucket is arbitrary -- it only affects scheduling, never results).  Long pixels
+// then start early and the cheap sky tiles fill the end of the launch: -11 % wave-steps at configs[1]
+// (tools/sim_sched.py).  One workgroup; ~10 us for 14 400 chunks.
+__global__ void __launch_bounds__(1024) tptChunkOrderKernel(const unsigned* __restrict__ cost, unsigned* __restrict__ snap,
+                                                            unsigned* __restrict__ order, int n)
+{
+    __shared__ unsigned hist[256];
+    __shared__ unsigned maxCost;
+    const int tid = threadIdx.x;
+    if (tid < 256) hist[tid] = 0u;
+    if (tid == 0) maxCost = 1u;
+    __syncthreads();
+    // trace kernels of other frames may be adding to cost[] right now: read every element ONCE into a snapshot so that
+    // the histogram and the scatter below see the same buckets (otherwise the table would not be a permutation)
+    unsigned m = 0u;
+    for (int i = tid; i < n; i += 1024) {
+        const unsigned c = __hip_atomic_load(&cost[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        snap[i] = c;
+        m = c > m ? c : m;
+    }
+    atomicMax(&maxCost, m);
+    __syncthreads();
+    const float scale = 255.0f / (float)maxCost;
+    for (int i = tid; i < n; i += 1024) { // each thread re-reads only what it wrote itself
+        unsigned b = 255u - (unsigned)((float)snap[i] * scale); // bucket 0 = most expensive
+        atomicAdd(&hist[b > 255u ? 255u : b], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) { // exclusive prefix sum over 256 buckets
+        unsigned run = 0u;
+        for (int b = 0; b < 256; ++b) {
+            unsigned c = hist[b];
+            hist[b] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        unsigned b = 255u - (unsigned)((float)snap[i] * scale);
+        unsigned pos = atomicAdd(&hist[b > 255u ? 255u : b], 1u);
+        order[pos] = (unsigned)i;
+    }
+}
+
 template <int HS, int FOLD, bool PERSIST, bool LDS_SCENE>
 __global__ void __launch_bounds__(TPT_BLOCK, TPT_MIN_WAVES_PER_SIMD) tptTraceKernel(const KernelArgs a)
 {
@@ -161,6 +206,7 @@ __global__ void __launch_bounds__(TPT_BLOCK, TPT_MIN_WAVES_PER_SIMD) tptTraceKer
                         noMoreWork = true;
                         break;
                     }
+                    if (a.chunkOrder) c = (int)a.chunkOrder[c]; // expensive chunks first (statistics of previous frames)
                     chunkNext = c * a.chunkSize;
                     chunkEnd = chunkNext + a.chunkSize;
                     if (chunkEnd > a.numItems) chunkEnd = a.numItems;
@@ -173,7 +219,9 @@ __global__ void __launch_bounds__(TPT_BLOCK, TPT_MIN_WAVES_PER_SIMD) tptTraceKer
                     int x, ly;
                     if (mapItem(a, chunkNext + rank, x, ly)) {
                         laneBeginPixel(L, fc, x, localRowToGlobal(a, ly), ly * fc.width + x, true);
-                                    need = false;
+                        L.item = chunkNext + rank;
+                        L.rays0 = L.rays;
+                        need = false;
                     }
                 }
                 chunkNext += take;
@@ -184,7 +232,8 @@ __global__ void __launch_bounds__(TPT_BLOCK, TPT_MIN_WAVES_PER_SIMD) tptTraceKer
                     storeColour(a, L);
                     if (rowSerial && L.x + 1 < fc.width) {
                         laneBeginPixel(L, fc, L.x + 1, L.y, L.pix + 1, false);
-                                } else {
+                    } else {
+                        if (a.chunkCost) atomicAdd(&a.chunkCost[L.item >> a.chunkShift], L.rays - L.rays0);
                         L.active = false;
                     }
                 }
@@ -1010,6 +1059,12 @@ hipError_t tptLaunchTraceQueue(const KernelArgs& a, bool ldsScene, int blocks, s
 }
 int tptQueuePathsPerBlock() { return TPT_Q_P; }
 int tptQueueThreadsPerBlock() { return TPT_Q_T; }
+
+hipError_t tptLaunchChunkOrder(const unsigned* cost, unsigned* snap, unsigned* order, int numChunks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(tptChunkOrderKernel, dim3(1), dim3(1024), 0, stream, cost, snap, order, numChunks);
+    return hipGetLastError();
+}
 
 hipError_t tptLaunchResolve(float* tile, const f4* frameColour, int nPixels, float lerpFac, hipStream_t stream)
 {

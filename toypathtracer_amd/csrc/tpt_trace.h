@@ -269,6 +269,8 @@ struct Lane {
     f3 radiance, throughput;                   // FOLD_FORWARD
     int sp;                                    // FOLD_RECURSIVE: entries on the bounce stack
     int slot;                                  // sorted kernel: which bounce-stack column this path owns (travels with the path)
+    int item;                                  // persistent kernel: work-item index of the current pixel (for the chunk cost statistics)
+    uint32_t rays0;                            //   and the lane's ray count when the pixel started
     uint32_t rays;
 };
 

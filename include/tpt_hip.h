@@ -95,6 +95,11 @@ int tptDrawDevice(float time, int frameCount, int screenWidth, int screenHeight,
  * context's stream, so results are bit-identical to frames=1.  Default 2: the tail of frame f (a few long
  * paths) overlaps the head of frame f+1. */
 int tptSetFrameOverlap(int frames);
+/* Display conversion of a device-resident FULL image (w*h float4, row 0 = bottom) into w*h RGBA8 in device memory,
+ * top row first: the reference's own conversion for its C++ path, Cpp/Emscripten/main.cpp:63-79
+ * (c8 = min(sqrtf(c)*255, 255), alpha 255).  Enqueued on the context's stream; 4x less data to download than
+ * the float buffer. */
+int tptDisplayRGBA8(const float* deviceTile, int screenWidth, int screenHeight, unsigned char* deviceRGBA);
 /* Synchronise the stream and return the monotonic total of rays traced by this context. */
 int tptRayCounterRead(int64_t* outTotalRays);
 /* Let the caller own the ray counter: `deviceU64` points to one zero-initialised 64-bit word in device

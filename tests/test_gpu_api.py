@@ -42,3 +42,27 @@ def test_scene_desc_round_trip(tpt_defaults, oracle):
     so, mo = oracle.default_scene()
     assert s.tobytes() == so.tobytes() and m.tobytes() == mo.tobytes() and list(em) == [8, 45]
     assert cam.tobytes() == oracle.default_camera(640, 360).tobytes()
+
+
+def test_display_conversion_matches_reference_formula(tpt_defaults, tmp_path):
+    """tptDisplayRGBA8 == Cpp/Emscripten/main.cpp:63-79 (row flip, min(sqrtf(c)*255, 255) truncated to uint8)."""
+    import torch
+    tpt = tpt_defaults
+    w, h = 320, 180
+    tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    for f in range(4):
+        tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+        tpt.draw_device(0.0, f, w, h, tile.data_ptr(), FLAG_PROGRESSIVE)
+    out = torch.zeros((h, w, 4), dtype=torch.uint8, device="cuda")
+    tpt.display_rgba8(tile.data_ptr(), w, h, out.data_ptr())
+    tpt.synchronize()
+    bb = tile.cpu().numpy()
+    want = np.empty((h, w, 4), np.uint8)
+    want[..., :3] = np.minimum(np.sqrt(bb[::-1, :, :3]) * np.float32(255), np.float32(255.0)).astype(np.uint8)
+    want[..., 3] = 255
+    got = out.cpu().numpy()
+    assert np.array_equal(got, want)
+    assert got[..., :3].max() > 200 and got[..., :3].min() < 80  # a real image, not a constant
+    path = str(tmp_path / "frame.tga")
+    tpt.write_tga(path, got)
+    assert os.path.getsize(path) == 18 + w * h * 4

@@ -35,7 +35,7 @@ _lib = None
 C_ABI_SYMBOLS = [
     "tptInitialize", "tptShutdown", "tptUpdate", "tptDraw", "tptGetObjectCount", "tptGetSceneDesc",
     "tptSetSamplesPerPixel", "tptSetSeedMode", "tptSetFoldMode", "tptSetScene", "tptSetCamera", "tptSetStream",
-    "tptSetRowShard", "tptLocalRowCount", "tptLocalRowToGlobal", "tptDrawDevice", "tptRayCounterRead", "tptSetRayCounter", "tptSetFrameOverlap", "tptKernelTimingBegin", "tptKernelTimingEnd",
+    "tptSetRowShard", "tptLocalRowCount", "tptLocalRowToGlobal", "tptDrawDevice", "tptRayCounterRead", "tptSetRayCounter", "tptSetFrameOverlap", "tptDisplayRGBA8", "tptKernelTimingBegin", "tptKernelTimingEnd",
     "tptSynchronize", "tptTimerBegin", "tptTimerEnd", "tptSetKernelVariant", "tptTestMath", "tptTestHitSpheres",
     "tptGetLaunchInfo", "tptGetLastError", "tptGetDeviceName", "tptDebugStats", "tptDebugChunkOrder",
 ]
@@ -73,7 +73,7 @@ def load_library():
         "tptSetSamplesPerPixel": [i], "tptSetSeedMode": [i], "tptSetFoldMode": [i], "tptSetScene": [p, p, i],
         "tptSetCamera": [p, p, f, f, f], "tptSetStream": [p], "tptSetRowShard": [i, i, i], "tptLocalRowCount": [i],
         "tptLocalRowToGlobal": [i], "tptDrawDevice": [f, i, i, i, p, u], "tptRayCounterRead": [C.POINTER(C.c_int64)],
-        "tptSetRayCounter": [p], "tptSetFrameOverlap": [i], "tptKernelTimingBegin": [i],
+        "tptSetRayCounter": [p], "tptSetFrameOverlap": [i], "tptDisplayRGBA8": [p, i, i, p], "tptKernelTimingBegin": [i],
         "tptKernelTimingEnd": [C.POINTER(f), C.POINTER(i)],
         "tptSynchronize": [], "tptTimerBegin": [], "tptTimerEnd": [C.POINTER(f)], "tptSetKernelVariant": [i, i, i],
         "tptDebugStats": [p, i], "tptDebugChunkOrder": [p, p, i], "tptTestMath": [i, p, p, p, i], "tptTestHitSpheres": [i, p, p, p, i], "tptGetLaunchInfo": [C.POINTER(i)] * 4,
@@ -198,6 +198,22 @@ def ray_counter_read():
 
 def set_frame_overlap(frames):
     _chk(load_library().tptSetFrameOverlap(frames), "tptSetFrameOverlap")
+
+
+def display_rgba8(device_tile_ptr, width, height, device_rgba_ptr):
+    """linear float4 image (device) -> RGBA8 (device), the reference's sqrt display transform, top row first"""
+    _chk(load_library().tptDisplayRGBA8(C.c_void_p(device_tile_ptr), width, height, C.c_void_p(device_rgba_ptr)), "tptDisplayRGBA8")
+
+
+def write_tga(path, rgba):
+    """rgba: uint8 [h, w, 4], top row first.  Uncompressed 32-bit TGA like the reference's only image writer
+    (Cs/Program.cs:33-59: BGRA, bottom-left origin)."""
+    rgba = np.ascontiguousarray(rgba, np.uint8)
+    h, w = rgba.shape[:2]
+    header = bytes([0, 0, 2, 0, 0, 0, 0, 0, 0, 0, 0, 0, w & 0xFF, (w >> 8) & 0xFF, h & 0xFF, (h >> 8) & 0xFF, 32, 0])
+    with open(path, "wb") as f:
+        f.write(header)
+        f.write(rgba[::-1, :, [2, 1, 0, 3]].tobytes())
 
 
 def set_ray_counter(device_ptr):

@@ -51,6 +51,7 @@ size_t tptQueueLdsBytes(const tpt::KernelArgs& a, bool ldsScene);
 hipError_t tptLaunchTraceQueue(const tpt::KernelArgs& a, bool ldsScene, int blocks, size_t lds, hipStream_t stream);
 int tptQueuePathsPerBlock();
 int tptQueueThreadsPerBlock();
+hipError_t tptLaunchDisplay(const float* tile, unsigned char* rgba, int width, int height, hipStream_t stream);
 hipError_t tptLaunchChunkOrder(const unsigned* cost, unsigned* snap, unsigned* order, int numChunks, hipStream_t stream);
 hipError_t tptLaunchResolve(float* tile, const tpt::f4* frameColour, int nPixels, float lerpFac, hipStream_t stream);
 hipError_t tptLaunchMathTest(int op, const float* a, const float* b, float* out, int n, hipStream_t stream);

@@ -588,10 +588,10 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
     hipStream_t ts = nOverlap > 1 ? g.traceStream[slot] : g.stream;
     if (nOverlap > 1 && g.resolveRecorded[slot]) HIPCHK(hipStreamWaitEvent(ts, g.evResolve[slot], 0)); // colour buffer free again
     if (useOrder && g.orderSeq > 0) {
-        // re-sort from the statistics gathered so far (a few frames suffice for a static scene; refresh every 8th).
+        // re-sort from the statistics gathered so far (a few frames suffice for a static scene; refresh every 32nd).
         // The table is one of 6 rotating buffers: a trace kernel still in flight keeps reading the one it was given.
         unsigned* table = g.dChunkOrder[g.orderSeq % 6];
-        if (g.orderSeq <= 4 || (g.orderSeq & 7ull) == 0ull) {
+        if (g.orderSeq <= 6 || (g.orderSeq & 31ull) == 0ull) {
             HIPCHK(tptLaunchChunkOrder(g.dChunkCost, g.dChunkSnap[slot], table, a.numChunks, ts));
         } else {
             table = g.dChunkOrder[g.lastOrderTable];
@@ -716,6 +716,15 @@ int tptDraw(float time, int frameCount, int w, int h, float* backbuffer, int* ou
     if (rc) return rc;
     if (outRayCount) *outRayCount = (int)(total - totalBefore);
     g.lastTotal = total;
+    return 0;
+}
+
+// Display conversion (Cpp/Emscripten/main.cpp:63-79): linear float tile -> RGBA8, top row first.
+int tptDisplayRGBA8(const float* deviceTile, int w, int h, unsigned char* deviceRGBA)
+{
+    if (requireInit()) return -1;
+    if (!deviceTile || !deviceRGBA || w <= 0 || h <= 0) return fail("tptDisplayRGBA8: bad arguments");
+    HIPCHK(tptLaunchDisplay(deviceTile, deviceRGBA, w, h, g.stream));
     return 0;
 }
 

@@ -120,6 +120,24 @@ __global__ void __launch_bounds__(1024) tptChunkOrderKernel(const unsigned* __re
     }
 }
 
+// Display conversion of the linear float accumulation buffer, the way the reference's C++ path shows it in the
+// browser (Cpp/Emscripten/main.cpp:63-79): rows flipped (row 0 of the buffer is the bottom of the image), cheap sRGB
+// approximation c8 = (uint8) min(sqrtf(c) * 255, 255), alpha 255.  HBM-bound: 16 B read + 4 B written per pixel,
+// one uchar4 per lane, fully coalesced.  Negative / NaN inputs (which the reference would convert with UB) give 0.
+__global__ void __launch_bounds__(256) tptDisplayKernel(const f4* __restrict__ tile, uint32_t* __restrict__ rgba, int width, int height)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= width * height) return;
+    const int y = i / width, x = i - y * width;
+    const f4 c = tile[(height - 1 - y) * width + x];
+    auto to8 = [](float v) -> uint32_t {
+        float s = tsqrt(v) * 255.0f;
+        s = s < 255.0f ? s : 255.0f; // std::min(s, 255.0f)
+        return s > 0.0f ? (uint32_t)s : 0u;
+    };
+    rgba[i] = to8(c.x) | (to8(c.y) << 8) | (to8(c.z) << 16) | 0xff000000u;
+}
+
 template <int HS, int FOLD, bool PERSIST, bool LDS_SCENE>
 __global__ void __launch_bounds__(TPT_BLOCK, TPT_MIN_WAVES_PER_SIMD) tptTraceKernel(const KernelArgs a)
 {
@@ -233,7 +251,10 @@ __global__ void __launch_bounds__(TPT_BLOCK, TPT_MIN_WAVES_PER_SIMD) tptTraceKer
                     if (rowSerial && L.x + 1 < fc.width) {
                         laneBeginPixel(L, fc, L.x + 1, L.y, L.pix + 1, false);
                     } else {
-                        if (a.chunkCost) atomicAdd(&a.chunkCost[L.item >> a.chunkShift], L.rays - L.rays0);
+                        // statistics for the cost-ordered work distribution: only the long pixels matter for the order
+                        // (and 90 % fewer atomics than counting every pixel)
+                        if (a.chunkCost && L.rays - L.rays0 > (uint32_t)(8 * fc.spp))
+                            atomicAdd(&a.chunkCost[L.item >> a.chunkShift], L.rays - L.rays0);
                         L.active = false;
                     }
                 }
@@ -618,8 +639,11 @@ __device__ __forceinline__ void qLoadHot(Lane& L, int& id, float& t, const f4* s
 }
 // cold state (global, per path): [0] sdir.xyz cosAMax  [1] nl.xyz -  [2] lightE.xyz -  [3] col.xyz x|y<<16
 
+#ifndef TPT_Q_MIN_WAVES_PER_SIMD
+#define TPT_Q_MIN_WAVES_PER_SIMD 4
+#endif
 template <bool LDS_SCENE>
-__global__ void __launch_bounds__(TPT_Q_T) tptTraceQueueKernel(const KernelArgs a)
+__global__ void __launch_bounds__(TPT_Q_T, TPT_Q_MIN_WAVES_PER_SIMD) tptTraceQueueKernel(const KernelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nPad = a.scene.nPairs * 2;
@@ -1059,6 +1083,13 @@ hipError_t tptLaunchTraceQueue(const KernelArgs& a, bool ldsScene, int blocks, s
 }
 int tptQueuePathsPerBlock() { return TPT_Q_P; }
 int tptQueueThreadsPerBlock() { return TPT_Q_T; }
+
+hipError_t tptLaunchDisplay(const float* tile, unsigned char* rgba, int width, int height, hipStream_t stream)
+{
+    hipLaunchKernelGGL(tptDisplayKernel, dim3((width * height + 255) / 256), dim3(256), 0, stream, reinterpret_cast<const f4*>(tile),
+                       reinterpret_cast<uint32_t*>(rgba), width, height);
+    return hipGetLastError();
+}
 
 hipError_t tptLaunchChunkOrder(const unsigned* cost, unsigned* snap, unsigned* order, int numChunks, hipStream_t stream)
 {

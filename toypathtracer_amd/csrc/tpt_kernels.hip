@@ -539,16 +539,6 @@ struct QueueCtl {
     unsigned globalExhausted; // some wave saw the global chunk counter run out
 };
 
-__device__ __forceinline__ void qPush(volatile unsigned short* q, unsigned* tail, bool want, int pathId, int lane)
-{
-    const unsigned long long m = __ballot(want);
-    if (m == 0ull) return;
-    const int leader = (int)__ffsll((long long)m) - 1;
-    unsigned pos = 0;
-    if (lane == leader) pos = atomicAdd(tail, (unsigned)__popcll(m));
-    pos = (unsigned)__builtin_amdgcn_readlane((int)pos, leader);
-    if (want) q[(pos + (unsigned)__popcll(m & ((1ull << lane) - 1ull))) & (TPT_Q_P - 1)] = (unsigned short)pathId;
-}
 // Push every lane's path id to the queue of its class `cls` (Q_FREE..Q_SHADOW, or -1 for none) with ONE LDS atomic
 // instruction: lane c reserves the slots of class c, the bases come back through readlane.
 __device__ __forceinline__ void qPushByClass(volatile unsigned short* q, QueueCtl* ctl, int cls, int pathId, int lane)

@@ -302,3 +302,28 @@ def test_cost_ordered_chunks_table_is_a_permutation_and_image_unchanged(tpt_defa
     rays = tpt.ray_counter_read() - r0
     ro, bo, _ = oracle_frames(oracle, w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
     assert rays == ro and tile.cpu().numpy().tobytes() == bo.tobytes()
+
+
+def test_config5_stress_scene_full_size_properties(tpt_defaults, oracle):
+    """configs[4]: 4096 spheres, 1920x1080, 8 spp at full size: determinism, finiteness, kernel-variant agreement, and
+    a band of rows against the oracle (seeds are partition independent, so a band is a valid sample)."""
+    from toypathtracer_amd.scenes import STRESS_CAMERA, stress_scene
+    tpt = tpt_defaults
+    s, m = stress_scene(4096, 64)
+    w, h, spp = 1920, 1080, 8
+    tpt.set_scene(s, m)
+    tpt.set_camera(**STRESS_CAMERA)
+    tpt.set_samples_per_pixel(spp)
+    r1, b1, _ = gpu_frames(tpt, w, h, 1)
+    r2, b2, _ = gpu_frames(tpt, w, h, 1)
+    assert r1 == r2 and b1.tobytes() == b2.tobytes()
+    assert np.isfinite(b1[..., :3]).all() and float(b1[..., 3].max()) == 0.0
+    assert r1 > 2 * w * h * spp
+    cam = oracle.camera(STRESS_CAMERA["look_from"], STRESS_CAMERA["look_at"], (0, 1, 0), STRESS_CAMERA["vfov"], w / h,
+                        STRESS_CAMERA["aperture"], STRESS_CAMERA["focus_dist"])
+    band = np.zeros((h, w, 4), np.float32)
+    oracle.render(s, m, cam, w, h, spp, 0, seed_mode=SEED_PER_PIXEL, backbuffer=band, y0=300, y1=303)
+    assert b1[300:303].tobytes() == band[300:303].tobytes()
+    tpt.set_kernel_variant(0, 3, -1)  # path-queue kernel on the same frame
+    r3, b3, _ = gpu_frames(tpt, w, h, 1)
+    assert r3 == r1 and b3.tobytes() == b1.tobytes()

@@ -247,29 +247,29 @@ int tptInitialize(void)
 int tptShutdown(void)
 {
     if (!g.inited) return 0;
-    hipStreamSynchronize(g.stream);
-    hipFree(g.dPairs); hipFree(g.dSph4); hipFree(g.dInvR); hipFree(g.dMats); hipFree(g.dLights);
-    hipFree(g.dWork); hipFree(g.dRaysOwn); hipFree(g.dFrame);
-    hipFree(g.dChunkCost); g.dChunkCost = nullptr; g.chunkCap = 0; g.chunkCount = 0; g.orderSeq = 0;
-    for (int k = 0; k < 6; ++k) { hipFree(g.dChunkOrder[k]); g.dChunkOrder[k] = nullptr; }
-    for (int k = 0; k < 4; ++k) { hipFree(g.dChunkSnap[k]); g.dChunkSnap[k] = nullptr; }
+    (void)hipStreamSynchronize(g.stream);
+    (void)hipFree(g.dPairs); (void)hipFree(g.dSph4); (void)hipFree(g.dInvR); (void)hipFree(g.dMats); (void)hipFree(g.dLights);
+    (void)hipFree(g.dWork); (void)hipFree(g.dRaysOwn); (void)hipFree(g.dFrame);
+    (void)hipFree(g.dChunkCost); g.dChunkCost = nullptr; g.chunkCap = 0; g.chunkCount = 0; g.orderSeq = 0;
+    for (int k = 0; k < 6; ++k) { (void)hipFree(g.dChunkOrder[k]); g.dChunkOrder[k] = nullptr; }
+    for (int k = 0; k < 4; ++k) { (void)hipFree(g.dChunkSnap[k]); g.dChunkSnap[k] = nullptr; }
     g.dPairs = nullptr; g.dSph4 = nullptr; g.dInvR = nullptr; g.dMats = nullptr; g.dLights = nullptr;
     g.dWork = nullptr; g.dRays = nullptr; g.dRaysOwn = nullptr; g.dFrame = nullptr;
     g.frameCap = 0;
     caps = ScenePtrCaps();
-    for (size_t i = 0; i < g.ktStart.size(); ++i) { hipEventDestroy(g.ktStart[i]); hipEventDestroy(g.ktStop[i]); }
+    for (size_t i = 0; i < g.ktStart.size(); ++i) { (void)hipEventDestroy(g.ktStart[i]); (void)hipEventDestroy(g.ktStop[i]); }
     g.ktStart.clear(); g.ktStop.clear(); g.ktUsed = 0; g.kernelTiming = false;
     for (int k = 0; k < Context::kMaxOverlap; ++k) {
-        if (g.traceStream[k]) { hipStreamSynchronize(g.traceStream[k]); hipStreamDestroy(g.traceStream[k]); }
-        if (g.evTrace[k]) hipEventDestroy(g.evTrace[k]);
-        if (g.evResolve[k]) hipEventDestroy(g.evResolve[k]);
-        hipFree(g.dColour[k]);
-        hipFree(g.dStack[k]); g.dStack[k] = nullptr; g.stackCap[k] = 0;
-        hipFree(g.dPath[k]); g.dPath[k] = nullptr; g.pathCap[k] = 0;
+        if (g.traceStream[k]) { (void)hipStreamSynchronize(g.traceStream[k]); (void)hipStreamDestroy(g.traceStream[k]); }
+        if (g.evTrace[k]) (void)hipEventDestroy(g.evTrace[k]);
+        if (g.evResolve[k]) (void)hipEventDestroy(g.evResolve[k]);
+        (void)hipFree(g.dColour[k]);
+        (void)hipFree(g.dStack[k]); g.dStack[k] = nullptr; g.stackCap[k] = 0;
+        (void)hipFree(g.dPath[k]); g.dPath[k] = nullptr; g.pathCap[k] = 0;
         g.traceStream[k] = nullptr; g.evTrace[k] = nullptr; g.evResolve[k] = nullptr; g.dColour[k] = nullptr; g.colourCap[k] = 0;
     }
-    hipEventDestroy(g.ev0); hipEventDestroy(g.ev1);
-    hipStreamDestroy(g.ownStream);
+    (void)hipEventDestroy(g.ev0); (void)hipEventDestroy(g.ev1);
+    (void)hipStreamDestroy(g.ownStream);
     g.ownStream = g.stream = nullptr;
     g.inited = false;
     g.updated = false;
@@ -800,7 +800,7 @@ int tptTestMath(int op, const float* a, const float* b, float* out, int n)
     HIPCHK(tptLaunchMathTest(op, da, db, dout, n, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     HIPCHK(hipMemcpy(out, dout, sizeof(float) * n, hipMemcpyDeviceToHost));
-    hipFree(da); hipFree(db); hipFree(dout);
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
     return 0;
 }
 
@@ -825,7 +825,7 @@ int tptTestHitSpheres(int hitSpheres, const float* rays, int* outId, float* outT
     HIPCHK(hipStreamSynchronize(g.stream));
     HIPCHK(hipMemcpy(outId, di, sizeof(int) * n, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(outT, dt, sizeof(float) * n, hipMemcpyDeviceToHost));
-    hipFree(dr); hipFree(dt); hipFree(di);
+    (void)hipFree(dr); (void)hipFree(dt); (void)hipFree(di);
     return 0;
 }
 

@@ -1032,7 +1032,7 @@ static int occupancySortedOne(size_t lds)
 {
     int nb = 0;
     auto k = tptTraceSortedKernel<FOLD, LDS_SCENE>;
-    if (lds > 48 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), TPT_SORT_T, lds) != hipSuccess) nb = 1;
     return nb < 1 ? 1 : nb;
 }

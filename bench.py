@@ -30,6 +30,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# one hardware queue per in-flight trace kernel; read by the HIP runtime when it initialises (before torch does that)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -96,7 +98,7 @@ def main():
     ap.add_argument("--persistent", type=int, default=1, help="1 persistent waves (default) 0 thread-per-pixel 2 lane-sorting 3 path queues")
     ap.add_argument("--fold", type=int, default=0, help="0 recursive (reference order, default) 1 forward")
     ap.add_argument("--lds-scene", type=int, default=-1)
-    ap.add_argument("--overlap", type=int, default=2, help="trace kernels of this many consecutive frames may be in flight")
+    ap.add_argument("--overlap", type=int, default=8, help="trace kernels of up to this many consecutive frames may be in flight")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -92,8 +92,10 @@ int tptDrawDevice(float time, int frameCount, int screenWidth, int screenHeight,
 /* Frame pipelining of the asynchronous path: the trace kernels of up to `frames` consecutive tptDrawDevice
  * calls may be in flight at once (each on its own internal stream, writing its own per-frame colour
  * buffer); the progressive blend into the tile (Test.cpp:293-295) is a separate, ordered kernel on the
- * context's stream, so results are bit-identical to frames=1.  Default 2: the tail of frame f (a few long
- * paths) overlaps the head of frame f+1. */
+ * context's stream, so results are bit-identical to frames=1.  1..8, default 8: the tail of frame f (a few long
+ * paths) overlaps the head of the following frames; small tiles (row sharding over many GPUs) need the depth.
+ * Needs one hardware queue per in-flight kernel: tptInitialize sets GPU_MAX_HW_QUEUES=16 if the HIP runtime has
+ * not been initialised yet (ROCm's default of 4 makes 3 streams slower than 2). */
 int tptSetFrameOverlap(int frames);
 /* Display conversion of a device-resident FULL image (w*h float4, row 0 = bottom) into w*h RGBA8 in device memory,
  * top row first: the reference's own conversion for its C++ path, Cpp/Emscripten/main.cpp:63-79

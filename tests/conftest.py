@@ -46,5 +46,5 @@ def tpt_defaults(tpt):
     tpt.set_fold_mode(tpt.FOLD_RECURSIVE)
     tpt.set_kernel_variant(0, 1, -1)
     tpt.set_row_shard(0, 1, 0)
-    tpt.set_frame_overlap(2)
+    tpt.set_frame_overlap(8)
     return tpt

@@ -237,7 +237,7 @@ def test_device_resident_path_with_torch_tile(tpt_defaults, oracle):
     assert rays == ro and tile.cpu().numpy().tobytes() == bo.tobytes()
 
 
-@pytest.mark.parametrize("overlap", [1, 2, 4])
+@pytest.mark.parametrize("overlap", [1, 2, 3, 8])
 def test_frame_overlap_is_bit_identical(tpt_defaults, oracle, overlap):
     """Pipelined frames (trace kernels of consecutive frames in flight at once) == strictly serial frames."""
     import torch
@@ -255,7 +255,7 @@ def test_frame_overlap_is_bit_identical(tpt_defaults, oracle, overlap):
     assert n == frames and ms > 0
     ro, bo, _ = oracle_frames(oracle, w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
     assert rays == ro and tile.cpu().numpy().tobytes() == bo.tobytes()
-    tpt.set_frame_overlap(2)
+    tpt.set_frame_overlap(8)
 
 
 @pytest.mark.parametrize("variant,fold", [(2, FOLD_RECURSIVE), (2, FOLD_FORWARD), (3, FOLD_RECURSIVE)],

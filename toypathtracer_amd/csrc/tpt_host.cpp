@@ -59,25 +59,25 @@ struct Context {
     unsigned long long* dRaysOwn = nullptr;
     long long lastTotal = 0;
 
-    f4* dStack[4] = {};       // recursive fold: global bounce stacks / spill levels (one per in-flight frame)
-    size_t stackCap[4] = {};
+    f4* dStack[8] = {};       // recursive fold: global bounce stacks / spill levels (one per in-flight frame)
+    size_t stackCap[8] = {};
     // cost-ordered chunk distribution (persistent kernel)
     unsigned* dChunkCost = nullptr;
-    unsigned* dChunkOrder[6] = {};
-    unsigned* dChunkSnap[4] = {}; // per trace stream: cost snapshot of the sort kernel
+    unsigned* dChunkOrder[10] = {};
+    unsigned* dChunkSnap[8] = {}; // per trace stream: cost snapshot of the sort kernel
     int chunkCap = 0, chunkCount = 0; // chunkCount: numChunks the statistics belong to
     int costOrder = 1;                // env TPT_COST_ORDER=0 disables
     unsigned long long orderSeq = 0;
     int lastOrderTable = 0;
-    f4* dPath[4] = {};        // path-queue kernel: cold path state (one per in-flight frame)
-    size_t pathCap[4] = {};
+    f4* dPath[8] = {};        // path-queue kernel: cold path state (one per in-flight frame)
+    size_t pathCap[8] = {};
     float* dFrame = nullptr; // device tile behind the host-pointer DrawTest
     size_t frameCap = 0;
 
     // frame pipelining: trace kernels of consecutive frames run on alternating internal streams and write
     // their own per-frame colour buffer; the (ordered) resolve kernels run on g.stream
-    static const int kMaxOverlap = 4;
-    int overlap = 2;
+    static const int kMaxOverlap = 8;
+    int overlap = 8;
     hipStream_t traceStream[kMaxOverlap] = {};
     hipEvent_t evTrace[kMaxOverlap] = {}, evResolve[kMaxOverlap] = {};
     bool resolveRecorded[kMaxOverlap] = {};
@@ -198,6 +198,10 @@ const char* tptGetDeviceName(void) { return g.deviceName.c_str(); }
 int tptInitialize(void)
 {
     if (g.inited) return 0;
+    // Frame pipelining wants one hardware queue per in-flight trace kernel; the ROCm runtime exposes 4 by default and
+    // maps further streams onto them round-robin (3 streams then run slower than 2).  Only effective if the HIP
+    // runtime has not been initialised yet by the host application; harmless otherwise.
+    setenv("GPU_MAX_HW_QUEUES", "16", 0);
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
@@ -251,8 +255,8 @@ int tptShutdown(void)
     (void)hipFree(g.dPairs); (void)hipFree(g.dSph4); (void)hipFree(g.dInvR); (void)hipFree(g.dMats); (void)hipFree(g.dLights);
     (void)hipFree(g.dWork); (void)hipFree(g.dRaysOwn); (void)hipFree(g.dFrame);
     (void)hipFree(g.dChunkCost); g.dChunkCost = nullptr; g.chunkCap = 0; g.chunkCount = 0; g.orderSeq = 0;
-    for (int k = 0; k < 6; ++k) { (void)hipFree(g.dChunkOrder[k]); g.dChunkOrder[k] = nullptr; }
-    for (int k = 0; k < 4; ++k) { (void)hipFree(g.dChunkSnap[k]); g.dChunkSnap[k] = nullptr; }
+    for (int k = 0; k < 10; ++k) { (void)hipFree(g.dChunkOrder[k]); g.dChunkOrder[k] = nullptr; }
+    for (int k = 0; k < 8; ++k) { (void)hipFree(g.dChunkSnap[k]); g.dChunkSnap[k] = nullptr; }
     g.dPairs = nullptr; g.dSph4 = nullptr; g.dInvR = nullptr; g.dMats = nullptr; g.dLights = nullptr;
     g.dWork = nullptr; g.dRays = nullptr; g.dRaysOwn = nullptr; g.dFrame = nullptr;
     g.frameCap = 0;
@@ -339,7 +343,7 @@ int tptKernelTimingEnd(float* outSumMs, int* outLaunches)
 
 int tptSetFrameOverlap(int frames)
 {
-    if (frames < 1 || frames > Context::kMaxOverlap) return fail("tptSetFrameOverlap: 1..4");
+    if (frames < 1 || frames > Context::kMaxOverlap) return fail("tptSetFrameOverlap: 1..8");
     if (g.inited) {
         HIPCHK(hipStreamSynchronize(g.stream));
         for (int k = 0; k < Context::kMaxOverlap; ++k)
@@ -546,12 +550,12 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
             for (int k = 0; k < Context::kMaxOverlap; ++k) HIPCHK(hipStreamSynchronize(g.traceStream[k]));
             if (g.dChunkCost) HIPCHK(hipFree(g.dChunkCost));
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dChunkCost), sizeof(unsigned) * (size_t)a.numChunks));
-            for (int k = 0; k < 6; ++k) {
+            for (int k = 0; k < 10; ++k) {
                 if (g.dChunkOrder[k]) HIPCHK(hipFree(g.dChunkOrder[k]));
                 g.dChunkOrder[k] = nullptr;
                 HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dChunkOrder[k]), sizeof(unsigned) * (size_t)a.numChunks));
             }
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < 8; ++k) {
                 if (g.dChunkSnap[k]) HIPCHK(hipFree(g.dChunkSnap[k]));
                 g.dChunkSnap[k] = nullptr;
                 HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dChunkSnap[k]), sizeof(unsigned) * (size_t)a.numChunks));
@@ -589,14 +593,15 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
     if (nOverlap > 1 && g.resolveRecorded[slot]) HIPCHK(hipStreamWaitEvent(ts, g.evResolve[slot], 0)); // colour buffer free again
     if (useOrder && g.orderSeq > 0) {
         // re-sort from the statistics gathered so far (a few frames suffice for a static scene; refresh every 32nd).
-        // The table is one of 6 rotating buffers: a trace kernel still in flight keeps reading the one it was given.
-        unsigned* table = g.dChunkOrder[g.orderSeq % 6];
+        // The table is one of 10 rotating buffers (> frames in flight): a trace kernel still in flight keeps reading the
+        // one it was given.
+        unsigned* table = g.dChunkOrder[g.orderSeq % 10];
         if (g.orderSeq <= 6 || (g.orderSeq & 31ull) == 0ull) {
             HIPCHK(tptLaunchChunkOrder(g.dChunkCost, g.dChunkSnap[slot], table, a.numChunks, ts));
         } else {
             table = g.dChunkOrder[g.lastOrderTable];
         }
-        g.lastOrderTable = (int)(table == g.dChunkOrder[g.orderSeq % 6] ? g.orderSeq % 6 : g.lastOrderTable);
+        g.lastOrderTable = (int)(table == g.dChunkOrder[g.orderSeq % 10] ? g.orderSeq % 10 : g.lastOrderTable);
         a.chunkOrder = table;
     }
     if (useOrder) g.orderSeq++;

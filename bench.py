@@ -216,8 +216,10 @@ def main():
                          "frac": hbm_write_gbs / PEAK_HBM_GBS, "traffic": traffic,
                          "achieved_read_plus_write": 2 * hbm_write_gbs,
                          "achieved_per_pipeline_slot": hbm_write_gbs * k_ms / p_ms, "launch_ms_avg": k_ms, "launches": launches,
-                         "note": "north_star's HBM-write roofline (W*H*16 B per frame / kernel time); the kernel is FP32-VALU bound "
-                                 "(arithmetic intensity ~440 flop/B), see roofline_valu",
+                         "note": "north_star's HBM-write roofline (W*H*16 B per frame / average launch duration); up to %d launches share "
+                                 "the GPU at once, so the per-launch figure understates the chip by that factor: *_per_pipeline_slot divides by "
+                                 "the time a frame occupies the pipeline instead.  The kernel is FP32-VALU bound (arithmetic intensity ~440 "
+                                 "flop/B), see roofline_valu" % args.overlap,
                          "kernel": "tptTraceKernel"},
             "roofline_valu": {"bound": "valu_fp32", "achieved": valu_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                               "frac": valu_tflops / PEAK_FP32_TFLOPS,

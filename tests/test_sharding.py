@@ -64,9 +64,10 @@ def _worker(rank, world, port, w, h, stripe, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gather_reassembles_the_single_process_image(oracle):
+@pytest.mark.parametrize("world,h,stripe", [(2, 42, 4), (3, 50, 8)], ids=["2ranks", "3ranks_uneven"])
+def test_gather_reassembles_the_single_process_image(oracle, world, h, stripe):
     from oracle_lib import SEED_PER_PIXEL
-    w, h, stripe, world = 64, 42, 4, 2
+    w = 64
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]

@@ -66,7 +66,11 @@ def assemble(tiles, height, stripe_rows, num_parts, out=None, row_index=None):
 
 class ShardedFrame:
     """One process per GPU.  The caller renders this rank's rows into `self.tile` (on `render_stream` when
-    on a GPU) and then calls `exchange()`; `finish()` drains the pipeline and returns what rank 0 holds."""
+    on a GPU) and then calls `exchange()`; `finish()` drains the pipeline and returns what rank 0 holds.
+
+    Per frame there is exactly ONE collective: a gather of `pad_rows + 1` rows per rank -- the tile plus one
+    extra row whose first 8 bytes carry the rank's 64-bit ray counter (exact integer, bit-cast) -- and on
+    rank 0 one index_select that de-interleaves the row stripes into the image."""
 
     def __init__(self, width, height, stripe_rows, rank, world, device, dist=None):
         import torch
@@ -85,11 +89,19 @@ class ShardedFrame:
         self.total_rays = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.steps = 0
         if world > 1:
-            self.send = [torch.zeros_like(self.tile) for _ in range(2)]
-            self.send_rays = [torch.zeros(1, dtype=torch.int64, device=self.device) for _ in range(2)]
-            self.recv = [[torch.empty_like(self.tile) for _ in range(world)] for _ in range(2)] if rank == 0 else None
-            self.row_index = [torch.as_tensor(local_to_global_rows(height, stripe_rows, world, p), device=self.device)
-                              for p in range(world)] if rank == 0 else None
+            assert width >= 1
+            self.send = [torch.zeros((self.pad_rows + 1, width, 4), **z) for _ in range(2)]
+            if rank == 0:
+                self.recv = [torch.zeros((world, self.pad_rows + 1, width, 4), **z) for _ in range(2)]
+                self.recv_list = [[r[i] for i in range(world)] for r in self.recv]
+                # image row y comes from row (p * (pad_rows + 1) + ly) of the flattened receive buffer
+                rowmap = np.empty(height, np.int64)
+                for p in range(world):
+                    g = local_to_global_rows(height, stripe_rows, world, p)
+                    rowmap[g] = p * (self.pad_rows + 1) + np.arange(len(g))
+                self.rowmap = torch.as_tensor(rowmap, device=self.device)
+            else:
+                self.recv = self.recv_list = None
         if self.on_gpu:
             self.render_stream = torch.cuda.Stream(device=self.device)
             self.comm_stream = torch.cuda.Stream(device=self.device)
@@ -98,9 +110,15 @@ class ShardedFrame:
         else:
             self.render_stream = self.comm_stream = None
 
+    def _fill_send(self, k):
+        send = self.send[k]
+        send[: self.pad_rows].copy_(self.tile, non_blocking=True)
+        # the 64-bit ray counter rides in the first 8 bytes of the extra row (bit-cast, not converted)
+        send[self.pad_rows, 0, :2].view(self.torch.int64).copy_(self.ray_counter, non_blocking=True)
+
     def exchange(self):
         """Call after this frame's render has been enqueued on render_stream."""
-        torch, dist = self.torch, self.dist
+        torch = self.torch
         k = self.steps & 1
         self.steps += 1
         if self.world <= 1:
@@ -109,25 +127,23 @@ class ShardedFrame:
             with torch.cuda.stream(self.render_stream):
                 if self.steps > 2:
                     self.render_stream.wait_event(self.ev_free[k])    # gather of frame f-2 has read this buffer
-                self.send[k].copy_(self.tile, non_blocking=True)
-                self.send_rays[k].copy_(self.ray_counter, non_blocking=True)
+                self._fill_send(k)
                 self.ev_ready[k].record(self.render_stream)
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(self.ev_ready[k])
                 self._collect(k)
                 self.ev_free[k].record(self.comm_stream)
         else:
-            self.send[k].copy_(self.tile)
-            self.send_rays[k].copy_(self.ray_counter)
+            self._fill_send(k)
             self._collect(k)
 
     def _collect(self, k):
-        dist = self.dist
-        dist.gather(self.send[k], self.recv[k] if self.rank == 0 else None, dst=0)  # the one exchange step
-        dist.reduce(self.send_rays[k], dst=0, op=dist.ReduceOp.SUM)                 # exact integer ray count
+        torch = self.torch
+        self.dist.gather(self.send[k], self.recv_list[k] if self.rank == 0 else None, dst=0)  # the one exchange step
         if self.rank == 0:
-            assemble(self.recv[k], self.height, self.stripe_rows, self.world, out=self.image, row_index=self.row_index)
-            self.total_rays.copy_(self.send_rays[k])
+            flat = self.recv[k].view(self.world * (self.pad_rows + 1), self.width, 4)
+            torch.index_select(flat, 0, self.rowmap, out=self.image)
+            self.last = k
 
     def finish(self):
         """Drain both streams.  Returns (image, cumulative rays over all ranks) on rank 0, (None, None) elsewhere."""
@@ -140,4 +156,7 @@ class ShardedFrame:
             self.total_rays.copy_(self.ray_counter)
         if self.rank != 0:
             return None, None
+        if self.world > 1 and self.steps > 0:
+            counters = self.recv[self.last][:, self.pad_rows, 0, :2].contiguous().view(torch.int64)
+            self.total_rays[0] = counters.sum()
         return self.image, int(self.total_rays.item())

@@ -47,6 +47,7 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_FP32_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector (counts FMA as 2)
 FLOP_PER_SPHERE_TEST = 17      # per (ray, sphere) test
 FLAG_PROGRESSIVE = 2
+FLAG_ANIMATE = 1
 
 
 def cpu_baseline(width, height, spp, budget_s=10.0):
@@ -98,6 +99,8 @@ def main():
     ap.add_argument("--persistent", type=int, default=1, help="1 persistent waves (default) 0 thread-per-pixel 2 lane-sorting 3 path queues")
     ap.add_argument("--fold", type=int, default=0, help="0 recursive (reference order, default) 1 forward")
     ap.add_argument("--lds-scene", type=int, default=-1)
+    ap.add_argument("--animate", action="store_true",
+                    help="kFlagAnimate: spheres 1 and 8 move every frame (time = frame/60 s), the scene is re-uploaded per frame")
     ap.add_argument("--overlap", type=int, default=8, help="trace kernels of up to this many consecutive frames may be in flight")
     args = ap.parse_args()
 
@@ -143,9 +146,12 @@ def main():
     api.set_ray_counter(sf.ray_counter.data_ptr())
     tile_ptr = sf.tile.data_ptr()
 
+    flags = FLAG_PROGRESSIVE | (FLAG_ANIMATE if args.animate else 0)
+
     def step(frame):
-        api.UpdateTest(0.0, frame, width, height, FLAG_PROGRESSIVE)
-        api.draw_device(0.0, frame, width, height, tile_ptr, FLAG_PROGRESSIVE)
+        t = frame / 60.0 if args.animate else 0.0
+        api.UpdateTest(t, frame, width, height, flags)
+        api.draw_device(t, frame, width, height, tile_ptr, flags)
         sf.exchange()
 
     def fence():
@@ -205,6 +211,7 @@ def main():
             "config": {"workload": label, "width": width, "height": height, "spp": spp, "spheres": n_spheres,
                        "seed_mode": "per_pixel", "fold": "forward" if args.fold else "recursive",
                        "hit_spheres": "simple" if args.hit_spheres else "two_phase", "kernel": ["thread_per_pixel", "persistent_waves", "lane_sorting", "path_queues"][args.persistent], "frame_overlap": args.overlap,
+                       "flags": "progressive|animate" if args.animate else "progressive",
                        "sharding": "none" if world == 1 else "row stripes of %d, round-robin over %d ranks, pipelined gather to rank 0" % (args.stripe_rows, world),
                        "device": api.device_name(), "grid_blocks": info["grid_blocks"], "blocks_per_cu": info["blocks_per_cu"],
                        "lds_bytes_per_block": info["lds_bytes"]},

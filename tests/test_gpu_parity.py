@@ -258,6 +258,37 @@ def test_frame_overlap_is_bit_identical(tpt_defaults, oracle, overlap):
     tpt.set_frame_overlap(8)
 
 
+@pytest.mark.parametrize("overlap", [1, 8])
+def test_animated_scene_async_upload_ring(tpt_defaults, oracle, overlap):
+    """kFlagAnimate on the asynchronous path: every frame re-packs the scene at its own time (Test.cpp:304-308) and
+    uploads it into the next scene set while up to 8 earlier frames are still tracing with the older sets.  40 frames
+    wrap the 16-set ring twice; no host synchronisation until the end."""
+    import torch
+    tpt = tpt_defaults
+    tpt.set_scene(None)
+    tpt.set_frame_overlap(overlap)
+    w, h, frames = 96, 64, 40
+    flags = FLAG_PROGRESSIVE | FLAG_ANIMATE
+    tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    r0 = tpt.ray_counter_read()
+    for f in range(frames):
+        t = 0.37 * f
+        tpt.UpdateTest(t, f, w, h, flags)
+        tpt.draw_device(t, f, w, h, tile.data_ptr(), flags)
+    rays = tpt.ray_counter_read() - r0
+    spheres, mats = oracle.default_scene()
+    cam = oracle.default_camera(w, h)
+    bo = np.zeros((h, w, 4), np.float32)
+    ro = 0
+    for f in range(frames):
+        oracle.animate(spheres, 0.37 * f)
+        r, _ = oracle.render(spheres, mats, cam, w, h, 4, f, flags, backbuffer=bo, seed_mode=SEED_PER_PIXEL)
+        ro += r
+    assert rays == ro and tile.cpu().numpy().tobytes() == bo.tobytes()
+    tpt.set_scene(None)
+    tpt.set_frame_overlap(8)
+
+
 @pytest.mark.parametrize("variant,fold", [(2, FOLD_RECURSIVE), (2, FOLD_FORWARD), (3, FOLD_RECURSIVE)],
                          ids=["sorted-recursive", "sorted-forward", "path_queues-recursive"])
 def test_experimental_kernels_full_size_and_stress(tpt_defaults, oracle, variant, fold):

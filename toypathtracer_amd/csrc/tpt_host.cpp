@@ -35,15 +35,28 @@ struct Context {
     CameraSetup camSetup = defaultCameraSetup();
     CameraPOD cam;
     PackedScene packed;
-    bool sceneDirty = true; // host arrays changed since last pack+upload
+    bool sceneDirty = true; // host arrays changed since last pack
     bool updated = false;   // tptUpdate ran at least once
 
-    // device scene
-    float* dPairs = nullptr;
-    f4* dSph4 = nullptr;
-    float* dInvR = nullptr;
-    f4* dMats = nullptr;
-    f4* dLights = nullptr;
+    // device scene: a ring of scene sets, so that an animated scene (kFlagAnimate re-packs every frame,
+    // Test.cpp:304-308,321-339) is uploaded asynchronously while earlier frames still read the older sets.
+    // One device blob + one pinned host staging blob per set, laid out pairs | sph4 | invR | mats | lights.
+    // A frame uploads at most one set, a set is reused after kSceneSets uploads, at most kMaxOverlap (8) frames
+    // are in flight and the upload is stream-ordered behind the resolve of frame f-8: no kernel still reads the
+    // set that is being overwritten.
+    static const int kSceneSets = 16;
+    struct SceneSet {
+        char* dev = nullptr;
+        char* stage = nullptr; // pinned
+        size_t cap = 0, bytes = 0;
+        size_t offSph4 = 0, offInvR = 0, offMats = 0, offLights = 0;
+        int nSpheres = 0, nPairs = 0, nLights = 0;
+        hipEvent_t evUploaded = nullptr;
+        hipStream_t uploadStream = nullptr;
+        bool copyEnqueued = false, copyDone = false;
+    } sets[kSceneSets];
+    int curSet = -1, pendingSet = -1;
+    unsigned uploadSeq = 0;
 
     // run-time versions of the reference's compile-time switches
     int spp = 4;                     // DO_SAMPLES_PER_PIXEL, Config.h:22
@@ -141,45 +154,91 @@ int ensureDev(T*& p, int& cap, int need)
     return 0;
 }
 
-struct ScenePtrCaps {
-    int pairs = 0, sph4 = 0, invR = 0, mats = 0, lights = 0;
-} caps;
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-int uploadSceneTracked()
+// UpdateTest's scene half: pack the host scene into the pinned staging blob of a fresh scene set.  Nothing is
+// enqueued here; the draw that follows copies the blob on its own trace stream (enqueueSceneUpload).
+int stageScene()
 {
     packScene(g.spheres, g.mats, g.packed);
     const PackedScene& P = g.packed;
-    int rc;
-    if ((rc = ensureDev(g.dPairs, caps.pairs, P.nPairs * 8))) return rc;
-    if ((rc = ensureDev(g.dSph4, caps.sph4, P.nPairs * 2))) return rc;
-    if ((rc = ensureDev(g.dInvR, caps.invR, P.nPairs * 2))) return rc;
-    if ((rc = ensureDev(g.dMats, caps.mats, P.nSpheres * 3))) return rc;
-    if ((rc = ensureDev(g.dLights, caps.lights, P.nLights * 2 + 2))) return rc;
-    HIPCHK(hipStreamSynchronize(g.stream)); // resolves wait on every trace kernel -> nothing reads the scene any more
-    for (int k = 0; k < Context::kMaxOverlap; ++k)
-        if (g.traceStream[k]) HIPCHK(hipStreamSynchronize(g.traceStream[k]));
-    HIPCHK(hipMemcpy(g.dPairs, P.pairs.data(), P.pairs.size() * sizeof(float), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(g.dSph4, P.sph4.data(), P.sph4.size() * sizeof(f4), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(g.dInvR, P.invR.data(), P.invR.size() * sizeof(float), hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(g.dMats, P.mats.data(), P.mats.size() * sizeof(f4), hipMemcpyHostToDevice));
-    if (!P.lights.empty())
-        HIPCHK(hipMemcpy(g.dLights, P.lights.data(), P.lights.size() * sizeof(f4), hipMemcpyHostToDevice));
+    if (g.pendingSet < 0) g.pendingSet = (int)(g.uploadSeq++ % Context::kSceneSets);
+    Context::SceneSet& S = g.sets[g.pendingSet];
+    const size_t bPairs = P.pairs.size() * sizeof(float), bSph4 = P.sph4.size() * sizeof(f4), bInvR = P.invR.size() * sizeof(float),
+                 bMats = P.mats.size() * sizeof(f4), bLights = P.lights.size() * sizeof(f4);
+    const size_t offSph4 = align256(bPairs), offInvR = offSph4 + align256(bSph4), offMats = offInvR + align256(bInvR),
+                 offLights = offMats + align256(bMats), total = offLights + align256(bLights + 32);
+    if (!S.evUploaded) HIPCHK(hipEventCreateWithFlags(&S.evUploaded, hipEventDisableTiming));
+    // the previous copy out of this staging blob (16 uploads ago) must have left the host before we overwrite it:
+    // only ever waits when the host has run more than 16 animated frames ahead of the GPU
+    if (S.copyEnqueued && !S.copyDone) HIPCHK(hipEventSynchronize(S.evUploaded));
+    if (total > S.cap) {
+        HIPCHK(hipDeviceSynchronize());
+        if (S.dev) HIPCHK(hipFree(S.dev));
+        if (S.stage) HIPCHK(hipHostFree(S.stage));
+        S.dev = nullptr; S.stage = nullptr; S.cap = 0;
+        const size_t cap = total < 4096 ? 4096 : total + total / 4;
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&S.dev), cap));
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&S.stage), cap, hipHostMallocDefault));
+        S.cap = cap;
+    }
+    memcpy(S.stage, P.pairs.data(), bPairs);
+    memcpy(S.stage + offSph4, P.sph4.data(), bSph4);
+    memcpy(S.stage + offInvR, P.invR.data(), bInvR);
+    memcpy(S.stage + offMats, P.mats.data(), bMats);
+    if (bLights) memcpy(S.stage + offLights, P.lights.data(), bLights);
+    S.bytes = offLights + bLights;
+    S.offSph4 = offSph4; S.offInvR = offInvR; S.offMats = offMats; S.offLights = offLights;
+    S.nSpheres = P.nSpheres; S.nPairs = P.nPairs; S.nLights = P.nLights;
+    S.copyEnqueued = false; S.copyDone = false; S.uploadStream = nullptr;
     g.sceneDirty = false;
     return 0;
+}
+
+// the set the next launch reads (the staged one if an upload is pending)
+Context::SceneSet* activeSet()
+{
+    const int k = g.pendingSet >= 0 ? g.pendingSet : g.curSet;
+    return k >= 0 ? &g.sets[k] : nullptr;
 }
 
 SceneView deviceView()
 {
     SceneView sv;
-    sv.pairs = g.dPairs;
-    sv.sph4 = g.dSph4;
-    sv.invR = g.dInvR;
-    sv.mats = g.dMats;
-    sv.lights = g.dLights;
-    sv.nSpheres = g.packed.nSpheres;
-    sv.nPairs = g.packed.nPairs;
-    sv.nLights = g.packed.nLights;
+    memset(&sv, 0, sizeof(sv));
+    Context::SceneSet* S = activeSet();
+    if (!S) return sv;
+    sv.pairs = reinterpret_cast<const float*>(S->dev);
+    sv.sph4 = reinterpret_cast<const f4*>(S->dev + S->offSph4);
+    sv.invR = reinterpret_cast<const float*>(S->dev + S->offInvR);
+    sv.mats = reinterpret_cast<const f4*>(S->dev + S->offMats);
+    sv.lights = reinterpret_cast<const f4*>(S->dev + S->offLights);
+    sv.nSpheres = S->nSpheres;
+    sv.nPairs = S->nPairs;
+    sv.nLights = S->nLights;
     return sv;
+}
+
+// Make the active scene set visible to work enqueued on `ts` from here on: copy a pending set on `ts` itself, or
+// make `ts` wait for the copy another stream carries.
+int enqueueSceneUpload(hipStream_t ts)
+{
+    if (g.pendingSet >= 0) {
+        Context::SceneSet& S = g.sets[g.pendingSet];
+        HIPCHK(hipMemcpyAsync(S.dev, S.stage, S.bytes, hipMemcpyHostToDevice, ts));
+        HIPCHK(hipEventRecord(S.evUploaded, ts));
+        S.copyEnqueued = true; S.copyDone = false; S.uploadStream = ts;
+        g.curSet = g.pendingSet;
+        g.pendingSet = -1;
+        return 0;
+    }
+    if (g.curSet < 0) return fail("tpt: no scene uploaded (call tptUpdate first)");
+    Context::SceneSet& S = g.sets[g.curSet];
+    if (!S.copyDone && S.uploadStream != ts) {
+        if (hipEventQuery(S.evUploaded) == hipSuccess) S.copyDone = true;
+        else HIPCHK(hipStreamWaitEvent(ts, S.evUploaded, 0));
+    }
+    return 0;
 }
 
 int requireInit()
@@ -252,15 +311,21 @@ int tptShutdown(void)
 {
     if (!g.inited) return 0;
     (void)hipStreamSynchronize(g.stream);
-    (void)hipFree(g.dPairs); (void)hipFree(g.dSph4); (void)hipFree(g.dInvR); (void)hipFree(g.dMats); (void)hipFree(g.dLights);
+    (void)hipDeviceSynchronize();
+    for (int k = 0; k < Context::kSceneSets; ++k) {
+        Context::SceneSet& S = g.sets[k];
+        (void)hipFree(S.dev);
+        if (S.stage) (void)hipHostFree(S.stage);
+        if (S.evUploaded) (void)hipEventDestroy(S.evUploaded);
+        S = Context::SceneSet();
+    }
+    g.curSet = -1; g.pendingSet = -1; g.uploadSeq = 0;
     (void)hipFree(g.dWork); (void)hipFree(g.dRaysOwn); (void)hipFree(g.dFrame);
     (void)hipFree(g.dChunkCost); g.dChunkCost = nullptr; g.chunkCap = 0; g.chunkCount = 0; g.orderSeq = 0;
     for (int k = 0; k < 10; ++k) { (void)hipFree(g.dChunkOrder[k]); g.dChunkOrder[k] = nullptr; }
     for (int k = 0; k < 8; ++k) { (void)hipFree(g.dChunkSnap[k]); g.dChunkSnap[k] = nullptr; }
-    g.dPairs = nullptr; g.dSph4 = nullptr; g.dInvR = nullptr; g.dMats = nullptr; g.dLights = nullptr;
     g.dWork = nullptr; g.dRays = nullptr; g.dRaysOwn = nullptr; g.dFrame = nullptr;
     g.frameCap = 0;
-    caps = ScenePtrCaps();
     for (size_t i = 0; i < g.ktStart.size(); ++i) { (void)hipEventDestroy(g.ktStart[i]); (void)hipEventDestroy(g.ktStop[i]); }
     g.ktStart.clear(); g.ktStop.clear(); g.ktUsed = 0; g.kernelTiming = false;
     for (int k = 0; k < Context::kMaxOverlap; ++k) {
@@ -418,8 +483,8 @@ int tptUpdate(float time, int frameCount, int screenWidth, int screenHeight, uns
         g.spheres[8].cz = sinf(time) * 0.3f;
         g.sceneDirty = true;
     }
-    if (g.sceneDirty) {
-        int rc = uploadSceneTracked();
+    if (g.sceneDirty || (g.curSet < 0 && g.pendingSet < 0)) {
+        int rc = stageScene();
         if (rc) return rc;
     }
     g.cam = makeCamera(g.camSetup, float(screenWidth) / float(screenHeight)); // Test.cpp:341
@@ -433,12 +498,12 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
     if (requireInit()) return -1;
     if (!g.updated) return fail("tptDrawDevice: call tptUpdate (UpdateTest) first");
     if (!deviceTile || w <= 0 || h <= 0) return fail("tptDrawDevice: bad arguments");
-    if (g.sceneDirty) {
-        int rc = uploadSceneTracked();
+    if (g.sceneDirty || (g.curSet < 0 && g.pendingSet < 0)) { // tptSetScene after the last tptUpdate
+        int rc = stageScene();
         if (rc) return rc;
     }
     KernelArgs a;
-    a.scene = deviceView();
+    a.scene = deviceView(); // pointers of the set this frame reads; its upload is enqueued below, on the frame's stream
     a.fc = makeFrameConsts(g.cam, w, h, g.spp, frameCount, testFlags, g.seedMode);
     a.nLocalRows = localRows(h);
     if (g.numParts > 1 && g.stripeRows > 0) {
@@ -591,6 +656,10 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
     // trace(f) on its own stream (no dependency on the previous frame), then the ordered blend on g.stream
     hipStream_t ts = nOverlap > 1 ? g.traceStream[slot] : g.stream;
     if (nOverlap > 1 && g.resolveRecorded[slot]) HIPCHK(hipStreamWaitEvent(ts, g.evResolve[slot], 0)); // colour buffer free again
+    {
+        int rc = enqueueSceneUpload(ts); // behind the wait above: frames <= f-8 are done, nobody reads the set being replaced
+        if (rc) return rc;
+    }
     if (useOrder && g.orderSeq > 0) {
         // re-sort from the statistics gathered so far (a few frames suffice for a static scene; refresh every 32nd).
         // The table is one of 10 rotating buffers (> frames in flight): a trace kernel still in flight keeps reading the
@@ -813,8 +882,12 @@ int tptTestHitSpheres(int hitSpheres, const float* rays, int* outId, float* outT
 {
     if (requireInit()) return -1;
     if (!rays || !outId || !outT || n <= 0) return fail("tptTestHitSpheres: bad arguments");
-    if (g.sceneDirty) {
-        int rc = uploadSceneTracked();
+    if (g.sceneDirty || (g.curSet < 0 && g.pendingSet < 0)) {
+        int rc = stageScene();
+        if (rc) return rc;
+    }
+    {
+        int rc = enqueueSceneUpload(g.stream);
         if (rc) return rc;
     }
     float *dr = nullptr, *dt = nullptr;

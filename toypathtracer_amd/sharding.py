@@ -8,8 +8,8 @@ rank renders its stripes into a compact tile that stays resident in its HBM, and
 8-byte sum-reduce of the ray counters.  Seeds depend on global (x, y) only, so the assembled image
 is bit-identical to a 1-GPU render.
 
-The exchange is software-pipelined against rendering: frame f's tile is snapshotted into one of two
-send buffers on the render stream and gathered on a communication stream while frame f+1 renders
+The exchange is software-pipelined against rendering: frame f's tile is snapshotted into one of `depth`
+(default 4) send buffers on the render stream and gathered on a communication stream while frame f+1 renders
 (the accumulation tile itself is read-modify-written in place by the kernel, so it cannot be the
 gather source).  With CPU tensors (gloo, the CPU test suite) the same code runs without streams.
 
@@ -72,7 +72,7 @@ class ShardedFrame:
     extra row whose first 8 bytes carry the rank's 64-bit ray counter (exact integer, bit-cast) -- and on
     rank 0 one index_select that de-interleaves the row stripes into the image."""
 
-    def __init__(self, width, height, stripe_rows, rank, world, device, dist=None):
+    def __init__(self, width, height, stripe_rows, rank, world, device, dist=None, depth=4):
         import torch
 
         self.torch, self.dist = torch, dist
@@ -88,11 +88,12 @@ class ShardedFrame:
         self.image = torch.zeros((height, width, 4), **z) if rank == 0 else None
         self.total_rays = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.steps = 0
+        self.depth = depth = max(1, int(depth))  # gathers that may be in flight behind the renderer
         if world > 1:
             assert width >= 1
-            self.send = [torch.zeros((self.pad_rows + 1, width, 4), **z) for _ in range(2)]
+            self.send = [torch.zeros((self.pad_rows + 1, width, 4), **z) for _ in range(depth)]
             if rank == 0:
-                self.recv = [torch.zeros((world, self.pad_rows + 1, width, 4), **z) for _ in range(2)]
+                self.recv = [torch.zeros((world, self.pad_rows + 1, width, 4), **z) for _ in range(depth)]
                 self.recv_list = [[r[i] for i in range(world)] for r in self.recv]
                 # image row y comes from row (p * (pad_rows + 1) + ly) of the flattened receive buffer
                 rowmap = np.empty(height, np.int64)
@@ -105,8 +106,8 @@ class ShardedFrame:
         if self.on_gpu:
             self.render_stream = torch.cuda.Stream(device=self.device)
             self.comm_stream = torch.cuda.Stream(device=self.device)
-            self.ev_ready = [torch.cuda.Event() for _ in range(2)]   # send buffer filled (render stream)
-            self.ev_free = [torch.cuda.Event() for _ in range(2)]    # send buffer consumed (comm stream)
+            self.ev_ready = [torch.cuda.Event() for _ in range(depth)]   # send buffer filled (render stream)
+            self.ev_free = [torch.cuda.Event() for _ in range(depth)]    # send buffer consumed (comm stream)
         else:
             self.render_stream = self.comm_stream = None
 
@@ -119,14 +120,14 @@ class ShardedFrame:
     def exchange(self):
         """Call after this frame's render has been enqueued on render_stream."""
         torch = self.torch
-        k = self.steps & 1
+        k = self.steps % self.depth
         self.steps += 1
         if self.world <= 1:
             return
         if self.on_gpu:
             with torch.cuda.stream(self.render_stream):
-                if self.steps > 2:
-                    self.render_stream.wait_event(self.ev_free[k])    # gather of frame f-2 has read this buffer
+                if self.steps > self.depth:
+                    self.render_stream.wait_event(self.ev_free[k])    # gather of frame f-depth has read this buffer
                 self._fill_send(k)
                 self.ev_ready[k].record(self.render_stream)
             with torch.cuda.stream(self.comm_stream):

@@ -27,7 +27,7 @@ for (w, h, spp, persist) in [(1280, 720, 4, 3), (3840, 2160, 16, 3)]:
     if waves:
         span = (int(st[26]) - int(st[25])) * 10e-9
         print("  waves %d  kernel span %.3f ms  mean wave lifetime %.3f ms  longest %.3f ms" % (waves, span * 1e3, int(st[24]) / waves * 10e-6, int(st[28]) * 10e-6))
-    QN = ["FREE", "INT", "END", "DIEL", "METAL", "LAMBERT", "SHADOW"]
+    QN = ["FREE", "INT", "END", "DIEL", "METAL", "LAMBERT"]
     for c, n in enumerate(QN):
         if st[16 + c]:
             print("  queue %-8s batches %9d  paths %11d  fill %.1f / 64" % (n, st[16 + c], st[48 + c], st[48 + c] / st[16 + c]))

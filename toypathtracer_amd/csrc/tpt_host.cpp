@@ -23,6 +23,8 @@ using namespace tpt;
 namespace {
 
 struct Context {
+    static const int kMaxOverlap = 16;              // frames in flight (trace streams, colour buffers, ...)
+    static const int kOrderTables = kMaxOverlap + 2; // rotating chunk-order tables: more than frames in flight
     bool inited = false;
     int device = 0, numCUs = 0;
     std::string deviceName, err;
@@ -41,10 +43,10 @@ struct Context {
     // device scene: a ring of scene sets, so that an animated scene (kFlagAnimate re-packs every frame,
     // Test.cpp:304-308,321-339) is uploaded asynchronously while earlier frames still read the older sets.
     // One device blob + one pinned host staging blob per set, laid out pairs | sph4 | invR | mats | lights.
-    // A frame uploads at most one set, a set is reused after kSceneSets uploads, at most kMaxOverlap (8) frames
+    // A frame uploads at most one set, a set is reused after kSceneSets uploads, at most kMaxOverlap frames
     // are in flight and the upload is stream-ordered behind the resolve of frame f-8: no kernel still reads the
     // set that is being overwritten.
-    static const int kSceneSets = 16;
+    static const int kSceneSets = 2 * kMaxOverlap;
     struct SceneSet {
         char* dev = nullptr;
         char* stage = nullptr; // pinned
@@ -65,6 +67,7 @@ struct Context {
     int hs = HS_TWO_PHASE, persist = 1, ldsScene = -1;
     int stripeRows = 0, numParts = 1, part = 0;
     int maxBlocksPerCU = 0, chunkOverride = 0; // tuning knobs (env TPT_MAX_BLOCKS_PER_CU, TPT_CHUNK)
+    int gridDiv = 1;                            // env TPT_GRID_DIV: launch resident/gridDiv workgroups per frame
     int ldsStackLevels = 6;                     // recursive fold: bounce-stack levels kept in LDS (env TPT_LDS_STACK_LEVELS)
 
     unsigned* dWork = nullptr;
@@ -72,24 +75,23 @@ struct Context {
     unsigned long long* dRaysOwn = nullptr;
     long long lastTotal = 0;
 
-    f4* dStack[8] = {};       // recursive fold: global bounce stacks / spill levels (one per in-flight frame)
-    size_t stackCap[8] = {};
+    f4* dStack[kMaxOverlap] = {};       // recursive fold: global bounce stacks / spill levels (one per in-flight frame)
+    size_t stackCap[kMaxOverlap] = {};
     // cost-ordered chunk distribution (persistent kernel)
     unsigned* dChunkCost = nullptr;
-    unsigned* dChunkOrder[10] = {};
-    unsigned* dChunkSnap[8] = {}; // per trace stream: cost snapshot of the sort kernel
+    unsigned* dChunkOrder[kOrderTables] = {};
+    unsigned* dChunkSnap[kMaxOverlap] = {}; // per trace stream: cost snapshot of the sort kernel
     int chunkCap = 0, chunkCount = 0; // chunkCount: numChunks the statistics belong to
     int costOrder = 1;                // env TPT_COST_ORDER=0 disables
     unsigned long long orderSeq = 0;
     int lastOrderTable = 0;
-    f4* dPath[8] = {};        // path-queue kernel: cold path state (one per in-flight frame)
-    size_t pathCap[8] = {};
+    f4* dPath[kMaxOverlap] = {};        // path-queue kernel: cold path state (one per in-flight frame)
+    size_t pathCap[kMaxOverlap] = {};
     float* dFrame = nullptr; // device tile behind the host-pointer DrawTest
     size_t frameCap = 0;
 
     // frame pipelining: trace kernels of consecutive frames run on alternating internal streams and write
     // their own per-frame colour buffer; the (ordered) resolve kernels run on g.stream
-    static const int kMaxOverlap = 8;
     int overlap = 8;
     hipStream_t traceStream[kMaxOverlap] = {};
     hipEvent_t evTrace[kMaxOverlap] = {}, evResolve[kMaxOverlap] = {};
@@ -169,7 +171,7 @@ int stageScene()
     const size_t offSph4 = align256(bPairs), offInvR = offSph4 + align256(bSph4), offMats = offInvR + align256(bInvR),
                  offLights = offMats + align256(bMats), total = offLights + align256(bLights + 32);
     if (!S.evUploaded) HIPCHK(hipEventCreateWithFlags(&S.evUploaded, hipEventDisableTiming));
-    // the previous copy out of this staging blob (16 uploads ago) must have left the host before we overwrite it:
+    // the previous copy out of this staging blob (kSceneSets uploads ago) must have left the host before we overwrite it:
     // only ever waits when the host has run more than 16 animated frames ahead of the GPU
     if (S.copyEnqueued && !S.copyDone) HIPCHK(hipEventSynchronize(S.evUploaded));
     if (total > S.cap) {
@@ -295,6 +297,7 @@ int tptInitialize(void)
     g.lastTotal = 0;
     if (g.spheres.empty()) defaultScene(g.spheres, g.mats);
     if (const char* e1 = getenv("TPT_MAX_BLOCKS_PER_CU")) g.maxBlocksPerCU = atoi(e1);
+    if (const char* e5 = getenv("TPT_GRID_DIV")) g.gridDiv = atoi(e5) > 0 ? atoi(e5) : 1;
     if (const char* e2 = getenv("TPT_CHUNK")) g.chunkOverride = atoi(e2);
     if (const char* e4 = getenv("TPT_COST_ORDER")) g.costOrder = atoi(e4);
     if (const char* e3 = getenv("TPT_LDS_STACK_LEVELS")) {
@@ -322,8 +325,8 @@ int tptShutdown(void)
     g.curSet = -1; g.pendingSet = -1; g.uploadSeq = 0;
     (void)hipFree(g.dWork); (void)hipFree(g.dRaysOwn); (void)hipFree(g.dFrame);
     (void)hipFree(g.dChunkCost); g.dChunkCost = nullptr; g.chunkCap = 0; g.chunkCount = 0; g.orderSeq = 0;
-    for (int k = 0; k < 10; ++k) { (void)hipFree(g.dChunkOrder[k]); g.dChunkOrder[k] = nullptr; }
-    for (int k = 0; k < 8; ++k) { (void)hipFree(g.dChunkSnap[k]); g.dChunkSnap[k] = nullptr; }
+    for (int k = 0; k < Context::kOrderTables; ++k) { (void)hipFree(g.dChunkOrder[k]); g.dChunkOrder[k] = nullptr; }
+    for (int k = 0; k < Context::kMaxOverlap; ++k) { (void)hipFree(g.dChunkSnap[k]); g.dChunkSnap[k] = nullptr; }
     g.dWork = nullptr; g.dRays = nullptr; g.dRaysOwn = nullptr; g.dFrame = nullptr;
     g.frameCap = 0;
     for (size_t i = 0; i < g.ktStart.size(); ++i) { (void)hipEventDestroy(g.ktStart[i]); (void)hipEventDestroy(g.ktStop[i]); }
@@ -408,7 +411,7 @@ int tptKernelTimingEnd(float* outSumMs, int* outLaunches)
 
 int tptSetFrameOverlap(int frames)
 {
-    if (frames < 1 || frames > Context::kMaxOverlap) return fail("tptSetFrameOverlap: 1..8");
+    if (frames < 1 || frames > Context::kMaxOverlap) return fail("tptSetFrameOverlap: 1..16");
     if (g.inited) {
         HIPCHK(hipStreamSynchronize(g.stream));
         for (int k = 0; k < Context::kMaxOverlap; ++k)
@@ -574,7 +577,7 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
         a.chunkSize = chunk;
         a.numChunks = (a.numItems + chunk - 1) / chunk;
         blocks = (a.numChunks + wavesPerBlock - 1) / wavesPerBlock;
-        if (blocks > resident) blocks = resident;
+        if (blocks > resident / g.gridDiv) blocks = resident / g.gridDiv;
         if (blocks < 1) blocks = 1;
         a.totalWaves = (unsigned)(blocks * wavesPerBlock);
     } else {
@@ -615,12 +618,12 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
             for (int k = 0; k < Context::kMaxOverlap; ++k) HIPCHK(hipStreamSynchronize(g.traceStream[k]));
             if (g.dChunkCost) HIPCHK(hipFree(g.dChunkCost));
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dChunkCost), sizeof(unsigned) * (size_t)a.numChunks));
-            for (int k = 0; k < 10; ++k) {
+            for (int k = 0; k < Context::kOrderTables; ++k) {
                 if (g.dChunkOrder[k]) HIPCHK(hipFree(g.dChunkOrder[k]));
                 g.dChunkOrder[k] = nullptr;
                 HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dChunkOrder[k]), sizeof(unsigned) * (size_t)a.numChunks));
             }
-            for (int k = 0; k < 8; ++k) {
+            for (int k = 0; k < Context::kMaxOverlap; ++k) {
                 if (g.dChunkSnap[k]) HIPCHK(hipFree(g.dChunkSnap[k]));
                 g.dChunkSnap[k] = nullptr;
                 HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dChunkSnap[k]), sizeof(unsigned) * (size_t)a.numChunks));
@@ -639,7 +642,7 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
     }
     a.pathBuf = nullptr;
     if (queued) {
-        const size_t need = (size_t)blocks * tptQueuePathsPerBlock() * 4 * sizeof(f4);
+        const size_t need = (size_t)blocks * tptQueuePathsPerBlock() * sizeof(f4); // one colour sum per path
         if (need > g.pathCap[slot]) {
             HIPCHK(hipStreamSynchronize(g.stream));
             HIPCHK(hipStreamSynchronize(g.traceStream[slot]));
@@ -662,15 +665,15 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
     }
     if (useOrder && g.orderSeq > 0) {
         // re-sort from the statistics gathered so far (a few frames suffice for a static scene; refresh every 32nd).
-        // The table is one of 10 rotating buffers (> frames in flight): a trace kernel still in flight keeps reading the
+        // The table is one of kOrderTables rotating buffers (> frames in flight): a trace kernel still in flight keeps reading the
         // one it was given.
-        unsigned* table = g.dChunkOrder[g.orderSeq % 10];
+        unsigned* table = g.dChunkOrder[g.orderSeq % Context::kOrderTables];
         if (g.orderSeq <= 6 || (g.orderSeq & 31ull) == 0ull) {
             HIPCHK(tptLaunchChunkOrder(g.dChunkCost, g.dChunkSnap[slot], table, a.numChunks, ts));
         } else {
             table = g.dChunkOrder[g.lastOrderTable];
         }
-        g.lastOrderTable = (int)(table == g.dChunkOrder[g.orderSeq % 10] ? g.orderSeq % 10 : g.lastOrderTable);
+        g.lastOrderTable = (int)(table == g.dChunkOrder[g.orderSeq % Context::kOrderTables] ? g.orderSeq % Context::kOrderTables : g.lastOrderTable);
         a.chunkOrder = table;
     }
     if (useOrder) g.orderSeq++;

@@ -512,17 +512,22 @@ __global__ void __launch_bounds__(TPT_SORT_T) tptTraceSortedKernel(const KernelA
 
 // ---------------------------------------------------------------- path-queue variant
 // A workgroup of 8 waves owns a pool of 1024 paths (2 per lane, so the queues below stay deep enough to hand out
-// full batches); two such workgroups fit on a CU, so consecutive frames still overlap.  Waves are interchangeable
-// workers that pop batches of up to 64 path ids from per-operation queues in LDS:
-//   FREE -> [start: assign a pixel, camera ray] -> INT -> [HitWorld, classify] -> END | DIEL | METAL | LAMBERT | SHADOW
-//        -> [lanePost for that class, + fold / next sample's camera ray] -> INT ... or FREE when the pixel is done.
-// A batch holds paths that all need the same code, so the post-intersection blocks run at (nearly) full lane
-// utilisation instead of ~25 %, and a lane never idles because "its" pixel ended: any wave picks up any path.
+// full batches); two such workgroups fit on a CU.  Waves are interchangeable workers that pop batches of up to 64
+// path ids from per-operation queues in LDS:
+//   FREE    -> [assign a pixel, camera ray]                       \
+//   END     -> [sky / emission, fold, next sample's camera ray]    |  then, in the SAME iteration, HitWorld for the
+//   DIEL    -> [Scatter: dielectric]                               |  rays the batch produced, classify the hits and
+//   METAL   -> [Scatter: metal]                                    |  push every path to the queue of its next class
+//   LAMBERT -> [Scatter: lambert + the whole light loop: every    /   (or FREE when its pixel is done)
+//               shadow ray is intersected and shaded in place]
+//   INT     -> overflow only: rays of batches that kept fewer than TPT_Q_FUSE_MIN lanes are re-batched here first
+// A batch holds paths that all need the same code, so Scatter and the intersections that follow run at (nearly)
+// full lane utilisation instead of ~40 %, a lane never idles because "its" pixel ended (any wave picks up any path),
+// and a path crosses a queue once per bounce (not once per ray: the shadow rays of a Lambert hit stay in registers).
 // No barriers: the queues are multi-producer / multi-consumer rings (reserve with an LDS atomic, publish by
-// overwriting a 0xFFFF sentinel).  Path state: the 48 B every operation needs (ray, rng, flags, hit) live in LDS;
-// the light-sampling context (48 B) and the pixel's colour sum (16 B) are only touched by some classes and live in
-// global memory (L2-resident: 64 B x 1024 paths x 512 workgroups = 32 MB).  FOLD_RECURSIVE only; the bounce stack
-// is in global memory, one column per path.
+// overwriting a 0xFFFF sentinel).  Path state: the 48 B every class needs (ray, rng, flags, hit) live in LDS; the
+// pixel's colour sum (16 B, touched when a sample ends) and the bounce stack live in global memory (L2-resident).
+// FOLD_RECURSIVE only.
 #ifndef TPT_Q_WAVES
 #define TPT_Q_WAVES 8
 #endif
@@ -530,8 +535,11 @@ __global__ void __launch_bounds__(TPT_SORT_T) tptTraceSortedKernel(const KernelA
 #ifndef TPT_Q_P
 #define TPT_Q_P 1024 // paths per workgroup (power of two)
 #endif
+#ifndef TPT_Q_FUSE_MIN
+#define TPT_Q_FUSE_MIN 48 // a batch intersects its own rays when at least this many lanes still hold one
+#endif
 #define TPT_Q_NF4 3
-enum { Q_FREE = 0, Q_INT = 1, Q_END = 2, Q_DIEL = 3, Q_METAL = 4, Q_LAMBERT = 5, Q_SHADOW = 6, Q_COUNT = 7 };
+enum { Q_FREE = 0, Q_INT = 1, Q_END = 2, Q_DIEL = 3, Q_METAL = 4, Q_LAMBERT = 5, Q_COUNT = 6 };
 struct QueueCtl {
     unsigned head[8];
     unsigned tail[8];
@@ -539,7 +547,7 @@ struct QueueCtl {
     unsigned globalExhausted; // some wave saw the global chunk counter run out
 };
 
-// Push every lane's path id to the queue of its class `cls` (Q_FREE..Q_SHADOW, or -1 for none) with ONE LDS atomic
+// Push every lane's path id to the queue of its class `cls` (Q_FREE..Q_LAMBERT, or -1 for none) with ONE LDS atomic
 // instruction: lane c reserves the slots of class c, the bases come back through readlane.
 __device__ __forceinline__ void qPushByClass(volatile unsigned short* q, QueueCtl* ctl, int cls, int pathId, int lane)
 {
@@ -607,12 +615,12 @@ __device__ __forceinline__ void qUnflags(Lane& L, uint32_t flags)
     L.doMatE = ((flags >> 25) & 1u) != 0;
     L.sp = (int)((flags >> 26) & 15u);
 }
-// hot state (LDS): [0] orig.xyz rng  [1] dir.xyz t  [2] flags, id, pix, hitId | j << 20
-__device__ __forceinline__ void qStoreHot(const Lane& L, f4* st, int p)
+// hot state (LDS): [0] orig.xyz rng  [1] dir.xyz t  [2] flags, hit id, pix, -
+__device__ __forceinline__ void qStoreHot(const Lane& L, int id, float t, f4* st, int p)
 {
     st[0 * TPT_Q_P + p] = mk4(L.orig.x, L.orig.y, L.orig.z, u2f(L.rng));
-    st[1 * TPT_Q_P + p] = mk4(L.dir.x, L.dir.y, L.dir.z, 0.0f);
-    st[2 * TPT_Q_P + p] = mk4(u2f(qFlags(L)), 0.0f, u2f((uint32_t)L.pix), u2f((uint32_t)L.hitId | ((uint32_t)L.j << 20)));
+    st[1 * TPT_Q_P + p] = mk4(L.dir.x, L.dir.y, L.dir.z, t);
+    st[2 * TPT_Q_P + p] = mk4(u2f(qFlags(L)), u2f((uint32_t)id), u2f((uint32_t)L.pix), 0.0f);
 }
 __device__ __forceinline__ void qLoadHot(Lane& L, int& id, float& t, const f4* st, int p)
 {
@@ -624,10 +632,8 @@ __device__ __forceinline__ void qLoadHot(Lane& L, int& id, float& t, const f4* s
     qUnflags(L, f2u(v.x));
     id = (int)f2u(v.y);
     L.pix = (int)f2u(v.z);
-    L.hitId = (int)(f2u(v.w) & 0xfffffu);
-    L.j = (int)(f2u(v.w) >> 20);
 }
-// cold state (global, per path): [0] sdir.xyz cosAMax  [1] nl.xyz -  [2] lightE.xyz -  [3] col.xyz x|y<<16
+// cold state (global, per path): colour sum of the pixel's finished samples .xyz, x | y << 16
 
 #ifndef TPT_Q_MIN_WAVES_PER_SIMD
 #define TPT_Q_MIN_WAVES_PER_SIMD 4
@@ -679,13 +685,13 @@ __global__ void __launch_bounds__(TPT_Q_T, TPT_Q_MIN_WAVES_PER_SIMD) tptTraceQue
 
     const FrameConsts& fc = a.fc;
     const unsigned long long laneBelow = (1ull << lane) - 1ull;
-    f4* cold = a.pathBuf + (size_t)blockIdx.x * TPT_Q_P * 4; // this workgroup's [P][4] f4
+    f4* cold = a.pathBuf + (size_t)blockIdx.x * TPT_Q_P; // this workgroup's [P] colour sums
     int chunkNext = 0, chunkEnd = 0; // this wave's private pixel pool
     bool noMoreChunks = false;
-    unsigned waveRays = 0;
+    unsigned myRays = 0;
 
     for (;;) {
-        // ---- what is waiting?  lanes 0..6 read one queue each, broadcast through readlane
+        // ---- what is waiting?  lanes 0..5 read one queue each, broadcast through readlane
         unsigned myAvail = 0;
         if (lane < Q_COUNT)
             myAvail = __hip_atomic_load(&ctl->tail[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) -
@@ -733,10 +739,22 @@ __global__ void __launch_bounds__(TPT_Q_T, TPT_Q_MIN_WAVES_PER_SIMD) tptTraceQue
         if (mine) { TPT_STAT(16 + pick); } // [16+pick] batches popped per queue, [48+pick] paths in them
 #endif
 
+        Lane L;
+        L.active = false;
+        L.kind = KIND_MAIN;
+        L.depth = 0;
+        L.orig = L.dir = mk3(0, 0, 0);
+        bool ray = false;    // this lane holds a ray that still has to be intersected
+        bool toFree = false; // this lane's path goes back to the FREE queue
+        BounceStack stack;
+        stack.base = nullptr;
+        stack.stride = 0;
+        stack.fastLevels = 0;
+        stack.spill = a.stackBuf + ((size_t)blockIdx.x * TPT_Q_P + p);
+        stack.spillStride = a.stackStride;
+
         if (pick == Q_FREE) {
             // ---- start pixels on free paths (this wave's chunk pool, refilled from the global counter)
-            Lane L;
-            L.active = false;
             bool need = mine;
             for (;;) {
                 const unsigned long long needMask = __ballot(need);
@@ -777,97 +795,97 @@ __global__ void __launch_bounds__(TPT_Q_T, TPT_Q_MIN_WAVES_PER_SIMD) tptTraceQue
                 if (lane == 0) atomicSub(&ctl->poolTotal, (unsigned)take);
             }
             if (mine && L.active) {
-                L.hitType = 0; L.j = 0; L.hitId = 0;
+                L.hitType = 0;
                 laneCamera<FOLD_RECURSIVE>(L, fc);
-                qStoreHot(L, st, p);
-                cold[p * 4 + 3] = mk4(0.0f, 0.0f, 0.0f, u2f((uint32_t)L.x | ((uint32_t)L.y << 16))); // colour sum = 0
+                cold[p] = mk4(0.0f, 0.0f, 0.0f, u2f((uint32_t)L.x | ((uint32_t)L.y << 16))); // colour sum = 0
+                ray = true;
+            } else if (mine) {
+                toFree = true; // no pixel left for this path
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            qPushByClass(q, ctl, mine ? (L.active ? Q_INT : Q_FREE) : -1, p, lane); // FREE again: no pixel left for these
         } else if (pick == Q_INT) {
-            // ---- HitWorld for a batch of rays (camera, bounce and shadow rays alike), then classify
-            int cls = -1;
+            // ---- overflow: rays of sparse batches, re-batched
             if (mine) {
-                TPT_STAT(ST_STEP);
-                const f4 v0 = st[0 * TPT_Q_P + p], v1 = st[1 * TPT_Q_P + p];
-                const uint32_t flags = f2u(st[2 * TPT_Q_P + p].x);
-                float t;
-                const int id = hitSpheres<HS_TWO_PHASE>(sv, mk3(v0.x, v0.y, v0.z), mk3(v1.x, v1.y, v1.z), TPT_MIN_T, TPT_MAX_T, t);
-                reinterpret_cast<float*>(&st[1 * TPT_Q_P + p])[3] = t;
-                reinterpret_cast<float*>(&st[2 * TPT_Q_P + p])[1] = u2f((uint32_t)id);
-                const int kind = (int)((flags >> 20) & 1u), depth = (int)((flags >> 16) & 15u);
-                if (kind == KIND_SHADOW)
-                    cls = Q_SHADOW;
-                else if (id < 0 || depth >= TPT_MAX_DEPTH)
-                    cls = Q_END;
-                else {
-                    const int type = (int)f2u(sv.mats[id * 3].w);
-                    cls = type == MAT_LAMBERT ? Q_LAMBERT : type == MAT_METAL ? Q_METAL : type == MAT_DIELECTRIC ? Q_DIEL : Q_END;
-                }
-            }
-            waveRays += (unsigned)n;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            qPushByClass(q, ctl, cls, p, lane);
-        } else {
-            // ---- post-intersection work of one class, at full lane utilisation
-            bool toInt = false, toFree = false;
-            if (mine) {
-                Lane L;
                 int id;
                 float t;
                 qLoadHot(L, id, t, st, p);
-                L.sdir = L.nl = L.lightE = L.albedo = L.matE = mk3(0, 0, 0);
-                L.cosAMax = 0.0f;
-                if (pick == Q_SHADOW) { // light-sampling context of the surface this shadow ray belongs to
-                    const f4 c0 = cold[p * 4 + 0], c1 = cold[p * 4 + 1], c2 = cold[p * 4 + 2];
-                    L.sdir = mk3(c0.x, c0.y, c0.z); L.cosAMax = c0.w;
-                    L.nl = mk3(c1.x, c1.y, c1.z);
-                    L.lightE = mk3(c2.x, c2.y, c2.z);
-                    const f4 m0 = sv.mats[L.hitId * 3], m1 = sv.mats[L.hitId * 3 + 1];
-                    L.albedo = mk3(m0.x, m0.y, m0.z);
-                    if (L.doMatE) L.matE = mk3(m1.x, m1.y, m1.z); // Test.cpp:210, decided when the surface was hit
+                ray = true;
+            }
+        } else if (mine) {
+            // ---- Scatter / sky / fold of one class, at full lane utilisation
+            int id;
+            float t;
+            qLoadHot(L, id, t, st, p);
+            L.sdir = L.nl = L.lightE = L.albedo = L.matE = mk3(0, 0, 0);
+            L.cosAMax = 0.0f;
+            L.hitId = 0;
+            L.j = 0;
+            L.col = mk3(0, 0, 0); // colour of the sample that ends in this step, if one does (0 + c == c)
+            L.x = 0; L.y = 0;
+            const int sampleBefore = L.sample;
+            const bool pixelDone = lanePost<FOLD_RECURSIVE>(L, id, t, sv, fc, stack);
+            if (L.sample != sampleBefore) {
+                // a sample ended: add it to the pixel's running sum (same order of additions as Test.cpp:289)
+                const f4 c3 = cold[p];
+                L.col = mk3(c3.x, c3.y, c3.z) + L.col;
+                L.x = (int)(f2u(c3.w) & 0xffffu);
+                L.y = (int)(f2u(c3.w) >> 16);
+                if (pixelDone) {
+                    storeColour(a, L);
+                    toFree = true;
+                } else {
+                    cold[p] = mk4(L.col.x, L.col.y, L.col.z, c3.w);
+                    laneCamera<FOLD_RECURSIVE>(L, fc); // needCamera is set: next sample of the same pixel
+                    ray = true;
                 }
-                BounceStack stack;
-                stack.base = nullptr;
-                stack.stride = 0;
-                stack.fastLevels = 0;
-                stack.spill = a.stackBuf + ((size_t)blockIdx.x * TPT_Q_P + p);
-                stack.spillStride = a.stackStride;
-                L.col = mk3(0, 0, 0); // colour of the sample that ends in this step, if one does (0 + c == c)
-                L.x = 0; L.y = 0;
-                const int sampleBefore = L.sample;
-                const bool pixelDone = lanePost<FOLD_RECURSIVE>(L, id, t, sv, fc, stack);
-                if (L.sample != sampleBefore) {
-                    // a sample ended: add it to the pixel's running sum (same order of additions as Test.cpp:289)
-                    const f4 c3 = cold[p * 4 + 3];
-                    L.col = mk3(c3.x, c3.y, c3.z) + L.col;
-                    L.x = (int)(f2u(c3.w) & 0xffffu);
-                    L.y = (int)(f2u(c3.w) >> 16);
-                    if (pixelDone) {
-                        storeColour(a, L);
-                        toFree = true;
+            } else {
+                ray = true; // bounce ray, or the first shadow ray of a Lambert hit
+            }
+        }
+
+        // ---- HitWorld for the rays this batch produced.  A Lambert hit runs its whole light loop here: the shadow
+        //      ray is intersected, shaded, and the next one (or the bounce ray) generated, all in registers.
+        int cls = -1;
+        const int nRay = __popcll(__ballot(ray));
+        if (pick == Q_FREE || pick == Q_INT || pick == Q_LAMBERT || nRay >= TPT_Q_FUSE_MIN) {
+            int hitId = -1;
+            float hitT = 0.0f;
+            bool pending = ray;
+            while (__ballot(pending) != 0ull) {
+                if (pending) {
+                    TPT_STAT(ST_STEP);
+                    float t;
+                    const int id = hitSpheres<HS_TWO_PHASE>(sv, L.orig, L.dir, TPT_MIN_T, TPT_MAX_T, t);
+                    myRays++;
+                    if (L.kind == KIND_SHADOW) {
+                        (void)lanePost<FOLD_RECURSIVE>(L, id, t, sv, fc, stack); // Test.cpp:123-132, then next light or bounce
                     } else {
-                        cold[p * 4 + 3] = mk4(L.col.x, L.col.y, L.col.z, c3.w);
-                        laneCamera<FOLD_RECURSIVE>(L, fc); // needCamera is set: next sample of the same pixel
+                        hitId = id;
+                        hitT = t;
+                        pending = false;
                     }
-                } else if (L.kind == KIND_SHADOW) {
-                    // in the light loop (Lambert hit or next light): keep the context for the shadow ray's return
-                    cold[p * 4 + 0] = mk4(L.sdir.x, L.sdir.y, L.sdir.z, L.cosAMax);
-                    if (pick != Q_SHADOW) cold[p * 4 + 1] = mk4(L.nl.x, L.nl.y, L.nl.z, 0.0f); // unchanged between lights
-                    cold[p * 4 + 2] = mk4(L.lightE.x, L.lightE.y, L.lightE.z, 0.0f);
-                }
-                if (!toFree) {
-                    qStoreHot(L, st, p);
-                    toInt = true;
                 }
             }
-            // (the cold state is global memory, but every wave that can pop this path runs on this CU and shares its L1:
-            //  the workgroup-scope release orders the stores before the queue entry becomes visible)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            qPushByClass(q, ctl, toInt ? Q_INT : toFree ? Q_FREE : -1, p, lane);
+            if (ray) {
+                if (hitId < 0 || L.depth >= TPT_MAX_DEPTH)
+                    cls = Q_END;
+                else {
+                    const int type = (int)f2u(sv.mats[hitId * 3].w);
+                    cls = type == MAT_LAMBERT ? Q_LAMBERT : type == MAT_METAL ? Q_METAL : type == MAT_DIELECTRIC ? Q_DIEL : Q_END;
+                }
+                qStoreHot(L, hitId, hitT, st, p);
+            }
+        } else if (ray) {
+            qStoreHot(L, 0, 0.0f, st, p);
+            cls = Q_INT;
         }
+        if (toFree) cls = Q_FREE;
+        // (the cold state is global memory, but every wave that can pop this path runs on this CU and shares its L1:
+        //  the workgroup-scope release orders the stores before the queue entry becomes visible)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        qPushByClass(q, ctl, mine ? cls : -1, p, lane);
     }
 
+    const unsigned waveRays = waveReduceAdd(myRays);
     if (lane == 0) {
         atomicAdd(a.rayCounter, (unsigned long long)waveRays);
         unsigned done = atomicAdd(&a.work[1], 1u) + 1u;

@@ -31,7 +31,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # one hardware queue per in-flight trace kernel; read by the HIP runtime when it initialises (before torch does that)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -96,12 +96,12 @@ def main():
     ap.add_argument("--stripe-rows", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--hit-spheres", type=int, default=0, help="0 two-phase (default) 1 simple")
-    ap.add_argument("--persistent", type=int, default=1, help="1 persistent waves (default) 0 thread-per-pixel 2 lane-sorting 3 path queues")
+    ap.add_argument("--persistent", type=int, default=3, help="3 path queues (default) 1 persistent waves with lane refill 0 thread-per-pixel 2 lane-sorting")
     ap.add_argument("--fold", type=int, default=0, help="0 recursive (reference order, default) 1 forward")
     ap.add_argument("--lds-scene", type=int, default=-1)
     ap.add_argument("--animate", action="store_true",
                     help="kFlagAnimate: spheres 1 and 8 move every frame (time = frame/60 s), the scene is re-uploaded per frame")
-    ap.add_argument("--overlap", type=int, default=8, help="trace kernels of up to this many consecutive frames may be in flight")
+    ap.add_argument("--overlap", type=int, default=16, help="trace kernels of up to this many consecutive frames may be in flight")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))

@@ -44,7 +44,7 @@ def tpt_defaults(tpt):
     tpt.set_samples_per_pixel(4)
     tpt.set_seed_mode(tpt.SEED_PER_PIXEL)
     tpt.set_fold_mode(tpt.FOLD_RECURSIVE)
-    tpt.set_kernel_variant(0, 1, -1)
+    tpt.set_kernel_variant(0, 3, -1)
     tpt.set_row_shard(0, 1, 0)
-    tpt.set_frame_overlap(8)
+    tpt.set_frame_overlap(16)
     return tpt

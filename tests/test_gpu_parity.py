@@ -237,13 +237,15 @@ def test_device_resident_path_with_torch_tile(tpt_defaults, oracle):
     assert rays == ro and tile.cpu().numpy().tobytes() == bo.tobytes()
 
 
-@pytest.mark.parametrize("overlap", [1, 2, 3, 8])
+@pytest.mark.parametrize("overlap", [1, 2, 3, 8, 16])
 def test_frame_overlap_is_bit_identical(tpt_defaults, oracle, overlap):
     """Pipelined frames (trace kernels of consecutive frames in flight at once) == strictly serial frames."""
     import torch
     tpt = tpt_defaults
     tpt.set_frame_overlap(overlap)
-    w, h, frames = 192, 128, 7
+    w, h, frames = 192, 128, (7 if overlap < 8 else 2 * overlap + 3)  # wraps the slot ring at least twice
+    if overlap == 16:
+        w, h = 640, 360  # enough work per frame that many launches really are in flight (adaptive grid size kicks in)
     tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
     r0 = tpt.ray_counter_read()
     tpt.kernel_timing_begin(frames)
@@ -255,19 +257,19 @@ def test_frame_overlap_is_bit_identical(tpt_defaults, oracle, overlap):
     assert n == frames and ms > 0
     ro, bo, _ = oracle_frames(oracle, w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
     assert rays == ro and tile.cpu().numpy().tobytes() == bo.tobytes()
-    tpt.set_frame_overlap(8)
+    tpt.set_frame_overlap(16)
 
 
-@pytest.mark.parametrize("overlap", [1, 8])
+@pytest.mark.parametrize("overlap", [1, 16])
 def test_animated_scene_async_upload_ring(tpt_defaults, oracle, overlap):
     """kFlagAnimate on the asynchronous path: every frame re-packs the scene at its own time (Test.cpp:304-308) and
-    uploads it into the next scene set while up to 8 earlier frames are still tracing with the older sets.  40 frames
-    wrap the 16-set ring twice; no host synchronisation until the end."""
+    uploads it into the next scene set while up to 16 earlier frames are still tracing with the older sets.  80 frames
+    wrap the 32-set ring twice; no host synchronisation until the end."""
     import torch
     tpt = tpt_defaults
     tpt.set_scene(None)
     tpt.set_frame_overlap(overlap)
-    w, h, frames = 96, 64, 40
+    w, h, frames = 96, 64, 80
     flags = FLAG_PROGRESSIVE | FLAG_ANIMATE
     tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
     r0 = tpt.ray_counter_read()
@@ -286,7 +288,7 @@ def test_animated_scene_async_upload_ring(tpt_defaults, oracle, overlap):
         ro += r
     assert rays == ro and tile.cpu().numpy().tobytes() == bo.tobytes()
     tpt.set_scene(None)
-    tpt.set_frame_overlap(8)
+    tpt.set_frame_overlap(16)
 
 
 @pytest.mark.parametrize("variant,fold", [(2, FOLD_RECURSIVE), (2, FOLD_FORWARD), (3, FOLD_RECURSIVE)],
@@ -319,6 +321,7 @@ def test_cost_ordered_chunks_table_is_a_permutation_and_image_unchanged(tpt_defa
     is rebuilt while other frames are in flight and must stay a permutation (every tile rendered exactly once)."""
     import torch
     tpt = tpt_defaults
+    tpt.set_kernel_variant(0, 1, -1)  # the lane-refill kernel (the fallback of the path-queue kernel) owns this mechanism
     w, h, frames = 640, 360, 20
     tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
     r0 = tpt.ray_counter_read()
@@ -329,7 +332,9 @@ def test_cost_ordered_chunks_table_is_a_permutation_and_image_unchanged(tpt_defa
             cost, order = tpt.debug_chunk_order()
             assert len(order) == (w // 8) * (h // 8)
             assert np.array_equal(np.sort(order), np.arange(len(order), dtype=np.uint32))
-            assert cost[order[0]] >= cost[order[-1]] and cost.max() > 0
+            assert cost.max() > 0
+            if f == 19:  # sorted from statistics that certainly include frames 0..9 (the call at f == 9 synchronised)
+                assert cost[order[0]] > cost[order[-1]]
     rays = tpt.ray_counter_read() - r0
     ro, bo, _ = oracle_frames(oracle, w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
     assert rays == ro and tile.cpu().numpy().tobytes() == bo.tobytes()
@@ -355,6 +360,6 @@ def test_config5_stress_scene_full_size_properties(tpt_defaults, oracle):
     band = np.zeros((h, w, 4), np.float32)
     oracle.render(s, m, cam, w, h, spp, 0, seed_mode=SEED_PER_PIXEL, backbuffer=band, y0=300, y1=303)
     assert b1[300:303].tobytes() == band[300:303].tobytes()
-    tpt.set_kernel_variant(0, 3, -1)  # path-queue kernel on the same frame
+    tpt.set_kernel_variant(0, 1, -1)  # lane-refill kernel on the same frame
     r3, b3, _ = gpu_frames(tpt, w, h, 1)
     assert r3 == r1 and b3.tobytes() == b1.tobytes()

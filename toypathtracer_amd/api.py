@@ -58,7 +58,7 @@ def load_library():
         return _lib
     # one hardware queue per in-flight trace kernel (the runtime's default of 4 serialises deeper frame pipelining);
     # must be in the environment before the HIP runtime initialises
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
     try:  # torch ships its own HIP runtime: load it first so both sides share one libamdhip64 in the process
         import torch  # noqa: F401
     except ImportError:

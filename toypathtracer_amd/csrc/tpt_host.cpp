@@ -64,10 +64,11 @@ struct Context {
     int spp = 4;                     // DO_SAMPLES_PER_PIXEL, Config.h:22
     int seedMode = SEED_PER_PIXEL;
     int foldMode = FOLD_RECURSIVE;
-    int hs = HS_TWO_PHASE, persist = 1, ldsScene = -1;
+    int hs = HS_TWO_PHASE, persist = 3, ldsScene = -1; // persist 3 = path queues (falls back to 1 where they do not apply)
     int stripeRows = 0, numParts = 1, part = 0;
     int maxBlocksPerCU = 0, chunkOverride = 0; // tuning knobs (env TPT_MAX_BLOCKS_PER_CU, TPT_CHUNK)
-    int gridDiv = 1;                            // env TPT_GRID_DIV: launch resident/gridDiv workgroups per frame
+    int gridDiv = 0;                            // env TPT_GRID_DIV: launch resident/gridDiv workgroups per frame; 0 = adaptive
+    unsigned long long oldestPending = 0;       // adaptive grid: oldest frame whose trace kernel may still be running
     int ldsStackLevels = 6;                     // recursive fold: bounce-stack levels kept in LDS (env TPT_LDS_STACK_LEVELS)
 
     unsigned* dWork = nullptr;
@@ -92,7 +93,7 @@ struct Context {
 
     // frame pipelining: trace kernels of consecutive frames run on alternating internal streams and write
     // their own per-frame colour buffer; the (ordered) resolve kernels run on g.stream
-    int overlap = 8;
+    int overlap = 16;
     hipStream_t traceStream[kMaxOverlap] = {};
     hipEvent_t evTrace[kMaxOverlap] = {}, evResolve[kMaxOverlap] = {};
     bool resolveRecorded[kMaxOverlap] = {};
@@ -243,6 +244,23 @@ int enqueueSceneUpload(hipStream_t ts)
     return 0;
 }
 
+// Number of earlier frames whose trace kernel has not finished yet (their events complete in order: amortised one
+// hipEventQuery per frame).
+int framesInFlight(int nOverlap)
+{
+    if (nOverlap <= 1) return 0;
+    if (g.oldestPending + (unsigned long long)nOverlap < g.frameSeq) g.oldestPending = g.frameSeq - (unsigned long long)nOverlap;
+    // (called after frameSeq was advanced for the frame being enqueued: that frame itself does not count)
+    const unsigned long long cur = g.frameSeq - 1;
+    while (g.oldestPending < cur) {
+        const int s = (int)(g.oldestPending % (unsigned long long)nOverlap);
+        if (hipEventQuery(g.evTrace[s]) != hipSuccess) break;
+        g.oldestPending++;
+    }
+    (void)hipGetLastError(); // hipErrorNotReady is not an error
+    return (int)(cur - g.oldestPending);
+}
+
 int requireInit()
 {
     if (!g.inited) return fail("tpt: not initialised (call tptInitialize / InitializeTest first)");
@@ -262,7 +280,7 @@ int tptInitialize(void)
     // Frame pipelining wants one hardware queue per in-flight trace kernel; the ROCm runtime exposes 4 by default and
     // maps further streams onto them round-robin (3 streams then run slower than 2).  Only effective if the HIP
     // runtime has not been initialised yet by the host application; harmless otherwise.
-    setenv("GPU_MAX_HW_QUEUES", "16", 0);
+    setenv("GPU_MAX_HW_QUEUES", "24", 0);
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
@@ -291,13 +309,14 @@ int tptInitialize(void)
         g.resolveRecorded[k] = false;
     }
     g.frameSeq = 0;
+    g.oldestPending = 0;
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dRaysOwn), 64));
     HIPCHK(hipMemset(g.dRaysOwn, 0, 64));
     g.dRays = g.dRaysOwn;
     g.lastTotal = 0;
     if (g.spheres.empty()) defaultScene(g.spheres, g.mats);
     if (const char* e1 = getenv("TPT_MAX_BLOCKS_PER_CU")) g.maxBlocksPerCU = atoi(e1);
-    if (const char* e5 = getenv("TPT_GRID_DIV")) g.gridDiv = atoi(e5) > 0 ? atoi(e5) : 1;
+    if (const char* e5 = getenv("TPT_GRID_DIV")) g.gridDiv = atoi(e5) > 0 ? atoi(e5) : 0;
     if (const char* e2 = getenv("TPT_CHUNK")) g.chunkOverride = atoi(e2);
     if (const char* e4 = getenv("TPT_COST_ORDER")) g.costOrder = atoi(e4);
     if (const char* e3 = getenv("TPT_LDS_STACK_LEVELS")) {
@@ -419,6 +438,7 @@ int tptSetFrameOverlap(int frames)
     }
     g.overlap = frames;
     g.frameSeq = 0;
+    g.oldestPending = 0;
     for (int k = 0; k < Context::kMaxOverlap; ++k) g.resolveRecorded[k] = false;
     return 0;
 }
@@ -577,7 +597,16 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
         a.chunkSize = chunk;
         a.numChunks = (a.numItems + chunk - 1) / chunk;
         blocks = (a.numChunks + wavesPerBlock - 1) / wavesPerBlock;
-        if (blocks > resident / g.gridDiv) blocks = resident / g.gridDiv;
+        // Frames in flight share the machine: with k trace kernels running side by side each one gets ~2/k of the
+        // resident workgroups (its pools then stay in steady state 8x longer before they drain, and the launches
+        // behind it fill the gaps).  A caller that synchronises every frame has nothing in flight and gets the full grid.
+        int div = g.gridDiv;
+        if (div <= 0) {
+            div = (framesInFlight(nOverlap) + 1) / 2;
+            if (div > nOverlap / 2) div = nOverlap / 2;
+            if (div < 1) div = 1;
+        }
+        if (blocks > resident / div) blocks = resident / div;
         if (blocks < 1) blocks = 1;
         a.totalWaves = (unsigned)(blocks * wavesPerBlock);
     } else {
@@ -664,11 +693,12 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
         if (rc) return rc;
     }
     if (useOrder && g.orderSeq > 0) {
-        // re-sort from the statistics gathered so far (a few frames suffice for a static scene; refresh every 32nd).
+        // re-sort from the statistics gathered so far (every frame until the first frames' statistics have certainly
+        // arrived -- the sort runs beside up to nOverlap unfinished frames -- then every 32nd).
         // The table is one of kOrderTables rotating buffers (> frames in flight): a trace kernel still in flight keeps reading the
         // one it was given.
         unsigned* table = g.dChunkOrder[g.orderSeq % Context::kOrderTables];
-        if (g.orderSeq <= 6 || (g.orderSeq & 31ull) == 0ull) {
+        if (g.orderSeq <= (unsigned long long)(2 * nOverlap + 2) || (g.orderSeq & 31ull) == 0ull) {
             HIPCHK(tptLaunchChunkOrder(g.dChunkCost, g.dChunkSnap[slot], table, a.numChunks, ts));
         } else {
             table = g.dChunkOrder[g.lastOrderTable];

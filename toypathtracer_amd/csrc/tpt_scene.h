@@ -110,7 +110,7 @@ inline void defaultScene(std::vector<SpherePOD>& S, std::vector<MaterialPOD>& M)
 
 // ---- packed arrays the kernels read
 struct PackedScene {
-    std::vector<float> pairs; // [nPairs][8]
+    std::vector<float> pairs; // [nPairs][8]: {cx0,cx1, cy0,cy1, cz0,cz1, -r0^2 (1+2^-16), -r1^2 (1+2^-16)}
     std::vector<f4> sph4;     // [nPairs*2]
     std::vector<float> invR;  // [nPairs*2]
     std::vector<f4> mats;     // [n][3]
@@ -135,7 +135,7 @@ inline void packScene(std::vector<SpherePOD>& S, const std::vector<MaterialPOD>&
     P.emissive.clear();
     const float negInf = u2f(0xff800000u);
     for (int i = 0; i < nPad; ++i) {
-        float cx = 0, cy = 0, cz = 0, sq = negInf; // padding sphere: discriminant = -inf, never a candidate
+        float cx = 0, cy = 0, cz = 0, sq = negInf; // padding sphere: filter value = -inf, never a candidate
         if (i < n) {
             S[i].invRadius = 1.0f / S[i].radius; // Sphere::UpdateDerivedData, Maths.h:359
             cx = S[i].cx; cy = S[i].cy; cz = S[i].cz;
@@ -165,7 +165,8 @@ inline void packScene(std::vector<SpherePOD>& S, const std::vector<MaterialPOD>&
         rec[0 + (i & 1)] = cx;
         rec[2 + (i & 1)] = cy;
         rec[4 + (i & 1)] = cz;
-        rec[6 + (i & 1)] = sq;
+        // phase 1's conservative filter (tpt_trace.h, phase1Pair) wants -r^2 (1 + 2^-16); padding: +inf
+        rec[6 + (i & 1)] = (float)(-(double)sq * (1.0 + 1.0 / 65536.0));
     }
     P.nLights = (int)P.emissive.size();
 }

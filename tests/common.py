@@ -43,3 +43,24 @@ def rel_err(a, b):
     a = a[..., :3].astype(np.float64)
     b = b[..., :3].astype(np.float64)
     return np.abs(a - b) / np.maximum(np.abs(b), 1e-30)
+
+
+def grazing_rays(spheres, n, seed=11):
+    """Unit-direction rays that pass within a hair of a sphere's silhouette (|offset| from 1e-8 to 1e-3 radii, both
+    signs): the discriminant of the targeted sphere is within rounding of zero -- the cases where a filter that is not
+    conservative would drop a sphere the exact arithmetic accepts."""
+    rng = np.random.default_rng(seed)
+    cnt = len(spheres)
+    idx = rng.integers(0, cnt, n)
+    c = np.stack([spheres["cx"][idx], spheres["cy"][idx], spheres["cz"][idx]], 1).astype(np.float64)
+    r = spheres["radius"][idx].astype(np.float64)
+    nrm = rng.normal(size=(n, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    tan = np.cross(nrm, rng.normal(size=(n, 3)))
+    tan /= np.linalg.norm(tan, axis=1, keepdims=True)
+    eps = 10.0 ** rng.uniform(-8, -3, n) * rng.choice([-1.0, 1.0], n)
+    p = c + nrm * (r * (1.0 + eps))[:, None]          # a point just above / below the surface
+    o = p - tan * rng.uniform(0.3, 6.0, n)[:, None]   # walk back along the tangent
+    d = tan.astype(np.float32)
+    d = (d / np.linalg.norm(d.astype(np.float64), axis=1, keepdims=True)).astype(np.float32)
+    return np.concatenate([o.astype(np.float32), d], 1).astype(np.float32)

@@ -95,4 +95,22 @@ float emu_sinf(float x) { return tsinf(x); }
 float emu_cosf(float x) { return tcosf(x); }
 float emu_pow5f(float x) { return tpow5f(x); }
 
+// HitSpheres alone: n rays [n][6] = origin, unit direction; hs 0 = two-phase (conservative FMA filter + exact test),
+// 1 = simple loop (the reference's arithmetic for every sphere).  Returns the number of phase-1 candidates is not
+// exposed; ids/ts must be identical between the two variants.
+void emu_hit_spheres(const void* spheres, const void* mats, int count, int hs, const float* rays, int n, int* outId, float* outT)
+{
+    std::vector<SpherePOD> S((const SpherePOD*)spheres, (const SpherePOD*)spheres + count);
+    std::vector<MaterialPOD> M((const MaterialPOD*)mats, (const MaterialPOD*)mats + count);
+    PackedScene P;
+    packScene(S, M, P);
+    SceneView sv = viewOf(P);
+    for (int i = 0; i < n; ++i) {
+        f3 o = mk3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]), d = mk3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
+        float t;
+        outId[i] = hs ? hitSpheres<HS_SIMPLE>(sv, o, d, TPT_MIN_T, TPT_MAX_T, t) : hitSpheres<HS_TWO_PHASE>(sv, o, d, TPT_MIN_T, TPT_MAX_T, t);
+        outT[i] = t;
+    }
+}
+
 } // extern "C"

@@ -160,6 +160,28 @@ def test_hit_spheres_kernel_vs_oracle(tpt_defaults, oracle):
         assert np.array_equal(ts.view(np.uint32), want_t.view(np.uint32))
 
 
+def test_two_phase_filter_is_conservative_on_grazing_rays_gpu(tpt_defaults):
+    """As tests/test_lane_logic.py's grazing-ray test, on the device: the FMA filter of phase 1 (v_pk_fma_f32) must never
+    drop a sphere the exact loop hits.  2M rays through the built-in scene, 200k through the 4096-sphere scene."""
+    from common import grazing_rays
+    from toypathtracer_amd.scenes import stress_scene
+    tpt = tpt_defaults
+    for scene, n in ((None, 2000000), (stress_scene(4096, 64), 200000)):
+        if scene is None:
+            tpt.set_scene(None)
+            s = tpt.GetSceneDesc()[0]
+        else:
+            tpt.set_scene(*scene)
+            s = scene[0]
+        tpt.UpdateTest(0.0, 0, 64, 64, 2)
+        rays = grazing_rays(s, n, seed=23)
+        id0, t0 = tpt.test_hit_spheres(rays, 0)
+        id1, t1 = tpt.test_hit_spheres(rays, 1)
+        assert np.array_equal(id0, id1) and np.array_equal(t0.view(np.uint32), t1.view(np.uint32))
+        assert (id1 >= 0).mean() > 0.3
+    tpt.set_scene(None)
+
+
 # ---- 3. BASELINE.json's full sizes
 def test_config2_1280x720_4spp_full_parity(tpt_defaults, oracle):
     """configs[1]: the headline workload; the oracle finishes it in seconds, so compare everything."""

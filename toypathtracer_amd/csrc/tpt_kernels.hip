@@ -638,8 +638,16 @@ __device__ __forceinline__ void qLoadHot(Lane& L, int& id, float& t, const f4* s
 #ifndef TPT_Q_MIN_WAVES_PER_SIMD
 #define TPT_Q_MIN_WAVES_PER_SIMD 4
 #endif
+// 4 waves/SIMD x 120 VGPRs leaves 32 registers per SIMD lane free: the resolve kernel's waves (10 VGPRs) can then
+// start beside a machine full of persistent trace workgroups instead of waiting for one of them to retire (measured:
+// resolve took 40-300 us instead of 4-10, and the ordered resolve chain is what bounds small / sharded frames).
+// (On gfx90a+ LLVM doubles the requested number -- it assumes an equal AGPR half of the unified file -- so 60 means 120.)
+#ifndef TPT_Q_MAX_VGPR
+#define TPT_Q_MAX_VGPR 60
+#endif
 template <bool LDS_SCENE>
-__global__ void __launch_bounds__(TPT_Q_T, TPT_Q_MIN_WAVES_PER_SIMD) tptTraceQueueKernel(const KernelArgs a)
+__global__ void __launch_bounds__(TPT_Q_T, TPT_Q_MIN_WAVES_PER_SIMD) __attribute__((amdgpu_num_vgpr(TPT_Q_MAX_VGPR)))
+tptTraceQueueKernel(const KernelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int nPad = a.scene.nPairs * 2;

@@ -112,6 +112,13 @@ struct Context {
 
 Context g;
 
+// Events that only order work between streams of THIS device (trace -> resolve -> next use of a colour buffer, scene
+// upload -> trace) or time it: without the system-scope fence a default event carries -- an L2 write-back + invalidate
+// at every record, several times per frame, under the feet of the trace kernels running beside it.  Visibility to the
+// host / other devices is established where the caller synchronises (stream sync, its own events), as always.
+const unsigned kOrderingEvent = hipEventDisableTiming | hipEventDisableSystemFence;
+const unsigned kTimingEvent = hipEventDisableSystemFence;
+
 int fail(const std::string& what)
 {
     g.err = what;
@@ -171,7 +178,7 @@ int stageScene()
                  bMats = P.mats.size() * sizeof(f4), bLights = P.lights.size() * sizeof(f4);
     const size_t offSph4 = align256(bPairs), offInvR = offSph4 + align256(bSph4), offMats = offInvR + align256(bInvR),
                  offLights = offMats + align256(bMats), total = offLights + align256(bLights + 32);
-    if (!S.evUploaded) HIPCHK(hipEventCreateWithFlags(&S.evUploaded, hipEventDisableTiming));
+    if (!S.evUploaded) HIPCHK(hipEventCreateWithFlags(&S.evUploaded, kOrderingEvent));
     // the previous copy out of this staging blob (kSceneSets uploads ago) must have left the host before we overwrite it:
     // only ever waits when the host has run more than 16 animated frames ahead of the GPU
     if (S.copyEnqueued && !S.copyDone) HIPCHK(hipEventSynchronize(S.evUploaded));
@@ -304,8 +311,8 @@ int tptInitialize(void)
     HIPCHK(hipMemset(g.dWork, 0, 64 * Context::kMaxOverlap));
     for (int k = 0; k < Context::kMaxOverlap; ++k) {
         HIPCHK(hipStreamCreateWithFlags(&g.traceStream[k], hipStreamNonBlocking));
-        HIPCHK(hipEventCreateWithFlags(&g.evTrace[k], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&g.evResolve[k], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&g.evTrace[k], kOrderingEvent));
+        HIPCHK(hipEventCreateWithFlags(&g.evResolve[k], kOrderingEvent));
         g.resolveRecorded[k] = false;
     }
     g.frameSeq = 0;
@@ -400,8 +407,8 @@ int tptKernelTimingBegin(int maxLaunches)
     if (maxLaunches < 1) maxLaunches = 1;
     while ((int)g.ktStart.size() < maxLaunches) {
         hipEvent_t a = nullptr, b = nullptr;
-        HIPCHK(hipEventCreate(&a));
-        HIPCHK(hipEventCreate(&b));
+        HIPCHK(hipEventCreateWithFlags(&a, kTimingEvent));
+        HIPCHK(hipEventCreateWithFlags(&b, kTimingEvent));
         g.ktStart.push_back(a);
         g.ktStop.push_back(b);
     }

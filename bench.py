@@ -31,7 +31,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # one hardware queue per in-flight trace kernel; read by the HIP runtime when it initialises (before torch does that)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -101,7 +101,10 @@ def main():
     ap.add_argument("--lds-scene", type=int, default=-1)
     ap.add_argument("--animate", action="store_true",
                     help="kFlagAnimate: spheres 1 and 8 move every frame (time = frame/60 s), the scene is re-uploaded per frame")
-    ap.add_argument("--overlap", type=int, default=16, help="trace kernels of up to this many consecutive frames may be in flight")
+    ap.add_argument("--overlap", type=int, default=0,
+                    help="trace kernels of up to this many consecutive frames may be in flight (0 = auto: 16, or 8 when the frame is "
+                         "sharded over more than 2 ranks -- with small tiles the per-packet latency of many active queues costs more "
+                         "than the extra overlap buys)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -131,6 +134,8 @@ def main():
     api.set_samples_per_pixel(spp)
     api.set_fold_mode(args.fold)
     api.set_kernel_variant(args.hit_spheres, args.persistent, args.lds_scene)
+    if args.overlap <= 0:
+        args.overlap = 16 if world <= 2 else 8
     api.set_frame_overlap(args.overlap)
     n_spheres = 46
     if scene == "stress":
@@ -150,9 +155,13 @@ def main():
 
     def step(frame):
         t = frame / 60.0 if args.animate else 0.0
+        mirror = sf.mirror_pointers()  # sharded: the resolve kernel also fills the snapshot the gather sends
+        if mirror:
+            sf.begin_frame()
+            api.set_tile_mirror(*mirror)
         api.UpdateTest(t, frame, width, height, flags)
         api.draw_device(t, frame, width, height, tile_ptr, flags)
-        sf.exchange()
+        sf.exchange(snapshot_done=bool(mirror))
 
     def fence():
         sf.render_stream.synchronize()

@@ -108,6 +108,12 @@ int tptRayCounterRead(int64_t* outTotalRays);
  * memory (e.g. a torch int64 tensor) that the kernels atomically add to; NULL -> the internal counter.
  * Lets the multi-GPU host sum-reduce the counters with RCCL without a host round trip. */
 int tptSetRayCounter(void* deviceU64);
+/* Sharded hosts: from the next tptDrawDevice on, the progressive blend also writes every blended pixel of the tile to
+ * `deviceMirror` (same size and layout as the tile) and the current ray-counter value to the 8 bytes at
+ * `deviceCounterOut` (may be NULL) -- the snapshot handed to the collective while later frames keep accumulating into
+ * the tile -- in the SAME kernel, so the frame's dependency chain stays one kernel long.  NULL turns it off.  The
+ * pointers are read at enqueue time; call again to rotate buffers. */
+int tptSetTileMirror(float* deviceMirror, void* deviceCounterOut);
 int tptSynchronize(void);
 /* hipEvent bracket on the context's stream, for kernel-only timing (as the reference times its
  * Dispatch with timestamp queries, TestWin.cpp:299-302). */

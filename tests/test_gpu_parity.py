@@ -259,6 +259,37 @@ def test_device_resident_path_with_torch_tile(tpt_defaults, oracle):
     assert rays == ro and tile.cpu().numpy().tobytes() == bo.tobytes()
 
 
+def test_tile_mirror_snapshot(tpt_defaults, oracle):
+    """tptSetTileMirror: the resolve kernel also writes the blended tile (and the ray counter) to a second buffer -- the
+    snapshot a sharded host hands to its gather.  Rotating mirrors every frame, as bench.py does."""
+    import torch
+    tpt = tpt_defaults
+    w, h, frames = 160, 96, 6
+    tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    mirrors = [torch.full((h + 1, w, 4), -1.0, dtype=torch.float32, device="cuda") for _ in range(3)]
+    r0 = tpt.ray_counter_read()
+    for f in range(frames):
+        mbuf = mirrors[f % 3]
+        tpt.set_tile_mirror(mbuf.data_ptr(), mbuf[h].data_ptr())
+        tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+        tpt.draw_device(0.0, f, w, h, tile.data_ptr(), FLAG_PROGRESSIVE)
+    tpt.set_tile_mirror(None)
+    rays = tpt.ray_counter_read() - r0
+    ro, bo, _ = oracle_frames(oracle, w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
+    assert rays == ro and tile.cpu().numpy().tobytes() == bo.tobytes()
+    last = mirrors[(frames - 1) % 3]
+    assert last[:h].cpu().numpy().tobytes() == bo.tobytes()                      # the newest mirror is the final tile
+    _, b4, _ = oracle_frames(oracle, w, h, 4, frames - 1, seed_mode=SEED_PER_PIXEL)
+    assert mirrors[(frames - 2) % 3][:h].cpu().numpy().tobytes() == b4.tobytes()  # the one before: the tile one frame earlier
+    counter = int(last[h, 0, :2].view(torch.int64).item())
+    assert r0 < counter <= r0 + rays  # a snapshot of the (monotonic) counter, taken no later than the last frame's end
+    tpt.UpdateTest(0.0, frames, w, h, FLAG_PROGRESSIVE)  # mirror off again: nothing but the tile is written
+    keep = last.clone()
+    tpt.draw_device(0.0, frames, w, h, tile.data_ptr(), FLAG_PROGRESSIVE)
+    tpt.synchronize()
+    assert torch.equal(keep, last)
+
+
 @pytest.mark.parametrize("overlap", [1, 2, 3, 8, 16])
 def test_frame_overlap_is_bit_identical(tpt_defaults, oracle, overlap):
     """Pipelined frames (trace kernels of consecutive frames in flight at once) == strictly serial frames."""

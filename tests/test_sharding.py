@@ -35,7 +35,7 @@ def test_product_row_mapping_matches_python():
     lib.tptSetRowShard(0, 1, 0)
 
 
-def _worker(rank, world, port, w, h, stripe, q):
+def _worker(rank, world, port, w, h, stripe, q, mirror=False):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from oracle_lib import Oracle, SEED_PER_PIXEL
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -46,7 +46,13 @@ def _worker(rank, world, port, w, h, stripe, q):
     cam = o.default_camera(w, h)
     sf = sharding.ShardedFrame(w, h, stripe, rank, world, torch.device("cpu"), dist)
     total = None
-    for frame in range(2):
+    import ctypes
+    for frame in range(6 if mirror else 2):
+        if mirror:
+            # what bench.py does on the GPU: ask for the snapshot addresses BEFORE the draw, let the library's resolve
+            # kernel fill them (tptSetTileMirror), then exchange(snapshot_done=True)
+            sf.begin_frame()
+            mirror_ptr, counter_ptr = sf.mirror_pointers()
         # render this rank's rows (progressive accumulation stays in the rank's own tile)
         full = np.zeros((h, w, 4), np.float32)
         rows = sharding.local_to_global_rows(h, stripe, world, rank)
@@ -57,15 +63,22 @@ def _worker(rank, world, port, w, h, stripe, q):
             rays += r
         sf.tile[: len(rows)] = torch.from_numpy(full[rows])
         sf.ray_counter += rays          # the kernels' atomic adds (tptSetRayCounter)
-        sf.exchange()
+        if mirror:
+            # stand-in for tptResolveMirrorKernel: raw writes through the two addresses
+            ctypes.memmove(mirror_ptr, sf.tile.data_ptr(), sf.tile.numel() * 4)
+            ctypes.memmove(counter_ptr, sf.ray_counter.data_ptr(), 8)
+            sf.exchange(snapshot_done=True)
+        else:
+            sf.exchange()
     img, total = sf.finish()
     if rank == 0:
         q.put((img.numpy().copy(), total))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,h,stripe", [(2, 42, 4), (3, 50, 8)], ids=["2ranks", "3ranks_uneven"])
-def test_gather_reassembles_the_single_process_image(oracle, world, h, stripe):
+@pytest.mark.parametrize("world,h,stripe,mirror", [(2, 42, 4, False), (3, 50, 8, False), (2, 42, 4, True)],
+                         ids=["2ranks", "3ranks_uneven", "2ranks_mirrored_snapshot"])
+def test_gather_reassembles_the_single_process_image(oracle, world, h, stripe, mirror):
     from oracle_lib import SEED_PER_PIXEL
     w = 64
     with socket.socket() as s:
@@ -73,7 +86,7 @@ def test_gather_reassembles_the_single_process_image(oracle, world, h, stripe):
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, w, h, stripe, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, w, h, stripe, q, mirror)) for r in range(world)]
     for p in procs:
         p.start()
     img, total = q.get(timeout=120)
@@ -84,7 +97,7 @@ def test_gather_reassembles_the_single_process_image(oracle, world, h, stripe):
     cam = oracle.default_camera(w, h)
     bb = np.zeros((h, w, 4), np.float32)
     rays_sum = 0
-    for frame in range(2):
+    for frame in range(6 if mirror else 2):  # 6 frames: the ring of 4 send buffers wraps
         r, _ = oracle.render(sc, m, cam, w, h, 2, frame, seed_mode=SEED_PER_PIXEL, backbuffer=bb)
         rays_sum += r
     assert total == rays_sum

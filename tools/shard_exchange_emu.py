@@ -1,0 +1,50 @@
+"""One-GPU emulation of rank 0 of an N-way sharded run INCLUDING the per-frame exchange plumbing (snapshot, events,
+assemble) with a stand-in for the collective (rank 0's own slice is copied; the other ranks' slices stay zero):
+what the render + exchange pipeline costs per frame apart from RCCL itself."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from toypathtracer_amd import api
+from toypathtracer_amd.sharding import ShardedFrame
+
+
+class FakeDist:
+    def gather(self, tensor, gather_list=None, dst=0):
+        if gather_list is not None:
+            gather_list[0].copy_(tensor, non_blocking=True)
+
+
+api.InitializeTest()
+if os.environ.get("TPT_EMU_OV"):
+    api.set_frame_overlap(int(os.environ["TPT_EMU_OV"]))
+w, h, frames, warm = 1280, 720, int(os.environ.get("TPT_EMU_FRAMES", "400")), 60
+dev = torch.device("cuda", 0)
+for n in [int(v) for v in os.environ.get("TPT_EMU_N", "1,2,4,8").split(",")]:
+    api.set_row_shard(8, n, 0)
+    sf = ShardedFrame(w, h, 8, 0, n, dev, FakeDist() if n > 1 else None)
+    api.set_stream(sf.render_stream.cuda_stream)
+    api.set_ray_counter(sf.ray_counter.data_ptr())
+    MIRROR = os.environ.get("TPT_EMU_MIRROR", "1") == "1"
+    def step(f):
+        mp = sf.mirror_pointers() if MIRROR else None
+        if mp:
+            sf.begin_frame()
+            api.set_tile_mirror(*mp)
+        api.UpdateTest(0.0, f, w, h, 2)
+        api.draw_device(0.0, f, w, h, sf.tile.data_ptr(), 2)
+        sf.exchange(snapshot_done=bool(mp))
+    for f in range(warm):
+        step(f)
+    sf.render_stream.synchronize(); torch.cuda.synchronize()
+    r0 = int(sf.ray_counter.item())
+    t0 = time.perf_counter()
+    for f in range(warm, warm + frames):
+        step(f)
+    sf.render_stream.synchronize(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    rays = int(sf.ray_counter.item()) - r0
+    print("N=%d: %.3f ms/frame  aggregate %.1f Gray/s (render + exchange plumbing, no RCCL)" % (n, dt / frames * 1e3, rays / dt / 1e9 * n), flush=True)
+    api.set_stream(None); api.set_ray_counter(None); api.set_tile_mirror(None)
+api.set_row_shard(0, 1, 0)
+api.ShutdownTest()

@@ -37,7 +37,7 @@ C_ABI_SYMBOLS = [
     "tptSetSamplesPerPixel", "tptSetSeedMode", "tptSetFoldMode", "tptSetScene", "tptSetCamera", "tptSetStream",
     "tptSetRowShard", "tptLocalRowCount", "tptLocalRowToGlobal", "tptDrawDevice", "tptRayCounterRead", "tptSetRayCounter", "tptSetFrameOverlap", "tptDisplayRGBA8", "tptKernelTimingBegin", "tptKernelTimingEnd",
     "tptSynchronize", "tptTimerBegin", "tptTimerEnd", "tptSetKernelVariant", "tptTestMath", "tptTestHitSpheres",
-    "tptGetLaunchInfo", "tptGetLastError", "tptGetDeviceName", "tptDebugStats", "tptDebugChunkOrder",
+    "tptGetLaunchInfo", "tptSetTileMirror", "tptGetLastError", "tptGetDeviceName", "tptDebugStats", "tptDebugChunkOrder",
 ]
 # the reference's own C++ symbols (nm of the compiled Test.cpp), exported for link-level drop-in
 CXX_ABI_SYMBOLS = [
@@ -58,7 +58,7 @@ def load_library():
         return _lib
     # one hardware queue per in-flight trace kernel (the runtime's default of 4 serialises deeper frame pipelining);
     # must be in the environment before the HIP runtime initialises
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
     try:  # torch ships its own HIP runtime: load it first so both sides share one libamdhip64 in the process
         import torch  # noqa: F401
     except ImportError:
@@ -76,7 +76,7 @@ def load_library():
         "tptSetSamplesPerPixel": [i], "tptSetSeedMode": [i], "tptSetFoldMode": [i], "tptSetScene": [p, p, i],
         "tptSetCamera": [p, p, f, f, f], "tptSetStream": [p], "tptSetRowShard": [i, i, i], "tptLocalRowCount": [i],
         "tptLocalRowToGlobal": [i], "tptDrawDevice": [f, i, i, i, p, u], "tptRayCounterRead": [C.POINTER(C.c_int64)],
-        "tptSetRayCounter": [p], "tptSetFrameOverlap": [i], "tptDisplayRGBA8": [p, i, i, p], "tptKernelTimingBegin": [i],
+        "tptSetRayCounter": [p], "tptSetTileMirror": [p, p], "tptSetFrameOverlap": [i], "tptDisplayRGBA8": [p, i, i, p], "tptKernelTimingBegin": [i],
         "tptKernelTimingEnd": [C.POINTER(f), C.POINTER(i)],
         "tptSynchronize": [], "tptTimerBegin": [], "tptTimerEnd": [C.POINTER(f)], "tptSetKernelVariant": [i, i, i],
         "tptDebugStats": [p, i], "tptDebugChunkOrder": [p, p, i], "tptTestMath": [i, p, p, p, i], "tptTestHitSpheres": [i, p, p, p, i], "tptGetLaunchInfo": [C.POINTER(i)] * 4,
@@ -222,6 +222,13 @@ def write_tga(path, rgba):
 def set_ray_counter(device_ptr):
     """device_ptr: address of one zeroed int64 in device memory (tensor.data_ptr()), or None/0 for the internal one."""
     _chk(load_library().tptSetRayCounter(C.c_void_p(device_ptr) if device_ptr else None), "tptSetRayCounter")
+
+
+def set_tile_mirror(mirror_ptr, counter_out_ptr=None):
+    """The resolve kernel also writes the blended tile to `mirror_ptr` and the ray counter to `counter_out_ptr` (device
+    addresses; None/0 turns it off)."""
+    _chk(load_library().tptSetTileMirror(C.c_void_p(mirror_ptr) if mirror_ptr else None,
+                                         C.c_void_p(counter_out_ptr) if counter_out_ptr else None), "tptSetTileMirror")
 
 
 def synchronize():

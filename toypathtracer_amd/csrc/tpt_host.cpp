@@ -67,10 +67,13 @@ struct Context {
     int hs = HS_TWO_PHASE, persist = 3, ldsScene = -1; // persist 3 = path queues (falls back to 1 where they do not apply)
     int stripeRows = 0, numParts = 1, part = 0;
     int maxBlocksPerCU = 0, chunkOverride = 0; // tuning knobs (env TPT_MAX_BLOCKS_PER_CU, TPT_CHUNK)
+    int gridFill = 0;                           // env TPT_GRID_FILL: % of the resident slots all in-flight launches ask for
     int gridDiv = 0;                            // env TPT_GRID_DIV: launch resident/gridDiv workgroups per frame; 0 = adaptive
     unsigned long long oldestPending = 0;       // adaptive grid: oldest frame whose trace kernel may still be running
     int ldsStackLevels = 6;                     // recursive fold: bounce-stack levels kept in LDS (env TPT_LDS_STACK_LEVELS)
 
+    float* mirror = nullptr;                    // tptSetTileMirror: second destination of the resolve kernel
+    unsigned long long* mirrorCounter = nullptr;
     unsigned* dWork = nullptr;
     unsigned long long* dRays = nullptr;    // the counter kernels add to (own or caller-provided)
     unsigned long long* dRaysOwn = nullptr;
@@ -287,7 +290,7 @@ int tptInitialize(void)
     // Frame pipelining wants one hardware queue per in-flight trace kernel; the ROCm runtime exposes 4 by default and
     // maps further streams onto them round-robin (3 streams then run slower than 2).  Only effective if the HIP
     // runtime has not been initialised yet by the host application; harmless otherwise.
-    setenv("GPU_MAX_HW_QUEUES", "24", 0);
+    setenv("GPU_MAX_HW_QUEUES", "32", 0);
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
@@ -323,6 +326,7 @@ int tptInitialize(void)
     g.lastTotal = 0;
     if (g.spheres.empty()) defaultScene(g.spheres, g.mats);
     if (const char* e1 = getenv("TPT_MAX_BLOCKS_PER_CU")) g.maxBlocksPerCU = atoi(e1);
+    if (const char* e6 = getenv("TPT_GRID_FILL")) g.gridFill = atoi(e6);
     if (const char* e5 = getenv("TPT_GRID_DIV")) g.gridDiv = atoi(e5) > 0 ? atoi(e5) : 0;
     if (const char* e2 = getenv("TPT_CHUNK")) g.chunkOverride = atoi(e2);
     if (const char* e4 = getenv("TPT_COST_ORDER")) g.costOrder = atoi(e4);
@@ -608,12 +612,24 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
         // resident workgroups (its pools then stay in steady state 8x longer before they drain, and the launches
         // behind it fill the gaps).  A caller that synchronises every frame has nothing in flight and gets the full grid.
         int div = g.gridDiv;
+        int cap = resident;
         if (div <= 0) {
-            div = (framesInFlight(nOverlap) + 1) / 2;
-            if (div > nOverlap / 2) div = nOverlap / 2;
-            if (div < 1) div = 1;
+            // the launches in flight together ask for gridFill % of the resident workgroup slots: 200 % on a single
+            // GPU (later launches queue behind and fill the gaps the draining ones leave); 75 % when the frame is
+            // sharded over ranks, so that the small kernels of the exchange (snapshot copy, RCCL, assemble) find a
+            // free CU instead of waiting for a persistent workgroup to retire
+            const int fill = g.gridFill > 0 ? g.gridFill : (g.numParts > 1 ? 100 : 200);
+            const int k = framesInFlight(nOverlap) + 1;
+            cap = (int)((long long)resident * fill / (100ll * k));
+            if (cap > resident) cap = resident;
+            const int floorBlocks = resident / (2 * (nOverlap > 1 ? nOverlap : 1));
+            if (cap < floorBlocks) cap = floorBlocks;
+            if (cap < 1) cap = 1;
+            div = 1;
+        } else {
+            cap = resident / div;
         }
-        if (blocks > resident / div) blocks = resident / div;
+        if (blocks > cap) blocks = cap;
         if (blocks < 1) blocks = 1;
         a.totalWaves = (unsigned)(blocks * wavesPerBlock);
     } else {
@@ -730,7 +746,7 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
         HIPCHK(hipEventRecord(g.evTrace[slot], ts));
         HIPCHK(hipStreamWaitEvent(g.stream, g.evTrace[slot], 0));
     }
-    HIPCHK(tptLaunchResolve(deviceTile, a.frameColour, a.nLocalRows * w, a.fc.lerpFac, g.stream));
+    HIPCHK(tptLaunchResolve(deviceTile, a.frameColour, a.nLocalRows * w, a.fc.lerpFac, g.mirror, g.dRays, g.mirrorCounter, g.stream));
     if (nOverlap > 1) {
         HIPCHK(hipEventRecord(g.evResolve[slot], g.stream));
         g.resolveRecorded[slot] = true;
@@ -745,6 +761,13 @@ int tptRayCounterRead(int64_t* outTotalRays)
     HIPCHK(hipMemcpyAsync(&v, g.dRays, sizeof(v), hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     if (outTotalRays) *outTotalRays = (int64_t)v;
+    return 0;
+}
+
+int tptSetTileMirror(float* deviceMirror, void* deviceCounterOut)
+{
+    g.mirror = deviceMirror;
+    g.mirrorCounter = deviceMirror ? static_cast<unsigned long long*>(deviceCounterOut) : nullptr;
     return 0;
 }
 

@@ -71,6 +71,23 @@ __global__ void __launch_bounds__(256) tptResolveKernel(float* __restrict__ tile
     t.x = r.x; t.y = r.y; t.z = r.z;
     reinterpret_cast<f4*>(tile)[i] = t;
 }
+// Same, and the blended pixel also goes to `mirror` (the snapshot a sharded host hands to its collective while the
+// next frames keep accumulating into the tile) and the current value of the ray counter to `counterOut`: one kernel
+// in the frame's dependency chain instead of three.
+__global__ void __launch_bounds__(256) tptResolveMirrorKernel(float* __restrict__ tile, const f4* __restrict__ colour, int nPixels, float lerpFac,
+                                                              f4* __restrict__ mirror, const unsigned long long* rayCounter,
+                                                              unsigned long long* counterOut)
+{
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && counterOut) *counterOut = __hip_atomic_load(rayCounter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (i >= nPixels) return;
+    f4 t = reinterpret_cast<const f4*>(tile)[i];
+    f4 c = colour[i];
+    f3 r = blendPixel(mk3(t.x, t.y, t.z), mk3(c.x, c.y, c.z), lerpFac);
+    t.x = r.x; t.y = r.y; t.z = r.z;
+    reinterpret_cast<f4*>(tile)[i] = t;
+    mirror[i] = t;
+}
 
 #ifndef TPT_MIN_WAVES_PER_SIMD
 #define TPT_MIN_WAVES_PER_SIMD 4 // caps the allocation at 128 VGPRs: 16 waves per CU
@@ -1113,9 +1130,15 @@ hipError_t tptLaunchChunkOrder(const unsigned* cost, unsigned* snap, unsigned* o
     return hipGetLastError();
 }
 
-hipError_t tptLaunchResolve(float* tile, const f4* frameColour, int nPixels, float lerpFac, hipStream_t stream)
+hipError_t tptLaunchResolve(float* tile, const f4* frameColour, int nPixels, float lerpFac, float* mirror,
+                            const unsigned long long* rayCounter, unsigned long long* counterOut, hipStream_t stream)
 {
-    hipLaunchKernelGGL(tptResolveKernel, dim3((nPixels + 255) / 256), dim3(256), 0, stream, tile, frameColour, nPixels, lerpFac);
+    if (nPixels <= 0) return hipSuccess;
+    if (mirror)
+        hipLaunchKernelGGL(tptResolveMirrorKernel, dim3((nPixels + 255) / 256), dim3(256), 0, stream, tile, frameColour, nPixels, lerpFac,
+                           reinterpret_cast<f4*>(mirror), rayCounter, counterOut);
+    else
+        hipLaunchKernelGGL(tptResolveKernel, dim3((nPixels + 255) / 256), dim3(256), 0, stream, tile, frameColour, nPixels, lerpFac);
     return hipGetLastError();
 }
 

@@ -117,7 +117,22 @@ class ShardedFrame:
         # the 64-bit ray counter rides in the first 8 bytes of the extra row (bit-cast, not converted)
         send[self.pad_rows, 0, :2].view(self.torch.int64).copy_(self.ray_counter, non_blocking=True)
 
-    def exchange(self):
+    def mirror_pointers(self):
+        """Device addresses (snapshot tile, 8-byte counter slot) of the send buffer the NEXT exchange() will use, for
+        tptSetTileMirror: the library's resolve kernel then fills the snapshot itself and exchange(snapshot_done=True)
+        skips the two copy kernels -- two fewer kernels in every frame's dependency chain.  None when not sharded."""
+        if self.world <= 1:
+            return None
+        send = self.send[self.steps % self.depth]
+        return send.data_ptr(), send[self.pad_rows].data_ptr()
+
+    def begin_frame(self):
+        """With mirroring: call BEFORE the frame's draw is enqueued -- makes the render stream wait until the collective
+        that last read the send buffer about to be overwritten has finished."""
+        if self.world > 1 and self.on_gpu and self.steps >= self.depth:
+            self.render_stream.wait_event(self.ev_free[self.steps % self.depth])
+
+    def exchange(self, snapshot_done=False):
         """Call after this frame's render has been enqueued on render_stream."""
         torch = self.torch
         k = self.steps % self.depth
@@ -126,9 +141,10 @@ class ShardedFrame:
             return
         if self.on_gpu:
             with torch.cuda.stream(self.render_stream):
-                if self.steps > self.depth:
-                    self.render_stream.wait_event(self.ev_free[k])    # gather of frame f-depth has read this buffer
-                self._fill_send(k)
+                if not snapshot_done:
+                    if self.steps > self.depth:
+                        self.render_stream.wait_event(self.ev_free[k])    # gather of frame f-depth has read this buffer
+                    self._fill_send(k)
                 self.ev_ready[k].record(self.render_stream)
             with torch.cuda.stream(self.comm_stream):
                 self.comm_stream.wait_event(self.ev_ready[k])

@@ -212,7 +212,7 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(args.workload)
+            traffic = json.load(open(tpath)).get(args.workload if args.persistent == 3 else "%s_persist%d" % (args.workload, args.persistent))
         out = {
             "metric": "Mray/s", "value": rays_total / dt / 1e6, "unit": "Mray/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -236,13 +236,14 @@ def main():
                                  "the GPU at once, so the per-launch figure understates the chip by that factor: *_per_pipeline_slot divides by "
                                  "the time a frame occupies the pipeline instead.  The kernel is FP32-VALU bound (arithmetic intensity ~440 "
                                  "flop/B), see roofline_valu" % args.overlap,
-                         "kernel": "tptTraceKernel"},
+                         "kernel": ["tptTraceKernel", "tptTraceKernel", "tptTraceSortedKernel", "tptTraceQueueKernel"][args.persistent]},
             "roofline_valu": {"bound": "valu_fp32", "achieved": valu_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                               "frac": valu_tflops / PEAK_FP32_TFLOPS,
                               "achieved_per_pipeline_slot": valu_tflops * k_ms / p_ms,
                               "frac_per_pipeline_slot": valu_tflops * k_ms / p_ms / PEAK_FP32_TFLOPS,
-                              "note": "algorithmic flops = rays x 17 flop x spheres (SURVEY 8d); peak counts FMA as 2 flop and the "
-                                      "parity contract forbids FMA contraction, so the reachable ceiling is 78.6 T non-fused op/s"},
+                              "note": "algorithmic flops = rays x 17 flop x spheres (SURVEY 8d: the reference's own per-test count); peak counts "
+                                      "FMA as 2 flop.  The exact arithmetic (phase 2 of HitSpheres, Scatter) may not contract to FMA (parity); "
+                                      "phase 1 is a conservative filter and does use FMA (10 packed ops per sphere pair instead of 16)"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(width, height, spp)

@@ -92,9 +92,10 @@ int tptDrawDevice(float time, int frameCount, int screenWidth, int screenHeight,
 /* Frame pipelining of the asynchronous path: the trace kernels of up to `frames` consecutive tptDrawDevice
  * calls may be in flight at once (each on its own internal stream, writing its own per-frame colour
  * buffer); the progressive blend into the tile (Test.cpp:293-295) is a separate, ordered kernel on the
- * context's stream, so results are bit-identical to frames=1.  1..8, default 8: the tail of frame f (a few long
- * paths) overlaps the head of the following frames; small tiles (row sharding over many GPUs) need the depth.
- * Needs one hardware queue per in-flight kernel: tptInitialize sets GPU_MAX_HW_QUEUES=16 if the HIP runtime has
+ * context's stream, so results are bit-identical to frames=1.  1..16, default 16: the tail of frame f (a few long
+ * paths) overlaps the following frames, and each launch takes only its share of the machine (2/frames-in-flight of
+ * the resident workgroups; a caller that synchronises every frame gets whole-machine launches).
+ * Needs one hardware queue per in-flight kernel: tptInitialize sets GPU_MAX_HW_QUEUES=32 if the HIP runtime has
  * not been initialised yet (ROCm's default of 4 makes 3 streams slower than 2). */
 int tptSetFrameOverlap(int frames);
 /* Display conversion of a device-resident FULL image (w*h float4, row 0 = bottom) into w*h RGBA8 in device memory,
@@ -129,14 +130,16 @@ int tptKernelTimingEnd(float* outSumMilliseconds, int* outLaunches);
 
 /* ================= 4. tuning / test hooks ================= */
 
-/* hitSpheres: 0 = two-phase (default), 1 = simple loop.  persistent: 1 = persistent waves with lane
- * refill (default), 0 = one thread per pixel, 2 = lane-sorting workgroups (experimental), 3 = path queues in
- * LDS (experimental; recursive fold only).  ldsScene: 1 = stage sphere records and materials in LDS (default
+/* hitSpheres: 0 = two-phase (default: conservative FMA filter + the reference's exact test for what passes),
+ * 1 = simple loop (exact test for every sphere).  persistent: 3 = path queues in LDS (default; per-pixel seeds,
+ * recursive fold, two-phase only -- anything else falls back to 1), 1 = persistent waves with lane refill,
+ * 0 = one thread per pixel, 2 = lane-sorting workgroups (experimental).  ldsScene: 1 = stage sphere records and materials in LDS (default
  * when they fit), 0 = read them from global memory, -1 = auto.  All variants produce identical bits. */
 int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene);
 /* device math unit tests: op 0 sqrt 1 div 2 sin 3 cos 4 pow5 5 rnd01^16 6 schlick 7 normalize.x; host arrays */
 int tptTestMath(int op, const float* a, const float* b, float* out, int n);
-/* intersect n host rays ([n][6] = origin, direction) with the current scene on the GPU */
+/* intersect n host rays ([n][6] = origin, UNIT direction -- the reference asserts it, Maths.h Ray ctor; the two-phase
+ * filter's error bound assumes it) with the current scene on the GPU */
 int tptTestHitSpheres(int hitSpheres, const float* rays, int* outId, float* outT, int n);
 /* kernel resource facts for DESIGN/bench: occupancy (blocks/CU), LDS bytes/block, grid size of the last launch */
 int tptGetLaunchInfo(int* outBlocksPerCU, int* outLdsBytes, int* outGridBlocks, int* outNumCUs);

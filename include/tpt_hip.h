@@ -138,7 +138,7 @@ int tptKernelTimingEnd(float* outSumMilliseconds, int* outLaunches);
 int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene);
 /* device math unit tests: op 0 sqrt 1 div 2 sin 3 cos 4 pow5 5 rnd01^16 6 schlick 7 normalize.x; host arrays */
 int tptTestMath(int op, const float* a, const float* b, float* out, int n);
-/* intersect n host rays ([n][6] = origin, UNIT direction -- the reference asserts it, Maths.h Ray ctor; the two-phase
+/* intersect n host rays ([n][6] = origin, UNIT direction -- the reference asserts it, Maths.h:337; the two-phase
  * filter's error bound assumes it) with the current scene on the GPU */
 int tptTestHitSpheres(int hitSpheres, const float* rays, int* outId, float* outT, int n);
 /* kernel resource facts for DESIGN/bench: occupancy (blocks/CU), LDS bytes/block, grid size of the last launch */

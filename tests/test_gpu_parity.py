@@ -259,6 +259,26 @@ def test_device_resident_path_with_torch_tile(tpt_defaults, oracle):
     assert rays == ro and tile.cpu().numpy().tobytes() == bo.tobytes()
 
 
+@pytest.mark.parametrize("persist,overlap", [(3, 16), (1, 8), (1, 16)], ids=["path_queues-16", "lane_refill-8", "lane_refill-16"])
+def test_seventy_pipelined_frames_at_config2(tpt_defaults, oracle, persist, overlap):
+    """configs[1] for 70 frames without a host sync: long enough for the periodic re-sort of the lane-refill kernel's tile
+    order (every 32nd frame) to happen twice with other frames in flight -- a frame on another stream once read the
+    table while it was being rewritten and skipped tiles (found by tools/soak.py)."""
+    import torch
+    tpt = tpt_defaults
+    tpt.set_kernel_variant(0, persist, -1)
+    tpt.set_frame_overlap(overlap)
+    w, h, frames = 1280, 720, 70
+    tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    r0 = tpt.ray_counter_read()
+    for f in range(frames):
+        tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+        tpt.draw_device(0.0, f, w, h, tile.data_ptr(), FLAG_PROGRESSIVE)
+    rays = tpt.ray_counter_read() - r0
+    ro, bo, _ = oracle_frames(oracle, w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
+    assert rays == ro and tile.cpu().numpy().tobytes() == bo.tobytes()
+
+
 def test_tile_mirror_snapshot(tpt_defaults, oracle):
     """tptSetTileMirror: the resolve kernel also writes the blended tile (and the ray counter) to a second buffer -- the
     snapshot a sharded host hands to its gather.  Rotating mirrors every frame, as bench.py does."""

@@ -87,6 +87,9 @@ struct Context {
     unsigned* dChunkSnap[kMaxOverlap] = {}; // per trace stream: cost snapshot of the sort kernel
     int chunkCap = 0, chunkCount = 0; // chunkCount: numChunks the statistics belong to
     int costOrder = 1;                // env TPT_COST_ORDER=0 disables
+    hipEvent_t evOrder = nullptr;     // the last sort of an order table (recorded on the stream that ran it)
+    hipStream_t orderStream = nullptr;
+    bool orderDone = true;
     unsigned long long orderSeq = 0;
     int lastOrderTable = 0;
     f4* dPath[kMaxOverlap] = {};        // path-queue kernel: cold path state (one per in-flight frame)
@@ -308,6 +311,8 @@ int tptInitialize(void)
     g.deviceName = std::string(prop.name) + " (" + prop.gcnArchName + ")";
     HIPCHK(hipStreamCreateWithFlags(&g.ownStream, hipStreamNonBlocking));
     g.stream = g.ownStream;
+    HIPCHK(hipEventCreateWithFlags(&g.evOrder, kOrderingEvent));
+    g.orderDone = true;
     HIPCHK(hipEventCreate(&g.ev0));
     HIPCHK(hipEventCreate(&g.ev1));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dWork), 64 * Context::kMaxOverlap));
@@ -371,6 +376,7 @@ int tptShutdown(void)
         g.traceStream[k] = nullptr; g.evTrace[k] = nullptr; g.evResolve[k] = nullptr; g.dColour[k] = nullptr; g.colourCap[k] = 0;
     }
     (void)hipEventDestroy(g.ev0); (void)hipEventDestroy(g.ev1);
+    if (g.evOrder) { (void)hipEventDestroy(g.evOrder); g.evOrder = nullptr; }
     (void)hipStreamDestroy(g.ownStream);
     g.ownStream = g.stream = nullptr;
     g.inited = false;
@@ -723,8 +729,19 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
         unsigned* table = g.dChunkOrder[g.orderSeq % Context::kOrderTables];
         if (g.orderSeq <= (unsigned long long)(2 * nOverlap + 2) || (g.orderSeq & 31ull) == 0ull) {
             HIPCHK(tptLaunchChunkOrder(g.dChunkCost, g.dChunkSnap[slot], table, a.numChunks, ts));
+            HIPCHK(hipEventRecord(g.evOrder, ts));
+            g.orderStream = ts;
+            g.orderDone = false;
         } else {
+            // reuse the most recent table -- which another stream's sort kernel may still be writing
             table = g.dChunkOrder[g.lastOrderTable];
+            if (!g.orderDone && g.orderStream != ts) {
+                if (hipEventQuery(g.evOrder) == hipSuccess)
+                    g.orderDone = true;
+                else
+                    HIPCHK(hipStreamWaitEvent(ts, g.evOrder, 0));
+                (void)hipGetLastError();
+            }
         }
         g.lastOrderTable = (int)(table == g.dChunkOrder[g.orderSeq % Context::kOrderTables] ? g.orderSeq % Context::kOrderTables : g.lastOrderTable);
         a.chunkOrder = table;

@@ -187,6 +187,10 @@ def local_row_count(height):
     return load_library().tptLocalRowCount(height)
 
 
+def local_row_to_global(local_row):
+    return load_library().tptLocalRowToGlobal(local_row)
+
+
 def draw_device(time, frameCount, screenWidth, screenHeight, device_ptr, testFlags):
     """Asynchronous DrawTest into a device-resident tile (raw device pointer, e.g. tensor.data_ptr())."""
     _chk(load_library().tptDrawDevice(time, frameCount, screenWidth, screenHeight, C.c_void_p(device_ptr), testFlags),

@@ -143,9 +143,9 @@ int tptTestMath(int op, const float* a, const float* b, float* out, int n);
 int tptTestHitSpheres(int hitSpheres, const float* rays, int* outId, float* outT, int n);
 /* kernel resource facts for DESIGN/bench: occupancy (blocks/CU), LDS bytes/block, grid size of the last launch */
 int tptGetLaunchInfo(int* outBlocksPerCU, int* outLdsBytes, int* outGridBlocks, int* outNumCUs);
-/* profiling builds only (-DTPT_STATS): 64 counters, wave-level entries [i] / lane counts [32+i] of the
+/* profiling builds only (-DTPT_STATS): 128 counters, wave-level entries [i] / lane counts [32+i] of the
  * state machine's blocks (enum ST_* in tpt_trace.h); the shipped build returns an error. */
-int tptDebugStats(unsigned long long* out64, int reset);
+int tptDebugStats(unsigned long long* out128, int reset);
 /* per-chunk accumulated ray counts and the chunk order table of the last launch (cost-ordered work distribution
  * of the persistent kernel); either pointer may be NULL; returns the number of chunks copied */
 int tptDebugChunkOrder(unsigned* outCost, unsigned* outOrder, int capacity);

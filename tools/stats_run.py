@@ -31,6 +31,12 @@ for (w, h, spp, persist) in [(1280, 720, 4, 3), (3840, 2160, 16, 3)]:
     for c, n in enumerate(QN):
         if st[16 + c]:
             print("  queue %-8s batches %9d  paths %11d  fill %.1f / 64" % (n, st[16 + c], st[48 + c], st[48 + c] / st[16 + c]))
+    tot = float(sum(int(st[64 + k]) for k in range(25))) or 1.0
+    if tot > 1:
+        print("  wave time by section (s_memtime ticks, share of all wave time): idle polls %.1f %%" % (100.0 * int(st[64 + 24]) / tot))
+        for c, n in enumerate(QN):
+            v = [int(st[64 + c * 4 + k]) for k in range(4)]
+            print("    %-8s pick+pop %5.1f %%  class code %5.1f %%  intersect+classify %5.1f %%  push %5.1f %%" % ((n,) + tuple(100.0 * x / tot for x in v)))
     for i, n in enumerate(NAMES):
         if st[i]:
             print("  %-10s wave-entries %10d (%.3f per step)  lanes %12d (%.2f per entry)" % (n, st[i], st[i] / steps_w, st[32 + i], st[32 + i] / st[i]))

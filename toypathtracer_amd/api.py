@@ -268,7 +268,7 @@ def launch_info():
 
 def debug_stats(reset=True):
     """profiling build only (TPT_LIB=... built with -DTPT_STATS)"""
-    out = np.zeros(64, np.uint64)
+    out = np.zeros(128, np.uint64)
     _chk(load_library().tptDebugStats(out.ctypes.data, 1 if reset else 0), "tptDebugStats")
     return out
 

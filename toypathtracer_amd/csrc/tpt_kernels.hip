@@ -156,7 +156,10 @@ __global__ void __launch_bounds__(256) tptDisplayKernel(const f4* __restrict__ t
 }
 
 template <int HS, int FOLD, bool PERSIST, bool LDS_SCENE>
-__global__ void __launch_bounds__(TPT_BLOCK, TPT_MIN_WAVES_PER_SIMD) tptTraceKernel(const KernelArgs a)
+// 112 VGPRs x 4 waves/SIMD leaves 64 registers per SIMD lane for the resolve kernel's waves (see tptTraceQueueKernel;
+// amdgpu_num_vgpr counts half of the unified file on gfx90a+, so 56 means 112)
+__global__ void __launch_bounds__(TPT_BLOCK, TPT_MIN_WAVES_PER_SIMD) __attribute__((amdgpu_num_vgpr(56)))
+tptTraceKernel(const KernelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // ---- carve LDS (every offset a multiple of 16)
@@ -715,7 +718,19 @@ tptTraceQueueKernel(const KernelArgs a)
     bool noMoreChunks = false;
     unsigned myRays = 0;
 
+#if defined(TPT_STATS)
+#define TPT_TSTAMP(v)                      \
+    __builtin_amdgcn_sched_barrier(0);     \
+    __builtin_amdgcn_s_waitcnt(0);         \
+    const unsigned long long v = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_sched_barrier(0)
+#define TPT_TADD(slot, a, b) do { if (lane == 0) atomicAdd(&g_tptStats[slot], (b) - (a)); } while (0)
+#else
+#define TPT_TSTAMP(v) do { } while (0)
+#define TPT_TADD(slot, a, b) do { } while (0)
+#endif
     for (;;) {
+        TPT_TSTAMP(tsTop);
         // ---- what is waiting?  lanes 0..5 read one queue each, broadcast through readlane
         unsigned myAvail = 0;
         if (lane < Q_COUNT)
@@ -753,12 +768,16 @@ tptTraceQueueKernel(const KernelArgs a)
             if (exhausted != 0u && pool == 0u) noMoreChunks = true;
             TPT_STAT(ST_REFILL); // idle polls
             __builtin_amdgcn_s_sleep(4);
+            TPT_TSTAMP(tsIdle);
+            TPT_TADD(64 + 24, tsTop, tsIdle);
             continue;
         }
         int p = 0;
         const int n = qPop(q + pick * TPT_Q_P, &ctl->head[pick], &ctl->tail[pick], lane, p);
         if (n == 0) continue;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        TPT_TSTAMP(tsPop);
+        TPT_TADD(64 + pick * 4 + 0, tsTop, tsPop);
         const bool mine = lane < n;
 #if defined(TPT_STATS)
         if (mine) { TPT_STAT(16 + pick); } // [16+pick] batches popped per queue, [48+pick] paths in them
@@ -847,10 +866,13 @@ tptTraceQueueKernel(const KernelArgs a)
             L.col = mk3(0, 0, 0); // colour of the sample that ends in this step, if one does (0 + c == c)
             L.x = 0; L.y = 0;
             const int sampleBefore = L.sample;
+            // END batches always finish a sample: ask for the pixel's running sum now, use it after the fold
+            f4 c3 = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (pick == Q_END) c3 = cold[p];
             const bool pixelDone = lanePost<FOLD_RECURSIVE>(L, id, t, sv, fc, stack);
             if (L.sample != sampleBefore) {
                 // a sample ended: add it to the pixel's running sum (same order of additions as Test.cpp:289)
-                const f4 c3 = cold[p];
+                if (pick != Q_END) c3 = cold[p];
                 L.col = mk3(c3.x, c3.y, c3.z) + L.col;
                 L.x = (int)(f2u(c3.w) & 0xffffu);
                 L.y = (int)(f2u(c3.w) >> 16);
@@ -867,6 +889,8 @@ tptTraceQueueKernel(const KernelArgs a)
             }
         }
 
+        TPT_TSTAMP(tsClass);
+        TPT_TADD(64 + pick * 4 + 1, tsPop, tsClass);
         // ---- HitWorld for the rays this batch produced.  A Lambert hit runs its whole light loop here: the shadow
         //      ray is intersected, shaded, and the next one (or the bounce ray) generated, all in registers.
         int cls = -1;
@@ -904,10 +928,14 @@ tptTraceQueueKernel(const KernelArgs a)
             cls = Q_INT;
         }
         if (toFree) cls = Q_FREE;
+        TPT_TSTAMP(tsInt);
+        TPT_TADD(64 + pick * 4 + 2, tsClass, tsInt);
         // (the cold state is global memory, but every wave that can pop this path runs on this CU and shares its L1:
         //  the workgroup-scope release orders the stores before the queue entry becomes visible)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         qPushByClass(q, ctl, mine ? cls : -1, p, lane);
+        TPT_TSTAMP(tsPush);
+        TPT_TADD(64 + pick * 4 + 3, tsInt, tsPush);
     }
 
     const unsigned waveRays = waveReduceAdd(myRays);
@@ -967,7 +995,7 @@ using namespace tpt;
 int tptReadStats(unsigned long long* out64)
 {
 #if defined(TPT_STATS)
-    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_tptStats), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -2;
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_tptStats), sizeof(unsigned long long) * 128) == hipSuccess ? 0 : -2;
 #else
     (void)out64;
     return -1;
@@ -976,7 +1004,7 @@ int tptReadStats(unsigned long long* out64)
 int tptResetStats()
 {
 #if defined(TPT_STATS)
-    unsigned long long z[64] = {0};
+    unsigned long long z[128] = {0};
     z[25] = ~0ull;
     return hipMemcpyToSymbol(HIP_SYMBOL(g_tptStats), z, sizeof(z)) == hipSuccess ? 0 : -2;
 #else

@@ -78,7 +78,7 @@ TPT_HD f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 
 // Profiling build only (-DTPT_STATS, tools/): wave-level entry counts [i] and lane counts [32+i] per block.
 #if defined(__HIPCC__) && defined(TPT_STATS)
-__device__ unsigned long long g_tptStats[64];
+__device__ unsigned long long g_tptStats[128];
 #endif
 #if defined(__HIP_DEVICE_COMPILE__) && defined(TPT_STATS)
 #define TPT_STAT(i)                                                                  \
@@ -525,15 +525,46 @@ TPT_HD bool lanePost(Lane& L, const int id, const float t, const SceneView& sv, 
             c = L.radiance + L.throughput * term;
         } else {
             c = term;
-            for (int lv = L.sp - 1; lv >= 0; --lv) { // matE + lightE + attenuation * Trace(...), Test.cpp:216
-                f4 e = stack.get(lv);
-                int a = (int)f2u(e.w);
-                f3 at = mk3(1, 1, 1);
-                if (a >= 0) {
-                    f4 m0 = sv.mats[a * 3];
-                    at = mk3(m0.x, m0.y, m0.z);
+            // matE + lightE + attenuation * Trace(...), Test.cpp:216, innermost level first.
+            const int sp = L.sp;
+            if (stack.fastLevels == 0) {
+                // Stack entirely in global memory (path-queue kernel).  The records of ALL levels are requested before
+                // the first one is used: a loop that loads one level per trip pays one memory latency per level, and a
+                // wave runs as many trips as its deepest lane -- that loop alone was a third of all wave time.  Two groups
+                // of five keep the register cost at 20.
+#pragma unroll
+                for (int g5 = 1; g5 >= 0; --g5) {
+                    f4 ent[5];
+#pragma unroll
+                    for (int k = 0; k < 5; ++k) {
+                        ent[k].x = ent[k].y = ent[k].z = ent[k].w = 0.0f;
+                        if (g5 * 5 + k < sp) ent[k] = stack.spill[(g5 * 5 + k) * stack.spillStride];
+                    }
+#pragma unroll
+                    for (int k = 4; k >= 0; --k) {
+                        if (g5 * 5 + k < sp) {
+                            const f4 e = ent[k];
+                            int a = (int)f2u(e.w);
+                            f3 at = mk3(1, 1, 1);
+                            if (a >= 0) {
+                                f4 m0 = sv.mats[a * 3];
+                                at = mk3(m0.x, m0.y, m0.z);
+                            }
+                            c = mk3(e.x, e.y, e.z) + at * c;
+                        }
+                    }
                 }
-                c = mk3(e.x, e.y, e.z) + at * c;
+            } else {
+                for (int lv = sp - 1; lv >= 0; --lv) { // LDS levels: a plain loop
+                    f4 e = stack.get(lv);
+                    int a = (int)f2u(e.w);
+                    f3 at = mk3(1, 1, 1);
+                    if (a >= 0) {
+                        f4 m0 = sv.mats[a * 3];
+                        at = mk3(m0.x, m0.y, m0.z);
+                    }
+                    c = mk3(e.x, e.y, e.z) + at * c;
+                }
             }
         }
         L.col = L.col + c;

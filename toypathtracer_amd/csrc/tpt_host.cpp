@@ -95,6 +95,7 @@ struct Context {
     f4* dPath[kMaxOverlap] = {};        // path-queue kernel: cold path state (one per in-flight frame)
     size_t pathCap[kMaxOverlap] = {};
     float* dFrame = nullptr; // device tile behind the host-pointer DrawTest
+    const float* uploadSrc = nullptr; // tptDraw: host backbuffer whose rows tptDrawDevice uploads once the trace is launched
     size_t frameCap = 0;
 
     // frame pipelining: trace kernels of consecutive frames run on alternating internal streams and write
@@ -272,6 +273,25 @@ int framesInFlight(int nOverlap)
     }
     (void)hipGetLastError(); // hipErrorNotReady is not an error
     return (int)(cur - g.oldestPending);
+}
+
+// tptDraw's upload of the caller's backbuffer (previous frame's RGB, caller-owned alpha) into g.dFrame, this rank's rows
+int uploadBackbuffer(const float* backbuffer, int w, int h)
+{
+    const int rows = localRows(h);
+    const size_t rowBytes = (size_t)w * 4 * sizeof(float);
+    const bool sharded = g.numParts > 1 && g.stripeRows > 0;
+    if (!sharded) {
+        HIPCHK(hipMemcpyAsync(g.dFrame, backbuffer, rowBytes * rows, hipMemcpyHostToDevice, g.stream));
+        return 0;
+    }
+    for (int ly = 0; ly < rows; ly += g.stripeRows) {
+        int n = rows - ly < g.stripeRows ? rows - ly : g.stripeRows;
+        HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(g.dFrame) + rowBytes * ly,
+                              reinterpret_cast<const char*>(backbuffer) + rowBytes * localToGlobal(ly), rowBytes * n,
+                              hipMemcpyHostToDevice, g.stream));
+    }
+    return 0;
 }
 
 int requireInit()
@@ -759,10 +779,14 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
         HIPCHK(hipEventRecord(g.ktStop[g.ktUsed], ts));
         g.ktUsed++;
     }
-    if (nOverlap > 1) {
-        HIPCHK(hipEventRecord(g.evTrace[slot], ts));
-        HIPCHK(hipStreamWaitEvent(g.stream, g.evTrace[slot], 0));
+    if (nOverlap > 1) HIPCHK(hipEventRecord(g.evTrace[slot], ts));
+    if (g.uploadSrc) { // tptDraw: the previous image crosses PCIe while the trace kernel runs (it is on another stream)
+        const float* src = g.uploadSrc;
+        g.uploadSrc = nullptr;
+        int rcUp = uploadBackbuffer(src, w, h);
+        if (rcUp) return rcUp;
     }
+    if (nOverlap > 1) HIPCHK(hipStreamWaitEvent(g.stream, g.evTrace[slot], 0));
     HIPCHK(tptLaunchResolve(deviceTile, a.frameColour, a.nLocalRows * w, a.fc.lerpFac, g.mirror, g.dRays, g.mirrorCounter, g.stream));
     if (nOverlap > 1) {
         HIPCHK(hipEventRecord(g.evResolve[slot], g.stream));
@@ -838,22 +862,18 @@ int tptDraw(float time, int frameCount, int w, int h, float* backbuffer, int* ou
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dFrame), need));
         g.frameCap = need;
     }
-    // the host buffer is the source of truth (previous frame's RGB, caller-owned alpha): upload this rank's rows
     const bool sharded = g.numParts > 1 && g.stripeRows > 0;
-    if (!sharded) {
-        HIPCHK(hipMemcpyAsync(g.dFrame, backbuffer, rowBytes * rows, hipMemcpyHostToDevice, g.stream));
-    } else {
-        for (int ly = 0; ly < rows; ly += g.stripeRows) {
-            int n = rows - ly < g.stripeRows ? rows - ly : g.stripeRows;
-            HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(g.dFrame) + rowBytes * ly,
-                                  reinterpret_cast<const char*>(backbuffer) + rowBytes * localToGlobal(ly), rowBytes * n,
-                                  hipMemcpyHostToDevice, g.stream));
-        }
-    }
     int64_t totalBefore = 0;
     int rc = tptRayCounterRead(&totalBefore); // rays of asynchronous tptDrawDevice calls made since must not count here
     if (rc) return rc;
+    // The host buffer is the source of truth (previous frame's RGB, caller-owned alpha).  Only the blend needs it, so
+    // tptDrawDevice uploads it AFTER it has launched the trace kernel: the PCIe copy runs beside the tracing.
+    g.uploadSrc = backbuffer;
     rc = tptDrawDevice(time, frameCount, w, h, g.dFrame, testFlags);
+    if (g.uploadSrc) { // not consumed (nothing to render on this rank, or an error)
+        g.uploadSrc = nullptr;
+        if (!rc && rows > 0) rc = uploadBackbuffer(backbuffer, w, h);
+    }
     if (rc) return rc;
     if (!sharded) {
         HIPCHK(hipMemcpyAsync(backbuffer, g.dFrame, rowBytes * rows, hipMemcpyDeviceToHost, g.stream));

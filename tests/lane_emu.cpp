@@ -33,6 +33,7 @@ int64_t emu_render_ex(const void* spheres, const void* mats, int count, const vo
     PackedScene P;
     packScene(S, M, P);
     SceneView sv = viewOf(P);
+    if (hs == 2) sv.nGroups = 0; // two-phase, brute force even for a large scene
     CameraPOD c;
     memcpy(&c, cam, sizeof(c));
     FrameConsts fc = makeFrameConsts(c, w, h, spp, frame, flags, seedMode);
@@ -57,8 +58,8 @@ int64_t emu_render_ex(const void* spheres, const void* mats, int count, const vo
                     done = fold == FOLD_FORWARD ? laneStep<HS_SIMPLE, FOLD_FORWARD>(L, sv, fc, stack)
                                                 : laneStep<HS_SIMPLE, FOLD_RECURSIVE>(L, sv, fc, stack);
                 else
-                    done = fold == FOLD_FORWARD ? laneStep<HS_TWO_PHASE, FOLD_FORWARD>(L, sv, fc, stack)
-                                                : laneStep<HS_TWO_PHASE, FOLD_RECURSIVE>(L, sv, fc, stack);
+                    done = fold == FOLD_FORWARD ? laneStep<HS_TWO_PHASE_GROUPS, FOLD_FORWARD>(L, sv, fc, stack)
+                                                : laneStep<HS_TWO_PHASE_GROUPS, FOLD_RECURSIVE>(L, sv, fc, stack);
                 if (done) break;
             }
             {
@@ -91,6 +92,15 @@ void emu_default_camera(void* cam, int w, int h)
     CameraPOD c = makeCamera(defaultCameraSetup(), float(w) / float(h));
     memcpy(cam, &c, sizeof(c));
 }
+// {nGroups, nGroupPairs, nBig} of the grouped representation packScene builds for this scene (0 groups: flat)
+void emu_group_info(const void* spheres, const void* mats, int count, int* out3)
+{
+    std::vector<SpherePOD> S((const SpherePOD*)spheres, (const SpherePOD*)spheres + count);
+    std::vector<MaterialPOD> M((const MaterialPOD*)mats, (const MaterialPOD*)mats + count);
+    PackedScene P;
+    packScene(S, M, P);
+    out3[0] = P.nGroups; out3[1] = P.nGroupPairs; out3[2] = P.nBig;
+}
 float emu_sinf(float x) { return tsinf(x); }
 float emu_cosf(float x) { return tcosf(x); }
 float emu_pow5f(float x) { return tpow5f(x); }
@@ -105,10 +115,11 @@ void emu_hit_spheres(const void* spheres, const void* mats, int count, int hs, c
     PackedScene P;
     packScene(S, M, P);
     SceneView sv = viewOf(P);
+    if (hs == 2) sv.nGroups = 0;
     for (int i = 0; i < n; ++i) {
         f3 o = mk3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]), d = mk3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
         float t;
-        outId[i] = hs ? hitSpheres<HS_SIMPLE>(sv, o, d, TPT_MIN_T, TPT_MAX_T, t) : hitSpheres<HS_TWO_PHASE>(sv, o, d, TPT_MIN_T, TPT_MAX_T, t);
+        outId[i] = hs == 1 ? hitSpheres<HS_SIMPLE>(sv, o, d, TPT_MIN_T, TPT_MAX_T, t) : hitSpheres<HS_TWO_PHASE_GROUPS>(sv, o, d, TPT_MIN_T, TPT_MAX_T, t);
         outT[i] = t;
     }
 }

@@ -115,7 +115,12 @@ def test_custom_scene_camera_stress(tpt_defaults, oracle):
     cam = oracle.camera(STRESS_CAMERA["look_from"], STRESS_CAMERA["look_at"], (0, 1, 0), STRESS_CAMERA["vfov"], w / h,
                         STRESS_CAMERA["aperture"], STRESS_CAMERA["focus_dist"])
     ro, bo, pero = oracle_frames(oracle, w, h, spp, 2, spheres=s, mats=m, cam=cam, seed_mode=SEED_PER_PIXEL)
-    assert per == pero and bb.tobytes() == bo.tobytes()
+    assert per == pero and bb.tobytes() == bo.tobytes()   # default: grouped traversal (compact groups of <= 16 spheres)
+    for hs, persist in ((2, 3), (2, 1), (0, 1), (1, 3)):  # flat two-phase, lane-refill kernel, all-exact loop
+        tpt.set_kernel_variant(hs, persist, -1)
+        rays2, bb2, per2 = gpu_frames(tpt, w, h, 2)
+        assert per2 == pero and bb2.tobytes() == bo.tobytes(), (hs, persist)
+    tpt.set_kernel_variant(0, 3, -1)
     # scene export round trip (GetSceneDesc, Test.cpp:377-384)
     s2, m2, cam2, em = tpt.GetSceneDesc()
     assert m2.tobytes() == m.tobytes() and list(em) == [1, 2, 3, 4] and cam2.tobytes() == cam.tobytes()

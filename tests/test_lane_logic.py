@@ -105,10 +105,67 @@ def test_two_phase_filter_is_conservative_on_grazing_rays(emu, oracle):
     for (s, m), n in ((oracle.default_scene(), 400000), (stress_scene(4096, 64), 20000)):
         rays = grazing_rays(s, n)
         out = []
-        for hs in (0, 1):
+        for hs in (0, 1, 2):  # 0: two-phase (grouped for the 4096-sphere scene), 1: all-exact loop, 2: two-phase flat
             ids, ts = np.empty(n, np.int32), np.empty(n, np.float32)
             emu.emu_hit_spheres(s.ctypes.data, m.ctypes.data, len(s), hs, rays.ctypes.data, n, ids.ctypes.data, ts.ctypes.data)
             out.append((ids, ts))
-        assert np.array_equal(out[0][0], out[1][0])
-        assert np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+        for k in (0, 2):
+            assert np.array_equal(out[k][0], out[1][0])
+            assert np.array_equal(out[k][1].view(np.uint32), out[1][1].view(np.uint32))
         assert (out[1][0] >= 0).mean() > 0.3  # the generator does produce hits (and near misses)
+
+
+@pytest.mark.parametrize("n", [256, 1000, 4096])
+def test_grouped_hit_world_equals_brute_force(emu, oracle, n):
+    """Large scenes are traversed through compact groups of <= 16 spheres with bounding spheres: a
+    small render of the stress scene must equal the oracle's brute force bit for bit, for the grouped path (hs 0), the
+    all-exact loop (hs 1) and the flat two-phase loop (hs 2)."""
+    from toypathtracer_amd.scenes import STRESS_CAMERA, stress_scene
+    s, m = stress_scene(n, 64 if n > 256 else 16)
+    w, h, spp = 64, 36, 2
+    cam = oracle.camera(STRESS_CAMERA["look_from"], STRESS_CAMERA["look_at"], (0, 1, 0), STRESS_CAMERA["vfov"], w / h,
+                        STRESS_CAMERA["aperture"], STRESS_CAMERA["focus_dist"])
+    ro, bo = oracle.render(s, m, cam, w, h, spp, 0, seed_mode=1)
+    import ctypes as C
+    info = np.zeros(3, np.int32)
+    emu.emu_group_info.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    emu.emu_group_info.restype = None
+    emu.emu_group_info(s.ctypes.data, m.ctypes.data, n, info.ctypes.data)
+    assert info[0] >= (n - info[2] + 15) // 16 and 1 <= info[2] <= 64  # grouped: ground + lights big, the rest in <= 16s
+    for hs in (0, 1, 2):
+        re, be = emu_frames(emu, s, m, cam, w, h, spp, 1, FLAG_PROGRESSIVE, 1, hs, 0)
+        assert re == ro and be.tobytes() == bo.tobytes(), hs
+
+
+def test_grouped_hit_world_breaks_ties_by_lowest_index(emu):
+    """Coincident spheres give equal t: the reference keeps the lowest index (ascending loop, strict t < hitT).  The grouped
+    traversal visits spheres in another order and must still return that one."""
+    import ctypes as C
+    from oracle_lib import MATERIAL_DT, SPHERE_DT
+    emu.emu_hit_spheres.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    emu.emu_hit_spheres.restype = None
+    rng = np.random.default_rng(3)
+    n = 600
+    s = np.zeros(n, SPHERE_DT); m = np.zeros(n, MATERIAL_DT)
+    s["cx"] = rng.uniform(-20, 20, n); s["cy"] = rng.uniform(-1, 1, n); s["cz"] = rng.uniform(-20, 20, n)
+    s["radius"] = rng.uniform(0.3, 0.5, n)
+    dup = rng.permutation(n)[:200]                      # 100 pairs of coincident spheres, far apart in index
+    for a, b in zip(dup[:100], dup[100:]):
+        s[b] = s[a]
+    s["invRadius"] = 1.0 / s["radius"]
+    k = 20000
+    tgt = rng.integers(0, n, k)
+    o = np.stack([rng.uniform(-25, 25, k), rng.uniform(3, 8, k), rng.uniform(-25, 25, k)], 1).astype(np.float32)
+    c = np.stack([s["cx"][tgt], s["cy"][tgt], s["cz"][tgt]], 1)
+    d = c + rng.normal(0, 0.2, (k, 3)) - o
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d = (d / np.linalg.norm(d.astype(np.float64), axis=1, keepdims=True)).astype(np.float32)
+    rays = np.concatenate([o, d], 1).astype(np.float32)
+    out = []
+    for hs in (0, 1):
+        ids, ts = np.empty(k, np.int32), np.empty(k, np.float32)
+        emu.emu_hit_spheres(s.ctypes.data, m.ctypes.data, n, hs, rays.ctypes.data, k, ids.ctypes.data, ts.ctypes.data)
+        out.append((ids, ts))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
+    hit_dups = np.isin(out[1][0], dup).sum()
+    assert hit_dups > 1000  # the duplicated spheres are hit often, so the tie rule is exercised

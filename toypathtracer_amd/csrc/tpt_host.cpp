@@ -52,7 +52,9 @@ struct Context {
         char* stage = nullptr; // pinned
         size_t cap = 0, bytes = 0;
         size_t offSph4 = 0, offInvR = 0, offMats = 0, offLights = 0;
+        size_t offGPairs = 0, offGSph = 0, offGId = 0, offBSph = 0, offBId = 0; // grouped representation (large scenes)
         int nSpheres = 0, nPairs = 0, nLights = 0;
+        int nGroups = 0, nGroupPairs = 0, nBig = 0;
         hipEvent_t evUploaded = nullptr;
         hipStream_t uploadStream = nullptr;
         bool copyEnqueued = false, copyDone = false;
@@ -64,6 +66,7 @@ struct Context {
     int spp = 4;                     // DO_SAMPLES_PER_PIXEL, Config.h:22
     int seedMode = SEED_PER_PIXEL;
     int foldMode = FOLD_RECURSIVE;
+    int allowGroups = 1; // hitSpheres variant 2 = two-phase, brute force even for large scenes
     int hs = HS_TWO_PHASE, persist = 3, ldsScene = -1; // persist 3 = path queues (falls back to 1 where they do not apply)
     int stripeRows = 0, numParts = 1, part = 0;
     int maxBlocksPerCU = 0, chunkOverride = 0; // tuning knobs (env TPT_MAX_BLOCKS_PER_CU, TPT_CHUNK)
@@ -183,8 +186,14 @@ int stageScene()
     Context::SceneSet& S = g.sets[g.pendingSet];
     const size_t bPairs = P.pairs.size() * sizeof(float), bSph4 = P.sph4.size() * sizeof(f4), bInvR = P.invR.size() * sizeof(float),
                  bMats = P.mats.size() * sizeof(f4), bLights = P.lights.size() * sizeof(f4);
+    const bool grouped = g.allowGroups && P.nGroups > 0;
+    const size_t bGPairs = grouped ? P.gpairs.size() * sizeof(float) : 0, bGSph = grouped ? P.gsph.size() * sizeof(f4) : 0,
+                 bGId = grouped ? P.gid.size() * sizeof(int) : 0, bBSph = grouped ? P.bsph.size() * sizeof(f4) : 0,
+                 bBId = grouped ? P.bid.size() * sizeof(int) : 0;
     const size_t offSph4 = align256(bPairs), offInvR = offSph4 + align256(bSph4), offMats = offInvR + align256(bInvR),
-                 offLights = offMats + align256(bMats), total = offLights + align256(bLights + 32);
+                 offLights = offMats + align256(bMats), offGPairs = offLights + align256(bLights + 32),
+                 offGSph = offGPairs + align256(bGPairs), offGId = offGSph + align256(bGSph), offBSph = offGId + align256(bGId),
+                 offBId = offBSph + align256(bBSph), total = offBId + align256(bBId + 32);
     if (!S.evUploaded) HIPCHK(hipEventCreateWithFlags(&S.evUploaded, kOrderingEvent));
     // the previous copy out of this staging blob (kSceneSets uploads ago) must have left the host before we overwrite it:
     // only ever waits when the host has run more than 16 animated frames ahead of the GPU
@@ -204,9 +213,18 @@ int stageScene()
     memcpy(S.stage + offInvR, P.invR.data(), bInvR);
     memcpy(S.stage + offMats, P.mats.data(), bMats);
     if (bLights) memcpy(S.stage + offLights, P.lights.data(), bLights);
-    S.bytes = offLights + bLights;
+    if (grouped) {
+        memcpy(S.stage + offGPairs, P.gpairs.data(), bGPairs);
+        memcpy(S.stage + offGSph, P.gsph.data(), bGSph);
+        memcpy(S.stage + offGId, P.gid.data(), bGId);
+        if (bBSph) memcpy(S.stage + offBSph, P.bsph.data(), bBSph);
+        if (bBId) memcpy(S.stage + offBId, P.bid.data(), bBId);
+    }
+    S.bytes = offBId + bBId;
     S.offSph4 = offSph4; S.offInvR = offInvR; S.offMats = offMats; S.offLights = offLights;
+    S.offGPairs = offGPairs; S.offGSph = offGSph; S.offGId = offGId; S.offBSph = offBSph; S.offBId = offBId;
     S.nSpheres = P.nSpheres; S.nPairs = P.nPairs; S.nLights = P.nLights;
+    S.nGroups = grouped ? P.nGroups : 0; S.nGroupPairs = grouped ? P.nGroupPairs : 0; S.nBig = grouped ? P.nBig : 0;
     S.copyEnqueued = false; S.copyDone = false; S.uploadStream = nullptr;
     g.sceneDirty = false;
     return 0;
@@ -233,6 +251,14 @@ SceneView deviceView()
     sv.nSpheres = S->nSpheres;
     sv.nPairs = S->nPairs;
     sv.nLights = S->nLights;
+    sv.gpairs = reinterpret_cast<const float*>(S->dev + S->offGPairs);
+    sv.gsph = reinterpret_cast<const f4*>(S->dev + S->offGSph);
+    sv.gid = reinterpret_cast<const int*>(S->dev + S->offGId);
+    sv.bsph = reinterpret_cast<const f4*>(S->dev + S->offBSph);
+    sv.bid = reinterpret_cast<const int*>(S->dev + S->offBId);
+    sv.nGroups = S->nGroups;
+    sv.nGroupPairs = S->nGroupPairs;
+    sv.nBig = S->nBig;
     return sv;
 }
 
@@ -482,7 +508,12 @@ int tptSetFrameOverlap(int frames)
 
 int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene)
 {
-    g.hs = hitSpheres ? HS_SIMPLE : HS_TWO_PHASE;
+    g.hs = hitSpheres == 1 ? HS_SIMPLE : HS_TWO_PHASE;
+    const int allow = hitSpheres == 2 ? 0 : 1;
+    if (allow != g.allowGroups) {
+        g.allowGroups = allow;
+        g.sceneDirty = true; // the staged scene set carries (or not) the grouped arrays
+    }
     g.persist = persistent < 0 ? 0 : (persistent > 3 ? 3 : persistent);
     g.ldsScene = ldsScene < 0 ? -1 : (ldsScene ? 1 : 0);
     return 0;
@@ -600,6 +631,7 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
     const int nPad = a.scene.nPairs * 2;
     // (20 B per padded sphere + 48 B of material per sphere; 46 spheres: 3.2 KB, fits up to ~600 spheres in 40 KB)
     bool ldsScene = g.ldsScene < 0 ? ((size_t)nPad * 20 + (size_t)a.scene.nSpheres * 48 <= 40960) : (g.ldsScene != 0);
+    if (a.scene.nGroups > 0) ldsScene = false; // the LDS-staging kernels are built without the grouped traversal
     // bounce stack: persistent kernel keeps the first levels in LDS and spills the rare deep ones to global memory;
     // the thread-per-pixel kernel (huge grids) keeps all of it in LDS
     a.ldsStackLevels = (g.persist && g.foldMode == FOLD_RECURSIVE) ? g.ldsStackLevels : TPT_MAX_DEPTH;
@@ -999,7 +1031,7 @@ int tptTestHitSpheres(int hitSpheres, const float* rays, int* outId, float* outT
     KernelArgs a;
     memset(&a, 0, sizeof(a));
     a.scene = deviceView();
-    HIPCHK(tptLaunchHitTest(a, hitSpheres ? HS_SIMPLE : HS_TWO_PHASE, dr, di, dt, n, g.stream));
+    HIPCHK(tptLaunchHitTest(a, hitSpheres == 1 ? HS_SIMPLE : HS_TWO_PHASE, dr, di, dt, n, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     HIPCHK(hipMemcpy(outId, di, sizeof(int) * n, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(outT, dt, sizeof(float) * n, hipMemcpyDeviceToHost));

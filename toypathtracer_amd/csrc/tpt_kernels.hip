@@ -161,6 +161,7 @@ template <int HS, int FOLD, bool PERSIST, bool LDS_SCENE>
 __global__ void __launch_bounds__(TPT_BLOCK, TPT_MIN_WAVES_PER_SIMD) __attribute__((amdgpu_num_vgpr(56)))
 tptTraceKernel(const KernelArgs a)
 {
+    constexpr int HSX = (HS == HS_TWO_PHASE && !LDS_SCENE) ? HS_TWO_PHASE_GROUPS : HS; // grouped scenes are never LDS-staged
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // ---- carve LDS (every offset a multiple of 16)
     const int nPad = a.scene.nPairs * 2;
@@ -213,7 +214,7 @@ tptTraceKernel(const KernelArgs a)
             laneBeginPixel(L, fc, x, localRowToGlobal(a, ly), ly * fc.width + x, true);
         }
         while (L.active) {
-            if (laneStep<HS, FOLD>(L, sv, fc, stack)) {
+            if (laneStep<HSX, FOLD>(L, sv, fc, stack)) {
                 storeColour(a, L);
                 if (rowSerial && L.x + 1 < fc.width) {
                     laneBeginPixel(L, fc, L.x + 1, L.y, L.pix + 1, false);
@@ -266,7 +267,7 @@ tptTraceKernel(const KernelArgs a)
             }
             if (__ballot(L.active) == 0ull) break;
             if (L.active) {
-                if (laneStep<HS, FOLD>(L, sv, fc, stack)) {
+                if (laneStep<HSX, FOLD>(L, sv, fc, stack)) {
                     storeColour(a, L);
                     if (rowSerial && L.x + 1 < fc.width) {
                         laneBeginPixel(L, fc, L.x + 1, L.y, L.pix + 1, false);
@@ -471,7 +472,7 @@ __global__ void __launch_bounds__(TPT_SORT_T) tptTraceSortedKernel(const KernelA
         if (L.active) {
             TPT_STAT(ST_STEP);
             if (L.needCamera) laneCamera<FOLD>(L, fc);
-            id = hitSpheres<HS_TWO_PHASE>(sv, L.orig, L.dir, TPT_MIN_T, TPT_MAX_T, t);
+            id = hitSpheres<LDS_SCENE ? HS_TWO_PHASE : HS_TWO_PHASE_GROUPS>(sv, L.orig, L.dir, TPT_MIN_T, TPT_MAX_T, t);
             L.rays++;
         }
         // ---- (4) classify; per-wave class histogram, 10 bits per class, one LDS word per wave
@@ -903,7 +904,7 @@ tptTraceQueueKernel(const KernelArgs a)
                 if (pending) {
                     TPT_STAT(ST_STEP);
                     float t;
-                    const int id = hitSpheres<HS_TWO_PHASE>(sv, L.orig, L.dir, TPT_MIN_T, TPT_MAX_T, t);
+                    const int id = hitSpheres<LDS_SCENE ? HS_TWO_PHASE : HS_TWO_PHASE_GROUPS>(sv, L.orig, L.dir, TPT_MIN_T, TPT_MAX_T, t);
                     myRays++;
                     if (L.kind == KIND_SHADOW) {
                         (void)lanePost<FOLD_RECURSIVE>(L, id, t, sv, fc, stack); // Test.cpp:123-132, then next light or bounce
@@ -1180,6 +1181,6 @@ hipError_t tptLaunchHitTest(const KernelArgs& a, int hs, const float* rays, int*
     if (hs == HS_SIMPLE)
         hipLaunchKernelGGL(tptHitTestKernel<HS_SIMPLE>, dim3((n + 255) / 256), dim3(256), 0, stream, a, rays, outId, outT, n);
     else
-        hipLaunchKernelGGL(tptHitTestKernel<HS_TWO_PHASE>, dim3((n + 255) / 256), dim3(256), 0, stream, a, rays, outId, outT, n);
+        hipLaunchKernelGGL(tptHitTestKernel<HS_TWO_PHASE_GROUPS>, dim3((n + 255) / 256), dim3(256), 0, stream, a, rays, outId, outT, n);
     return hipGetLastError();
 }

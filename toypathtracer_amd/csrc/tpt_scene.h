@@ -9,6 +9,7 @@
 #include "tpt_trace.h"
 #include <math.h>
 #include <string.h>
+#include <algorithm>
 #include <vector>
 
 namespace tpt {
@@ -117,7 +118,125 @@ struct PackedScene {
     std::vector<f4> lights;   // [nLights][2]
     std::vector<int> emissive; // ids, as GetSceneDesc exports them (Test.cpp:382)
     int nSpheres = 0, nPairs = 0, nLights = 0;
+    // grouped representation for large scenes (SceneView, hitSpheresGrouped); nGroups == 0: not grouped
+    std::vector<float> gpairs; // [nGroupPairs][8] bounding spheres of the groups, pair-record format
+    std::vector<f4> gsph;      // [nGroups * TPT_GROUP] members {centre, r^2}, padding r^2 = -inf
+    std::vector<int> gid;      // original sphere index of every member slot, padding -1
+    std::vector<f4> bsph;      // the big spheres {centre, r^2} ...
+    std::vector<int> bid;      // ... and their original indices (ascending)
+    int nGroups = 0, nGroupPairs = 0, nBig = 0;
 };
+
+// Large scenes: compact groups of <= TPT_GROUP small spheres (median splits) with bounding spheres, big spheres kept apart.
+// Leaves P ungrouped (nGroups = 0) when the scene is small or a bound would be too loose for the filter's slack
+// (tpt_trace.h, hitSpheresGrouped).
+inline void buildGroups(const std::vector<SpherePOD>& S, PackedScene& P)
+{
+    P.gpairs.clear(); P.gsph.clear(); P.gid.clear(); P.bsph.clear(); P.bid.clear();
+    P.nGroups = P.nGroupPairs = P.nBig = 0;
+    const int n = (int)S.size();
+    if (n < TPT_GROUP_MIN_SPHERES) return;
+    std::vector<float> radii(n);
+    for (int i = 0; i < n; ++i) {
+        radii[i] = fabsf(S[i].radius);
+        if (!(radii[i] < 1e30f) || !(fabsf(S[i].cx) < 1e30f) || !(fabsf(S[i].cy) < 1e30f) || !(fabsf(S[i].cz) < 1e30f)) return; // inf / NaN: flat
+    }
+    std::vector<float> sorted = radii;
+    std::nth_element(sorted.begin(), sorted.begin() + n / 2, sorted.end());
+    const float median = sorted[n / 2];
+    std::vector<int> small, big;
+    for (int i = 0; i < n; ++i) (radii[i] > 3.0f * median ? big : small).push_back(i);
+    if ((int)big.size() > 32 || (int)small.size() < TPT_GROUP) return;
+    // kd-style median splits (widest axis of the centres' box) down to <= TPT_GROUP members: compact groups whatever
+    // the distribution.  `order` ends up holding the groups back to back, `cuts` their boundaries.
+    std::vector<int> order = small;
+    std::vector<std::pair<int, int>> work, leaves; // [first, last) ranges of `order`
+    work.push_back(std::make_pair(0, (int)order.size()));
+    while (!work.empty()) {
+        const std::pair<int, int> rg = work.back();
+        work.pop_back();
+        const int cntR = rg.second - rg.first;
+        if (cntR <= TPT_GROUP) {
+            leaves.push_back(rg);
+            continue;
+        }
+        double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+        for (int k = rg.first; k < rg.second; ++k) {
+            const double c[3] = {S[order[k]].cx, S[order[k]].cy, S[order[k]].cz};
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], c[a]); hi[a] = std::max(hi[a], c[a]); }
+        }
+        int axis = 0;
+        for (int a = 1; a < 3; ++a) if (hi[a] - lo[a] > hi[axis] - lo[axis]) axis = a;
+        // left part: a multiple of TPT_GROUP nearest to half, so the leaves come out full
+        int left = ((cntR / 2 + TPT_GROUP / 2) / TPT_GROUP) * TPT_GROUP;
+        if (left <= 0 || left >= cntR) left = cntR / 2;
+        auto key = [&](int i) { return axis == 0 ? S[i].cx : axis == 1 ? S[i].cy : S[i].cz; };
+        std::nth_element(order.begin() + rg.first, order.begin() + rg.first + left, order.begin() + rg.second,
+                         [&](int x, int y) { return key(x) < key(y) || (key(x) == key(y) && x < y); });
+        work.push_back(std::make_pair(rg.first, rg.first + left));
+        work.push_back(std::make_pair(rg.first + left, rg.second));
+    }
+    std::sort(leaves.begin(), leaves.end());
+    // bounds; a group whose bound is too loose for the filter's slack (rho > 64: tiny spheres far apart) is dissolved
+    // into the flat list of big spheres
+    const float negInf = u2f(0xff800000u), posInf = u2f(0x7f800000u);
+    struct GroupRec { float C[3]; double R; std::vector<int> mem; };
+    std::vector<GroupRec> groups;
+    for (size_t l = 0; l < leaves.size(); ++l) {
+        GroupRec G;
+        for (int k = leaves[l].first; k < leaves[l].second; ++k) G.mem.push_back(order[k]);
+        std::sort(G.mem.begin(), G.mem.end());
+        double c[3] = {0, 0, 0};
+        for (int i : G.mem) { c[0] += S[i].cx; c[1] += S[i].cy; c[2] += S[i].cz; }
+        for (int a = 0; a < 3; ++a) G.C[a] = (float)(c[a] / (double)G.mem.size()); // the centre the kernel will see
+        double R = 0, rho = 0;
+        for (int i : G.mem) {
+            const double dxx = (double)S[i].cx - G.C[0], dyy = (double)S[i].cy - G.C[1], dzz = (double)S[i].cz - G.C[2];
+            const double a = sqrt(dxx * dxx + dyy * dyy + dzz * dzz), r = radii[i];
+            R = std::max(R, a + r);
+            rho = std::max(rho, r > 0 ? a / r : 1e300);
+        }
+        if (!(rho <= 64.0)) {
+            for (int i : G.mem) big.push_back(i);
+            continue;
+        }
+        G.R = R * 1.00001;
+        groups.push_back(G);
+    }
+    if ((int)big.size() > 64 || groups.empty()) return;
+    std::sort(big.begin(), big.end());
+    const int nGroups = (int)groups.size();
+    const int nGroupPairs = (nGroups + 1) / 2;
+    std::vector<float> gpairs((size_t)nGroupPairs * 8, 0.0f);
+    std::vector<f4> gsph((size_t)nGroups * TPT_GROUP);
+    std::vector<int> gid((size_t)nGroups * TPT_GROUP, -1);
+    for (size_t k = 0; k < gsph.size(); ++k) { f4 v = {0, 0, 0, negInf}; gsph[k] = v; }
+    for (int g = 0; g < nGroupPairs * 2; ++g) {
+        float* rec = &gpairs[(size_t)(g / 2) * 8];
+        if (g >= nGroups) { // padding group: never a candidate
+            rec[6 + (g & 1)] = posInf;
+            continue;
+        }
+        const GroupRec& G = groups[g];
+        for (size_t k = 0; k < G.mem.size(); ++k) {
+            const int i = G.mem[k];
+            f4 v = {S[i].cx, S[i].cy, S[i].cz, S[i].radius * S[i].radius}; // r^2 exactly as packScene / Test.cpp:329
+            gsph[(size_t)g * TPT_GROUP + k] = v;
+            gid[(size_t)g * TPT_GROUP + k] = i;
+        }
+        rec[0 + (g & 1)] = G.C[0];
+        rec[2 + (g & 1)] = G.C[1];
+        rec[4 + (g & 1)] = G.C[2];
+        rec[6 + (g & 1)] = (float)(-(G.R * G.R) * (1.0 + 1.0 / 4096.0));
+    }
+    P.gpairs.swap(gpairs); P.gsph.swap(gsph); P.gid.swap(gid);
+    for (int i : big) {
+        f4 v = {S[i].cx, S[i].cy, S[i].cz, S[i].radius * S[i].radius};
+        P.bsph.push_back(v);
+        P.bid.push_back(i);
+    }
+    P.nGroups = nGroups; P.nGroupPairs = nGroupPairs; P.nBig = (int)big.size();
+}
 
 // UpdateTest's scene half (Test.cpp:321-339): derived data, SoA, emissive list -- in kernel layout.
 inline void packScene(std::vector<SpherePOD>& S, const std::vector<MaterialPOD>& M, PackedScene& P)
@@ -169,6 +288,7 @@ inline void packScene(std::vector<SpherePOD>& S, const std::vector<MaterialPOD>&
         rec[6 + (i & 1)] = (float)(-(double)sq * (1.0 + 1.0 / 65536.0));
     }
     P.nLights = (int)P.emissive.size();
+    buildGroups(S, P);
 }
 
 inline SceneView viewOf(const PackedScene& P)
@@ -182,6 +302,14 @@ inline SceneView viewOf(const PackedScene& P)
     sv.nSpheres = P.nSpheres;
     sv.nPairs = P.nPairs;
     sv.nLights = P.nLights;
+    sv.gpairs = P.gpairs.data();
+    sv.gsph = P.gsph.data();
+    sv.gid = P.gid.data();
+    sv.bsph = P.bsph.data();
+    sv.bid = P.bid.data();
+    sv.nGroups = P.nGroups;
+    sv.nGroupPairs = P.nGroupPairs;
+    sv.nBig = P.nBig;
     return sv;
 }
 

@@ -40,7 +40,7 @@ struct alignas(16) f4 {
 enum { MAT_LAMBERT = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2 }; // Test.cpp:38
 enum { SEED_ROW_SERIAL = 0, SEED_PER_PIXEL = 1 };            // Test.cpp:280 / ComputeShader.hlsl:380
 enum { FOLD_RECURSIVE = 0, FOLD_FORWARD = 1 };               // Test.cpp:216 nesting / front-to-back
-enum { HS_TWO_PHASE = 0, HS_SIMPLE = 1 };
+enum { HS_TWO_PHASE = 0, HS_SIMPLE = 1, HS_TWO_PHASE_GROUPS = 2 }; // _GROUPS: two-phase that also understands grouped scenes
 
 // Camera: byte-for-byte the reference layout (Maths.h:444-449, 88 B) so GetSceneDesc can memcpy it.
 struct CameraPOD {
@@ -62,7 +62,19 @@ struct SceneView {
     const f4* mats;
     const f4* lights;
     int nSpheres, nPairs, nLights;
+    // Grouped scenes (packScene builds them for >= TPT_GROUP_MIN_SPHERES spheres; nGroups == 0: flat brute force).
+    // Small spheres are split (median cuts) into compact groups of <= TPT_GROUP; `gpairs` holds the groups'
+    // bounding spheres in the pair-record format of phase 1, `gsph`/`gid` the members {centre, r^2} and their
+    // original indices (padding: r^2 = -inf, id -1); the few big spheres (ground, lights) stay in a flat list.
+    const float* gpairs;
+    const f4* gsph;
+    const int* gid;
+    const f4* bsph;
+    const int* bid;
+    int nGroups, nGroupPairs, nBig;
 };
+#define TPT_GROUP 16
+#define TPT_GROUP_MIN_SPHERES 256
 
 struct FrameConsts {
     CameraPOD cam;
@@ -189,6 +201,21 @@ TPT_HD void phase1Pair(PairPtr rec, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f 
     m = alignbit(m, f2u(discr[1]), 31);
 }
 
+// Candidate mask of up to 32 pair records (64 spheres): sphere k of the chunk sits at bit (63 - k).
+TPT_HD uint64_t phase1Chunk(PairPtr rec, int cnt, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f dz)
+{
+    const int c0 = cnt < 16 ? cnt : 16, c1 = cnt - c0;
+    uint32_t m0 = 0, m1 = 0;
+#pragma unroll 4
+    for (int p = 0; p < c0; ++p) phase1Pair(rec + p * 8, ox, oy, oz, dx, dy, dz, m0);
+#pragma unroll 4
+    for (int p = 0; p < c1; ++p) phase1Pair(rec + (16 + p) * 8, ox, oy, oz, dx, dy, dz, m1);
+    // candidates = sign bit clear (value >= +0)
+    uint32_t cand0 = ~m0 << (32 - 2 * c0);
+    uint32_t cand1 = c1 ? (~m1 << (32 - 2 * c1)) : 0u;
+    return ((uint64_t)cand0 << 32) | cand1;
+}
+
 // Measured alternatives (profiles/r01/run8*.log, run9*.log): scalar VOP2 arithmetic instead of packed VOP3P is
 // a wash (packed ops issue at half rate on gfx950); software-pipelining the scalar loads one 4-pair block
 // ahead costs 64 more SGPRs, spills, and is 8-15 % slower than letting 3-4 waves per SIMD hide the latency.
@@ -202,42 +229,7 @@ TPT_HD int hitSpheresTwoPhase(const SceneView& sv, f3 o, f3 d, float tMin, float
     for (int pb = 0; pb < sv.nPairs; pb += 32) { // chunks of 64 spheres
         int cnt = sv.nPairs - pb;
         if (cnt > 32) cnt = 32;
-        const int c0 = cnt < 16 ? cnt : 16, c1 = cnt - c0;
-        const PairPtr rec = pairPtr(sv.pairs + (size_t)pb * 8);
-        uint32_t m0 = 0, m1 = 0;
-#pragma unroll 4
-        for (int p = 0; p < c0; ++p) phase1Pair(rec + p * 8, ox, oy, oz, dx, dy, dz, m0);
-#pragma unroll 4
-        for (int p = 0; p < c1; ++p) phase1Pair(rec + (16 + p) * 8, ox, oy, oz, dx, dy, dz, m1);
-        // candidates = sign bit clear (discr >= +0); sphere (pb*2 + k) sits at bit (63-k)
-        uint32_t cand0 = ~m0 << (32 - 2 * c0);
-        uint32_t cand1 = c1 ? (~m1 << (32 - 2 * c1)) : 0u;
-        uint64_t cand = ((uint64_t)cand0 << 32) | cand1;
-#if defined(TPT_PHASE2_PREFETCH)
-        // software pipeline: the {centre, r^2} record of the NEXT candidate is fetched while this one is tested
-        if (cand) {
-            int k = __builtin_clzll(cand);
-            cand &= ~(0x8000000000000000ull >> k);
-            int i = pb * 2 + k;
-            f4 rec = sv.sph4[i];
-            for (;;) {
-                int iNext = i;
-                f4 recNext = rec;
-                const bool more = cand != 0;
-                if (more) {
-                    int kn = __builtin_clzll(cand);
-                    cand &= ~(0x8000000000000000ull >> kn);
-                    iNext = pb * 2 + kn;
-                    recNext = sv.sph4[iNext];
-                }
-                TPT_STAT(ST_PHASE2);
-                testSphere(rec, i, o, d, tMin, hitT, id);
-                if (!more) break;
-                i = iNext;
-                rec = recNext;
-            }
-        }
-#else
+        uint64_t cand = phase1Chunk(pairPtr(sv.pairs + (size_t)pb * 8), cnt, ox, oy, oz, dx, dy, dz);
         while (cand) {
             int k = __builtin_clzll(cand);
             cand &= ~(0x8000000000000000ull >> k);
@@ -245,7 +237,85 @@ TPT_HD int hitSpheresTwoPhase(const SceneView& sv, f3 o, f3 d, float tMin, float
             TPT_STAT(ST_PHASE2);
             testSphere(sv.sph4[i], i, o, d, tMin, hitT, id);
         }
-#endif
+    }
+    outT = hitT;
+    return id;
+}
+
+// ---------------------------------------------------------------- grouped HitWorld (large scenes)
+// Same result as the flat loops, sphere for sphere: every sphere the reference's test accepts is still tested with
+// the reference's arithmetic (testSphere's), only the ORDER differs -- so the winner among equal t is chosen
+// explicitly (lowest original index, what ascending order + strict t < hitT gives the reference).
+TPT_HD void testSphereTie(f4 s, int i, f3 o, f3 d, float tMin, float& hitT, int& id)
+{
+    float coX = s.x - o.x;
+    float coY = s.y - o.y;
+    float coZ = s.z - o.z;
+    float nb = coX * d.x + coY * d.y + coZ * d.z;
+    float c = coX * coX + coY * coY + coZ * coZ - s.w;
+    float discr = nb * nb - c;
+    if (discr > 0) {
+        float discrSq = tsqrt(discr);
+        float t = nb - discrSq;
+        if (t <= tMin) t = nb + discrSq;
+        if (t > tMin && (t < hitT || (t == hitT && i < id))) {
+            id = i;
+            hitT = t;
+        }
+    }
+}
+TPT_HD float fma1(float a, float b, float c)
+{
+    return __builtin_fmaf(a, b, c);
+}
+// per-lane version of phase1Pair's conservative filter for one sphere (dk = direction scaled by TPT_P1_K)
+TPT_HD bool memberFilter(f4 s, f3 o, f3 dk)
+{
+    float coX = s.x - o.x;
+    float coY = s.y - o.y;
+    float coZ = s.z - o.z;
+    float nb = fma1(coZ, dk.z, fma1(coY, dk.y, coX * dk.x));
+    float e = fma1(coZ, coZ, fma1(coY, coY, fma1(coX, coX, s.w * -1.0000152587890625f))); // S - r^2 (1 + 2^-16); padding: +inf
+    float v = fma1(nb, nb, -e);
+    return (f2u(v) >> 31) == 0u;
+}
+// Group bounds are looser than sphere bounds on purpose.  A member the reference accepts lies within
+// sqrt(r^2 + 13 u (S + r^2)) of the ray's line (the reference's own rounding error), and its centre at most a = |c - C|
+// from the group centre C: against R = max(a + r) the squared distance to C overshoots R^2 by up to
+// 13 u (S_i + r^2)(1 + a / r) <= 26 u (S + R^2)(1 + rho), rho = max a / r.  Together with the filter's own 13 u (S + R^2)
+// that must stay below the slack tau (S + R^2) the filter grants; with the direction scaled by 1 + 2^-13 (square
+// >= 1 + 2^-12) and the record carrying -R^2 (1 + 2^-12), tau = 2^-13 = 2 048 u (same algebra as phase1Pair), i.e.
+// rho <= 77.  packScene groups a scene only if rho <= 64 for every group and rounds R up.
+#define TPT_PG_K 1.0001220703125f /* 1 + 2^-13: (1 + 2^-13)^2 > 1 + 2^-12 */
+TPT_HD int hitSpheresGrouped(const SceneView& sv, f3 o, f3 d, float tMin, float tMax, float& outT)
+{
+    float hitT = tMax;
+    int id = -1;
+    // the big spheres: exact test each (a handful)
+    for (int b = 0; b < sv.nBig; ++b) testSphereTie(sv.bsph[b], sv.bid[b], o, d, tMin, hitT, id);
+    const f3 dk = mk3(d.x * TPT_P1_K, d.y * TPT_P1_K, d.z * TPT_P1_K);
+    const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+    const float gx = d.x * TPT_PG_K, gy = d.y * TPT_PG_K, gz = d.z * TPT_PG_K;
+    const v2f dx = {gx, gx}, dy = {gy, gy}, dz = {gz, gz};
+    for (int pb = 0; pb < sv.nGroupPairs; pb += 32) { // 64 groups per chunk: wave-uniform filter on the bounding spheres
+        int cnt = sv.nGroupPairs - pb;
+        if (cnt > 32) cnt = 32;
+        uint64_t cand = phase1Chunk(pairPtr(sv.gpairs + (size_t)pb * 8), cnt, ox, oy, oz, dx, dy, dz);
+        while (cand) { // per lane: the groups this ray's line touches
+            int k = __builtin_clzll(cand);
+            cand &= ~(0x8000000000000000ull >> k);
+            const int base = (pb * 2 + k) * TPT_GROUP;
+            const f4* mem = sv.gsph + base;
+            uint32_t mm = 0;
+#pragma unroll 4
+            for (int j = 0; j < TPT_GROUP; ++j) mm |= (memberFilter(mem[j], o, dk) ? 1u : 0u) << j;
+            while (mm) {
+                const int j = __builtin_ctz(mm);
+                mm &= mm - 1u;
+                TPT_STAT(ST_PHASE2);
+                testSphereTie(mem[j], sv.gid[base + j], o, d, tMin, hitT, id);
+            }
+        }
     }
     outT = hitT;
     return id;
@@ -255,6 +325,9 @@ template <int HS>
 TPT_HD int hitSpheres(const SceneView& sv, f3 o, f3 d, float tMin, float tMax, float& outT)
 {
     if (HS == HS_SIMPLE) return hitSpheresSimple(sv, o, d, tMin, tMax, outT);
+    // (kernels that stage the scene in LDS are instantiated without the grouped code: such scenes are small and never
+    //  grouped, and the extra registers cost the 46-sphere kernel 4 %)
+    if (HS == HS_TWO_PHASE_GROUPS && sv.nGroups > 0) return hitSpheresGrouped(sv, o, d, tMin, tMax, outT);
     return hitSpheresTwoPhase(sv, o, d, tMin, tMax, outT);
 }
 

@@ -243,7 +243,9 @@ def main():
                               "frac_per_pipeline_slot": valu_tflops * k_ms / p_ms / PEAK_FP32_TFLOPS,
                               "note": "algorithmic flops = rays x 17 flop x spheres (SURVEY 8d: the reference's own per-test count); peak counts "
                                       "FMA as 2 flop.  The exact arithmetic (phase 2 of HitSpheres, Scatter) may not contract to FMA (parity); "
-                                      "phase 1 is a conservative filter and does use FMA (10 packed ops per sphere pair instead of 16)"},
+                                      "phase 1 is a conservative filter and does use FMA (10 packed ops per sphere pair instead of 16)"
+                                      + ("; this scene is traversed through sphere groups, so the figure is the brute-force-EQUIVALENT rate "
+                                         "(most of those tests are never executed)" if (n_spheres >= 256 and args.hit_spheres == 0) else "")},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(width, height, spp)

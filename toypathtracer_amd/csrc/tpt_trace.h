@@ -73,7 +73,9 @@ struct SceneView {
     const int* bid;
     int nGroups, nGroupPairs, nBig;
 };
-#define TPT_GROUP 16
+#ifndef TPT_GROUP
+#define TPT_GROUP 16 /* members per group, <= 32 */
+#endif
 #define TPT_GROUP_MIN_SPHERES 256
 
 struct FrameConsts {

@@ -289,6 +289,34 @@ TPT_HD bool memberFilter(f4 s, f3 o, f3 dk)
 // >= 1 + 2^-12) and the record carrying -R^2 (1 + 2^-12), tau = 2^-13 = 2 048 u (same algebra as phase1Pair), i.e.
 // rho <= 77.  packScene groups a scene only if rho <= 64 for every group and rounds R up.
 #define TPT_PG_K 1.0001220703125f /* 1 + 2^-13: (1 + 2^-13)^2 > 1 + 2^-12 */
+// Per-lane FIFO of up to 8 member slots (16 bits each) in two 64-bit words: exact tests are deferred so that the lanes of
+// a wave run them together (tested right where they are found, 3.5 of 64 lanes were busy per trip on the stress scene).
+struct SlotQueue {
+    uint64_t a, b;
+    int n;
+};
+TPT_HD void sqPush(SlotQueue& q, uint32_t slot)
+{
+    q.b = (q.b << 16) | (q.a >> 48);
+    q.a = (q.a << 16) | (uint64_t)(slot & 0xffffu);
+    q.n++;
+}
+TPT_HD uint32_t sqPop(SlotQueue& q) // most recent first; the order is irrelevant (explicit tie-break)
+{
+    const uint32_t slot = (uint32_t)(q.a & 0xffffull);
+    q.a = (q.a >> 16) | (q.b << 48);
+    q.b >>= 16;
+    q.n--;
+    return slot;
+}
+TPT_HD void sqDrain(SlotQueue& q, const SceneView& sv, f3 o, f3 d, float tMin, float& hitT, int& id)
+{
+    while (q.n > 0) {
+        const uint32_t slot = sqPop(q);
+        TPT_STAT(ST_PHASE2);
+        testSphereTie(sv.gsph[slot], sv.gid[slot], o, d, tMin, hitT, id);
+    }
+}
 TPT_HD int hitSpheresGrouped(const SceneView& sv, f3 o, f3 d, float tMin, float tMax, float& outT)
 {
     float hitT = tMax;
@@ -299,26 +327,52 @@ TPT_HD int hitSpheresGrouped(const SceneView& sv, f3 o, f3 d, float tMin, float 
     const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
     const float gx = d.x * TPT_PG_K, gy = d.y * TPT_PG_K, gz = d.z * TPT_PG_K;
     const v2f dx = {gx, gx}, dy = {gy, gy}, dz = {gz, gz};
-    for (int pb = 0; pb < sv.nGroupPairs; pb += 32) { // 64 groups per chunk: wave-uniform filter on the bounding spheres
-        int cnt = sv.nGroupPairs - pb;
-        if (cnt > 32) cnt = 32;
-        uint64_t cand = phase1Chunk(pairPtr(sv.gpairs + (size_t)pb * 8), cnt, ox, oy, oz, dx, dy, dz);
-        while (cand) { // per lane: the groups this ray's line touches
-            int k = __builtin_clzll(cand);
-            cand &= ~(0x8000000000000000ull >> k);
-            const int base = (pb * 2 + k) * TPT_GROUP;
+    SlotQueue q;
+    q.a = q.b = 0ull;
+    q.n = 0;
+    const bool slots16 = sv.nGroups * TPT_GROUP <= 65536; // else: no deferral (slots would not fit 16 bits)
+    for (int pb0 = 0; pb0 < sv.nGroupPairs; pb0 += 128) {
+        // wave-uniform filter on the bounding spheres of up to 256 groups: four 64-bit candidate masks per lane
+        uint64_t cm0 = 0, cm1 = 0, cm2 = 0, cm3 = 0;
+        {
+            const int left = sv.nGroupPairs - pb0;
+            cm0 = phase1Chunk(pairPtr(sv.gpairs + (size_t)pb0 * 8), left < 32 ? left : 32, ox, oy, oz, dx, dy, dz);
+            if (left > 32) cm1 = phase1Chunk(pairPtr(sv.gpairs + (size_t)(pb0 + 32) * 8), left - 32 < 32 ? left - 32 : 32, ox, oy, oz, dx, dy, dz);
+            if (left > 64) cm2 = phase1Chunk(pairPtr(sv.gpairs + (size_t)(pb0 + 64) * 8), left - 64 < 32 ? left - 64 : 32, ox, oy, oz, dx, dy, dz);
+            if (left > 96) cm3 = phase1Chunk(pairPtr(sv.gpairs + (size_t)(pb0 + 96) * 8), left - 96 < 32 ? left - 96 : 32, ox, oy, oz, dx, dy, dz);
+        }
+        // per lane: ONE loop over the groups this ray's line touches, whichever mask word they sit in (a loop per word
+        // costs the sum of the per-word maxima over the lanes instead of the maximum of the sums)
+        for (;;) {
+            const int sel = cm0 ? 0 : cm1 ? 1 : cm2 ? 2 : 3;
+            const uint64_t w = cm0 ? cm0 : cm1 ? cm1 : cm2 ? cm2 : cm3;
+            if (!w) break;
+            const int k = __builtin_clzll(w);
+            const uint64_t keep = ~(0x8000000000000000ull >> k);
+            cm0 &= sel == 0 ? keep : ~0ull;
+            cm1 &= sel == 1 ? keep : ~0ull;
+            cm2 &= sel == 2 ? keep : ~0ull;
+            cm3 &= sel == 3 ? keep : ~0ull;
+            const int base = ((pb0 + sel * 32) * 2 + k) * TPT_GROUP;
             const f4* mem = sv.gsph + base;
+            TPT_STAT(ST_SPHERELOOP); // profiling build: group visits
             uint32_t mm = 0;
 #pragma unroll 4
             for (int j = 0; j < TPT_GROUP; ++j) mm |= (memberFilter(mem[j], o, dk) ? 1u : 0u) << j;
             while (mm) {
                 const int j = __builtin_ctz(mm);
                 mm &= mm - 1u;
-                TPT_STAT(ST_PHASE2);
-                testSphereTie(mem[j], sv.gid[base + j], o, d, tMin, hitT, id);
+                if (slots16) {
+                    if (q.n == 8) sqDrain(q, sv, o, d, tMin, hitT, id);
+                    sqPush(q, (uint32_t)(base + j));
+                } else {
+                    TPT_STAT(ST_PHASE2);
+                    testSphereTie(mem[j], sv.gid[base + j], o, d, tMin, hitT, id);
+                }
             }
         }
     }
+    sqDrain(q, sv, o, d, tMin, hitT, id);
     outT = hitT;
     return id;
 }

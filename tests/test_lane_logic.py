@@ -115,17 +115,20 @@ def test_two_phase_filter_is_conservative_on_grazing_rays(emu, oracle):
         assert (out[1][0] >= 0).mean() > 0.3  # the generator does produce hits (and near misses)
 
 
-@pytest.mark.parametrize("n", [256, 1000, 4096])
+@pytest.mark.parametrize("n", [256, 1000, 4096, 20000])
 def test_grouped_hit_world_equals_brute_force(emu, oracle, n):
     """Large scenes are traversed through compact groups of <= 16 spheres with bounding spheres: a
     small render of the stress scene must equal the oracle's brute force bit for bit, for the grouped path (hs 0), the
     all-exact loop (hs 1) and the flat two-phase loop (hs 2)."""
     from toypathtracer_amd.scenes import STRESS_CAMERA, stress_scene
-    s, m = stress_scene(n, 64 if n > 256 else 16)
+    s, m = stress_scene(n, 64 if n <= 4096 and n > 256 else (16 if n <= 256 else 160))  # 20000: several 256-group super-chunks
     w, h, spp = 64, 36, 2
     cam = oracle.camera(STRESS_CAMERA["look_from"], STRESS_CAMERA["look_at"], (0, 1, 0), STRESS_CAMERA["vfov"], w / h,
                         STRESS_CAMERA["aperture"], STRESS_CAMERA["focus_dist"])
-    ro, bo = oracle.render(s, m, cam, w, h, spp, 0, seed_mode=1)
+    if n <= 4096:
+        ro, bo = oracle.render(s, m, cam, w, h, spp, 0, seed_mode=1)
+    else:  # the oracle holds at most 4104 spheres: the all-exact loop (checked against it above) is the reference here
+        ro, bo = emu_frames(emu, s, m, cam, w, h, spp, 1, FLAG_PROGRESSIVE, 1, 1, 0)
     import ctypes as C
     info = np.zeros(3, np.int32)
     emu.emu_group_info.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]

@@ -230,6 +230,11 @@ def main():
             "pipeline_Mray_s": rays_per_launch * world / (p_ms * 1e-3) / 1e6,
             "roofline": {"bound": "hbm", "achieved": hbm_write_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": hbm_write_gbs / PEAK_HBM_GBS, "traffic": traffic,
+                         "traffic_note": ("bytes per trace launch on the L2's fabric side (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes, "
+                                          "profiles/pmc_traffic.json; Infinity-Cache hits included).  Beyond the 16 B/pixel image write it is the "
+                                          "per-path bounce stack and colour sums of the bit-exact recursive fold (16-B records, paths migrate between "
+                                          "waves so they cannot live in a wave's LDS slice), not re-reads of the image; 13 % of HBM peak at this rate"
+                                          if args.persistent == 3 else "see profiles/pmc_traffic.json"),
                          "achieved_read_plus_write": 2 * hbm_write_gbs,
                          "achieved_per_pipeline_slot": hbm_write_gbs * k_ms / p_ms, "launch_ms_avg": k_ms, "launches": launches,
                          "note": "north_star's HBM-write roofline (W*H*16 B per frame / average launch duration); up to %d launches share "

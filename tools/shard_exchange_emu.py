@@ -23,6 +23,8 @@ dev = torch.device("cuda", 0)
 for n in [int(v) for v in os.environ.get("TPT_EMU_N", "1,2,4,8").split(",")]:
     api.set_row_shard(8, n, 0)
     sf = ShardedFrame(w, h, 8, 0, n, dev, FakeDist() if n > 1 else None)
+    if os.environ.get("TPT_EMU_NOASSEMBLE") and n > 1:  # experiment: how much of the period is the comm stream's chain?
+        sf._collect = lambda k, sf=sf: (sf.dist.gather(sf.send[k], sf.recv_list[k], dst=0), setattr(sf, "last", k))
     api.set_stream(sf.render_stream.cuda_stream)
     api.set_ray_counter(sf.ray_counter.data_ptr())
     MIRROR = os.environ.get("TPT_EMU_MIRROR", "1") == "1"

@@ -20,7 +20,9 @@ def run(w, h, spp, frames, persist, overlap, animate=False):
 
 bad = 0
 t0 = time.time()
+SCALE = int(os.environ.get("SOAK_SCALE", "1"))  # multiply the frame counts
 for (w, h, spp, frames) in [(1280, 720, 4, 150), (640, 360, 1, 300), (203, 117, 3, 400), (64, 8, 16, 400), (1920, 1080, 2, 40), (333, 5, 2, 300)]:
+    frames *= SCALE
     ref = run(w, h, spp, frames, 1, 8)
     for ov in (16, 16, 5, 1):
         got = run(w, h, spp, frames if ov > 1 else min(frames, 60), 3, ov)

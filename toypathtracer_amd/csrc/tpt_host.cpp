@@ -428,6 +428,8 @@ int tptShutdown(void)
     g.inited = false;
     g.updated = false;
     g.occCache.clear();
+    g.mirror = nullptr; g.mirrorCounter = nullptr; g.uploadSrc = nullptr;
+    g.orderDone = true; g.orderStream = nullptr; g.oldestPending = 0; g.frameSeq = 0;
     return 0;
 }
 

@@ -172,3 +172,15 @@ def test_grouped_hit_world_breaks_ties_by_lowest_index(emu):
     assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1].view(np.uint32), out[1][1].view(np.uint32))
     hit_dups = np.isin(out[1][0], dup).sum()
     assert hit_dups > 1000  # the duplicated spheres are hit often, so the tie rule is exercised
+
+
+def test_filters_never_miss_in_an_adversarial_search(tmp_path):
+    """tests/adversarial_filter.cpp: 60 M near-tangent ray/sphere configurations over six decades of scale (2 G were run
+    once by hand: 0 misses); neither the sphere filter nor the group-bound filter may reject what the reference accepts."""
+    import subprocess
+    exe = str(tmp_path / "adv")
+    subprocess.check_call(["g++", "-O2", "-fopenmp", "-std=c++17", "-ffp-contract=off", "-Wno-unknown-pragmas",
+                           "-I", os.path.join(ROOT, "toypathtracer_amd", "csrc"), os.path.join(ROOT, "tests", "adversarial_filter.cpp"), "-o", exe])
+    out = subprocess.run([exe, "60000000"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout
+    assert "FILTER MISSES 0" in out.stdout and "GROUP FILTER MISSES 0" in out.stdout

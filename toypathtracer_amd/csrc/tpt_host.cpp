@@ -585,6 +585,226 @@ int tptUpdate(float time, int frameCount, int screenWidth, int screenHeight, uns
     return 0;
 }
 
+// ---------------------------------------------------------------- one frame: plan, buffers, enqueue
+} // extern "C"
+
+namespace {
+
+// Everything decided about a frame before anything is enqueued.
+struct FramePlan {
+    KernelArgs a;
+    bool rowSerial = false, sorted = false, queued = false, ldsScene = false, useOrder = false;
+    size_t lds = 0;
+    int occ = 0, threadsPerBlock = 0, blocks = 0;
+    int nOverlap = 1, slot = 0; // frames in flight allowed / this frame's slot (trace stream, colour buffer, ...)
+};
+
+// Grow one of the per-slot device buffers (colour, bounce stack, path state).  Nothing may still use the old one.
+template <class T>
+int growSlotBuffer(T*& p, size_t& capBytes, size_t needBytes, int slot)
+{
+    if (needBytes <= capBytes) return 0;
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipStreamSynchronize(g.traceStream[slot]));
+    if (p) HIPCHK(hipFree(p));
+    p = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&p), needBytes));
+    capBytes = needBytes;
+    return 0;
+}
+
+// Which kernel runs this frame, how much LDS it takes, how many workgroups fit on a CU.
+int chooseKernel(FramePlan& P)
+{
+    KernelArgs& a = P.a;
+    P.rowSerial = g.seedMode == SEED_ROW_SERIAL;
+    // LDS scene staging: default when {centre, r^2} + 1/r (20 B per padded sphere) + 48 B of material per sphere fit in
+    // 40 KB (46 spheres: 3.2 KB; up to ~600 spheres)
+    const int nPad = a.scene.nPairs * 2;
+    P.ldsScene = g.ldsScene < 0 ? ((size_t)nPad * 20 + (size_t)a.scene.nSpheres * 48 <= 40960) : (g.ldsScene != 0);
+    if (a.scene.nGroups > 0) P.ldsScene = false; // the LDS-staging kernels are built without the grouped traversal
+    // bounce stack: the lane-refill kernel keeps the first levels in LDS and spills the rare deep ones to global memory;
+    // the thread-per-pixel kernel (huge grids) keeps all of it in LDS
+    a.ldsStackLevels = (g.persist && g.foldMode == FOLD_RECURSIVE) ? g.ldsStackLevels : TPT_MAX_DEPTH;
+    const size_t ldsV1 = tptLdsBytes(a, g.foldMode, P.ldsScene);
+    P.sorted = g.persist == 2 && !P.rowSerial && g.hs == HS_TWO_PHASE; // lane-sorting kernel (PER_PIXEL seeds only)
+    // path-queue kernel: PER_PIXEL seeds, recursive fold, two-phase HitSpheres
+    P.queued = g.persist == 3 && !P.rowSerial && g.hs == HS_TWO_PHASE && g.foldMode == FOLD_RECURSIVE;
+    P.lds = P.queued ? tptQueueLdsBytes(a, P.ldsScene) : P.sorted ? tptSortedLdsBytes(a, g.foldMode, P.ldsScene) : ldsV1;
+    if (P.lds > 160 * 1024) return fail("tptDrawDevice: scene too large for LDS staging; use tptSetKernelVariant(.., .., 0)");
+    if (P.sorted || P.queued) a.ldsStackLevels = 0;
+    const int key = (P.queued ? (1 << 30) : 0) | (P.sorted ? 16 : 0) | (g.hs ? 8 : 0) | (g.foldMode ? 4 : 0) | (g.persist ? 2 : 0) |
+                    (P.ldsScene ? 1 : 0) | ((int)(P.lds / 256) << 5);
+    auto it = g.occCache.find(key);
+    if (it == g.occCache.end()) {
+        P.occ = P.queued   ? (int)(160 * 1024 / (P.lds + 256))
+                : P.sorted ? tptTraceSortedOccupancy(g.foldMode, P.ldsScene, P.lds)
+                           : tptTraceOccupancy(g.hs, g.foldMode, g.persist != 0, P.ldsScene, P.lds);
+        g.occCache[key] = P.occ;
+    } else {
+        P.occ = it->second;
+    }
+    P.threadsPerBlock = P.queued ? tptQueueThreadsPerBlock() : P.sorted ? 64 * TPT_SORT_WAVES : TPT_BLOCK;
+    return 0;
+}
+
+// Work items, chunk size and the number of workgroups of this launch.
+void sizeGrid(FramePlan& P)
+{
+    KernelArgs& a = P.a;
+    if (!g.persist) { // one thread per pixel
+        a.chunkSize = 0;
+        a.numChunks = 0;
+        P.blocks = (a.numItems + TPT_BLOCK - 1) / TPT_BLOCK;
+        a.totalWaves = 0;
+        return;
+    }
+    int occUse = P.occ;
+    if (g.maxBlocksPerCU > 0 && g.maxBlocksPerCU < occUse) occUse = g.maxBlocksPerCU;
+    const int resident = g.numCUs * occUse; // workgroups that can be co-resident
+    const int wavesPerBlock = P.threadsPerBlock / 64;
+    int chunk = P.rowSerial ? 1 : TPT_CHUNK_PIXELS;
+    // small frames: hand out single 8x8 tiles so every resident wave gets several chunks
+    if (!P.rowSerial && a.numItems / TPT_CHUNK_PIXELS < 8 * resident * wavesPerBlock) chunk = 64;
+    if (!P.rowSerial && g.chunkOverride >= 64) chunk = g.chunkOverride & ~63;
+    if (P.queued) chunk = 64; // the path-queue kernel accounts its pixel pools in 64-pixel chunks
+    a.chunkSize = chunk;
+    a.numChunks = (a.numItems + chunk - 1) / chunk;
+    int blocks = (a.numChunks + wavesPerBlock - 1) / wavesPerBlock;
+    // Frames in flight share the machine: with k trace kernels side by side each one gets fill / k of the resident
+    // workgroups -- its pools then stay in steady state longer before they drain, and the launches behind it fill the
+    // gaps.  fill = 200 % on a single GPU (measured best), 100 % when the frame is sharded over ranks (oversubscription
+    // buys nothing on small tiles).  A caller that synchronises every frame has nothing in flight and gets the full grid.
+    int cap;
+    if (g.gridDiv > 0) {
+        cap = resident / g.gridDiv;
+    } else {
+        const int fill = g.gridFill > 0 ? g.gridFill : (g.numParts > 1 ? 100 : 200);
+        const int k = framesInFlight(P.nOverlap) + 1;
+        cap = (int)((long long)resident * fill / (100ll * k));
+        if (cap > resident) cap = resident;
+        const int floorBlocks = resident / (2 * (P.nOverlap > 1 ? P.nOverlap : 1));
+        if (cap < floorBlocks) cap = floorBlocks;
+    }
+    if (cap < 1) cap = 1;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    P.blocks = blocks;
+    a.totalWaves = (unsigned)(blocks * wavesPerBlock);
+}
+
+// Per-slot buffers of this frame: colour, bounce-stack spill / per-path stacks, path colour sums.
+int ensureFrameBuffers(FramePlan& P, int w)
+{
+    KernelArgs& a = P.a;
+    const int slot = P.slot;
+    int rc = growSlotBuffer(g.dColour[slot], g.colourCap[slot], (size_t)a.nLocalRows * w * sizeof(f4), slot);
+    if (rc) return rc;
+    a.frameColour = g.dColour[slot];
+    a.work = g.dWork + 16 * slot;
+    a.rayCounter = g.dRays;
+    a.stackBuf = nullptr;
+    a.stackStride = 0;
+    const int stackColumns = P.queued ? P.blocks * tptQueuePathsPerBlock() : P.blocks * P.threadsPerBlock;
+    if (g.persist && g.foldMode == FOLD_RECURSIVE && a.ldsStackLevels < TPT_MAX_DEPTH) {
+        rc = growSlotBuffer(g.dStack[slot], g.stackCap[slot], (size_t)stackColumns * (TPT_MAX_DEPTH - a.ldsStackLevels) * sizeof(f4), slot);
+        if (rc) return rc;
+        a.stackBuf = g.dStack[slot];
+        a.stackStride = stackColumns;
+    }
+    a.pathBuf = nullptr;
+    if (P.queued) {
+        rc = growSlotBuffer(g.dPath[slot], g.pathCap[slot], (size_t)P.blocks * tptQueuePathsPerBlock() * sizeof(f4), slot); // one colour sum per path
+        if (rc) return rc;
+        a.pathBuf = g.dPath[slot];
+    }
+    return 0;
+}
+
+int syncAllStreams()
+{
+    HIPCHK(hipStreamSynchronize(g.stream));
+    for (int k = 0; k < Context::kMaxOverlap; ++k) HIPCHK(hipStreamSynchronize(g.traceStream[k]));
+    return 0;
+}
+
+// Cost-ordered work distribution of the lane-refill kernel: statistics and order tables for this chunk count.
+int prepareChunkOrder(FramePlan& P)
+{
+    KernelArgs& a = P.a;
+    a.chunkOrder = nullptr;
+    a.chunkCost = nullptr;
+    a.chunkShift = 6;
+    P.useOrder = g.costOrder && g.persist == 1 && !P.rowSerial && !P.sorted && !P.queued && a.numChunks > 1 &&
+                 (a.chunkSize & (a.chunkSize - 1)) == 0;
+    if (!P.useOrder) return 0;
+    int sh = 0;
+    while ((1 << sh) < a.chunkSize) ++sh;
+    a.chunkShift = sh;
+    const size_t bytes = sizeof(unsigned) * (size_t)a.numChunks;
+    if (a.numChunks > g.chunkCap) {
+        int rc = syncAllStreams();
+        if (rc) return rc;
+        if (g.dChunkCost) HIPCHK(hipFree(g.dChunkCost));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dChunkCost), bytes));
+        for (int k = 0; k < Context::kOrderTables; ++k) {
+            if (g.dChunkOrder[k]) HIPCHK(hipFree(g.dChunkOrder[k]));
+            g.dChunkOrder[k] = nullptr;
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dChunkOrder[k]), bytes));
+        }
+        for (int k = 0; k < Context::kMaxOverlap; ++k) {
+            if (g.dChunkSnap[k]) HIPCHK(hipFree(g.dChunkSnap[k]));
+            g.dChunkSnap[k] = nullptr;
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dChunkSnap[k]), bytes));
+        }
+        g.chunkCap = a.numChunks;
+        g.chunkCount = 0;
+    }
+    if (g.chunkCount != a.numChunks) { // new resolution / sharding: statistics start over
+        int rc = syncAllStreams();
+        if (rc) return rc;
+        HIPCHK(hipMemset(g.dChunkCost, 0, bytes));
+        g.chunkCount = a.numChunks;
+        g.orderSeq = 0;
+        g.orderDone = true;
+    }
+    a.chunkCost = g.dChunkCost;
+    return 0;
+}
+
+// Give the launch on `ts` an order table: re-sorted from the statistics gathered so far (every frame until the first
+// frames' statistics have certainly arrived -- the sort runs beside up to nOverlap unfinished frames -- then every
+// 32nd), or the most recent one.  Tables rotate over kOrderTables buffers (> frames in flight): a trace kernel still in
+// flight keeps reading the one it was given.
+int enqueueChunkOrder(FramePlan& P, hipStream_t ts)
+{
+    if (!P.useOrder) return 0;
+    if (g.orderSeq > 0) {
+        const int fresh = (int)(g.orderSeq % Context::kOrderTables);
+        if (g.orderSeq <= (unsigned long long)(2 * P.nOverlap + 2) || (g.orderSeq & 31ull) == 0ull) {
+            HIPCHK(tptLaunchChunkOrder(g.dChunkCost, g.dChunkSnap[P.slot], g.dChunkOrder[fresh], P.a.numChunks, ts));
+            HIPCHK(hipEventRecord(g.evOrder, ts));
+            g.orderStream = ts;
+            g.orderDone = false;
+            g.lastOrderTable = fresh;
+        } else if (!g.orderDone && g.orderStream != ts) {
+            // the most recent table may still be being written by another stream's sort kernel
+            if (hipEventQuery(g.evOrder) == hipSuccess)
+                g.orderDone = true;
+            else
+                HIPCHK(hipStreamWaitEvent(ts, g.evOrder, 0));
+            (void)hipGetLastError();
+        }
+        P.a.chunkOrder = g.dChunkOrder[g.lastOrderTable];
+    }
+    g.orderSeq++;
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
 int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, unsigned testFlags)
 {
     (void)time; // stored but never read by the reference either (Test.cpp:257,347)
@@ -595,7 +815,8 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
         int rc = stageScene();
         if (rc) return rc;
     }
-    KernelArgs a;
+    FramePlan P;
+    KernelArgs& a = P.a;
     a.scene = deviceView(); // pointers of the set this frame reads; its upload is enqueued below, on the frame's stream
     a.fc = makeFrameConsts(g.cam, w, h, g.spp, frameCount, testFlags, g.seedMode);
     a.nLocalRows = localRows(h);
@@ -611,218 +832,48 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
     if (a.nLocalRows <= 0) return 0; // nothing to do on this rank
     a.tilesX = (w + 7) / 8;
     const int tilesY = (a.nLocalRows + 7) / 8;
-    const bool rowSerial = g.seedMode == SEED_ROW_SERIAL;
-    a.numItems = rowSerial ? a.nLocalRows : a.tilesX * tilesY * 64;
-    const int nOverlap = g.overlap < 1 ? 1 : (g.overlap > Context::kMaxOverlap ? Context::kMaxOverlap : g.overlap);
-    const int slot = (int)(g.frameSeq % (unsigned long long)nOverlap);
+    a.numItems = g.seedMode == SEED_ROW_SERIAL ? a.nLocalRows : a.tilesX * tilesY * 64;
+    P.nOverlap = g.overlap < 1 ? 1 : (g.overlap > Context::kMaxOverlap ? Context::kMaxOverlap : g.overlap);
+    P.slot = (int)(g.frameSeq % (unsigned long long)P.nOverlap);
     g.frameSeq++;
-    const size_t colourBytes = (size_t)a.nLocalRows * w * sizeof(f4);
-    if (colourBytes > g.colourCap[slot]) {
-        HIPCHK(hipStreamSynchronize(g.stream));
-        HIPCHK(hipStreamSynchronize(g.traceStream[slot]));
-        if (g.dColour[slot]) HIPCHK(hipFree(g.dColour[slot]));
-        g.dColour[slot] = nullptr;
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dColour[slot]), colourBytes));
-        g.colourCap[slot] = colourBytes;
-    }
-    a.frameColour = g.dColour[slot];
-    a.work = g.dWork + 16 * slot;
-    a.rayCounter = g.dRays;
 
-    // LDS scene staging: default when {centre,r^2}+1/r (20 B/sphere) + lights + bounce stack fit in 64 KB
-    const int nPad = a.scene.nPairs * 2;
-    // (20 B per padded sphere + 48 B of material per sphere; 46 spheres: 3.2 KB, fits up to ~600 spheres in 40 KB)
-    bool ldsScene = g.ldsScene < 0 ? ((size_t)nPad * 20 + (size_t)a.scene.nSpheres * 48 <= 40960) : (g.ldsScene != 0);
-    if (a.scene.nGroups > 0) ldsScene = false; // the LDS-staging kernels are built without the grouped traversal
-    // bounce stack: persistent kernel keeps the first levels in LDS and spills the rare deep ones to global memory;
-    // the thread-per-pixel kernel (huge grids) keeps all of it in LDS
-    a.ldsStackLevels = (g.persist && g.foldMode == FOLD_RECURSIVE) ? g.ldsStackLevels : TPT_MAX_DEPTH;
-    const size_t ldsV1 = tptLdsBytes(a, g.foldMode, ldsScene);
+    int rc = chooseKernel(P);
+    if (rc) return rc;
+    sizeGrid(P);
+    if ((rc = ensureFrameBuffers(P, w))) return rc;
+    if ((rc = prepareChunkOrder(P))) return rc;
+    g.lastBlocksPerCU = P.occ;
+    g.lastLds = (int)P.lds;
+    g.lastGrid = P.blocks;
 
-    const bool sorted = g.persist == 2 && !rowSerial && g.hs == HS_TWO_PHASE; // lane-sorting kernel (PER_PIXEL seeds only)
-    // path-queue kernel: PER_PIXEL seeds, recursive fold, two-phase HitSpheres
-    const bool queued = g.persist == 3 && !rowSerial && g.hs == HS_TWO_PHASE && g.foldMode == FOLD_RECURSIVE;
-    const size_t lds = queued ? tptQueueLdsBytes(a, ldsScene) : sorted ? tptSortedLdsBytes(a, g.foldMode, ldsScene) : ldsV1;
-    if (lds > 160 * 1024) return fail("tptDrawDevice: scene too large for LDS staging; use tptSetKernelVariant(.., .., 0)");
-    const int key = (queued ? (1 << 30) : 0) | (sorted ? 16 : 0) | (g.hs ? 8 : 0) | (g.foldMode ? 4 : 0) | (g.persist ? 2 : 0) | (ldsScene ? 1 : 0) | ((int)(lds / 256) << 5);
-    int occ;
-    auto it = g.occCache.find(key);
-    if (it == g.occCache.end()) {
-        occ = queued ? (int)(160 * 1024 / (lds + 256)) : sorted ? tptTraceSortedOccupancy(g.foldMode, ldsScene, lds) : tptTraceOccupancy(g.hs, g.foldMode, g.persist != 0, ldsScene, lds);
-        g.occCache[key] = occ;
-    } else {
-        occ = it->second;
-    }
-    const int threadsPerBlock = queued ? tptQueueThreadsPerBlock() : sorted ? 64 * TPT_SORT_WAVES : TPT_BLOCK;
-    int blocks;
-    if (g.persist) {
-        int occUse = occ;
-        if (g.maxBlocksPerCU > 0 && g.maxBlocksPerCU < occUse) occUse = g.maxBlocksPerCU;
-        const int resident = g.numCUs * occUse; // workgroups that can be co-resident
-        const int wavesPerBlock = threadsPerBlock / 64;
-        int chunk = rowSerial ? 1 : TPT_CHUNK_PIXELS;
-        // small frames: hand out single 8x8 tiles so every resident wave gets several chunks
-        if (!rowSerial && a.numItems / TPT_CHUNK_PIXELS < 8 * resident * wavesPerBlock) chunk = 64;
-        if (!rowSerial && g.chunkOverride >= 64) chunk = g.chunkOverride & ~63;
-        if (queued) chunk = 64; // the path-queue kernel accounts its pixel pools in 64-pixel chunks
-        a.chunkSize = chunk;
-        a.numChunks = (a.numItems + chunk - 1) / chunk;
-        blocks = (a.numChunks + wavesPerBlock - 1) / wavesPerBlock;
-        // Frames in flight share the machine: with k trace kernels running side by side each one gets ~2/k of the
-        // resident workgroups (its pools then stay in steady state 8x longer before they drain, and the launches
-        // behind it fill the gaps).  A caller that synchronises every frame has nothing in flight and gets the full grid.
-        int div = g.gridDiv;
-        int cap = resident;
-        if (div <= 0) {
-            // the launches in flight together ask for gridFill % of the resident workgroup slots: 200 % on a single
-            // GPU (later launches queue behind and fill the gaps the draining ones leave); 75 % when the frame is
-            // sharded over ranks, so that the small kernels of the exchange (snapshot copy, RCCL, assemble) find a
-            // free CU instead of waiting for a persistent workgroup to retire
-            const int fill = g.gridFill > 0 ? g.gridFill : (g.numParts > 1 ? 100 : 200);
-            const int k = framesInFlight(nOverlap) + 1;
-            cap = (int)((long long)resident * fill / (100ll * k));
-            if (cap > resident) cap = resident;
-            const int floorBlocks = resident / (2 * (nOverlap > 1 ? nOverlap : 1));
-            if (cap < floorBlocks) cap = floorBlocks;
-            if (cap < 1) cap = 1;
-            div = 1;
-        } else {
-            cap = resident / div;
-        }
-        if (blocks > cap) blocks = cap;
-        if (blocks < 1) blocks = 1;
-        a.totalWaves = (unsigned)(blocks * wavesPerBlock);
-    } else {
-        a.chunkSize = 0;
-        a.numChunks = 0;
-        blocks = (a.numItems + TPT_BLOCK - 1) / TPT_BLOCK;
-        a.totalWaves = 0;
-    }
-    a.stackBuf = nullptr;
-    a.stackStride = 0;
-    if (sorted || queued) a.ldsStackLevels = 0;
-    const int stackColumns = queued ? blocks * tptQueuePathsPerBlock() : blocks * threadsPerBlock;
-    if (g.persist && g.foldMode == FOLD_RECURSIVE && a.ldsStackLevels < TPT_MAX_DEPTH) {
-        const size_t need = (size_t)stackColumns * (TPT_MAX_DEPTH - a.ldsStackLevels) * sizeof(f4);
-        if (need > g.stackCap[slot]) {
-            HIPCHK(hipStreamSynchronize(g.stream));
-            HIPCHK(hipStreamSynchronize(g.traceStream[slot]));
-            if (g.dStack[slot]) HIPCHK(hipFree(g.dStack[slot]));
-            g.dStack[slot] = nullptr;
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dStack[slot]), need));
-            g.stackCap[slot] = need;
-        }
-        a.stackBuf = g.dStack[slot];
-        a.stackStride = stackColumns;
-    }
-    // cost-ordered work distribution for the default persistent kernel
-    a.chunkOrder = nullptr;
-    a.chunkCost = nullptr;
-    a.chunkShift = 6;
-    const bool useOrder = g.costOrder && g.persist == 1 && !rowSerial && !sorted && !queued && a.numChunks > 1 &&
-                          (a.chunkSize & (a.chunkSize - 1)) == 0;
-    if (useOrder) {
-        int sh = 0;
-        while ((1 << sh) < a.chunkSize) ++sh;
-        a.chunkShift = sh;
-        if (a.numChunks > g.chunkCap) {
-            HIPCHK(hipStreamSynchronize(g.stream));
-            for (int k = 0; k < Context::kMaxOverlap; ++k) HIPCHK(hipStreamSynchronize(g.traceStream[k]));
-            if (g.dChunkCost) HIPCHK(hipFree(g.dChunkCost));
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dChunkCost), sizeof(unsigned) * (size_t)a.numChunks));
-            for (int k = 0; k < Context::kOrderTables; ++k) {
-                if (g.dChunkOrder[k]) HIPCHK(hipFree(g.dChunkOrder[k]));
-                g.dChunkOrder[k] = nullptr;
-                HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dChunkOrder[k]), sizeof(unsigned) * (size_t)a.numChunks));
-            }
-            for (int k = 0; k < Context::kMaxOverlap; ++k) {
-                if (g.dChunkSnap[k]) HIPCHK(hipFree(g.dChunkSnap[k]));
-                g.dChunkSnap[k] = nullptr;
-                HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dChunkSnap[k]), sizeof(unsigned) * (size_t)a.numChunks));
-            }
-            g.chunkCap = a.numChunks;
-            g.chunkCount = 0;
-        }
-        if (g.chunkCount != a.numChunks) { // new resolution / sharding: statistics start over
-            HIPCHK(hipStreamSynchronize(g.stream));
-            for (int k = 0; k < Context::kMaxOverlap; ++k) HIPCHK(hipStreamSynchronize(g.traceStream[k]));
-            HIPCHK(hipMemset(g.dChunkCost, 0, sizeof(unsigned) * (size_t)a.numChunks));
-            g.chunkCount = a.numChunks;
-            g.orderSeq = 0;
-        }
-        a.chunkCost = g.dChunkCost;
-    }
-    a.pathBuf = nullptr;
-    if (queued) {
-        const size_t need = (size_t)blocks * tptQueuePathsPerBlock() * sizeof(f4); // one colour sum per path
-        if (need > g.pathCap[slot]) {
-            HIPCHK(hipStreamSynchronize(g.stream));
-            HIPCHK(hipStreamSynchronize(g.traceStream[slot]));
-            if (g.dPath[slot]) HIPCHK(hipFree(g.dPath[slot]));
-            g.dPath[slot] = nullptr;
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dPath[slot]), need));
-            g.pathCap[slot] = need;
-        }
-        a.pathBuf = g.dPath[slot];
-    }
-    g.lastBlocksPerCU = occ;
-    g.lastLds = (int)lds;
-    g.lastGrid = blocks;
     // trace(f) on its own stream (no dependency on the previous frame), then the ordered blend on g.stream
-    hipStream_t ts = nOverlap > 1 ? g.traceStream[slot] : g.stream;
-    if (nOverlap > 1 && g.resolveRecorded[slot]) HIPCHK(hipStreamWaitEvent(ts, g.evResolve[slot], 0)); // colour buffer free again
-    {
-        int rc = enqueueSceneUpload(ts); // behind the wait above: frames <= f-8 are done, nobody reads the set being replaced
-        if (rc) return rc;
-    }
-    if (useOrder && g.orderSeq > 0) {
-        // re-sort from the statistics gathered so far (every frame until the first frames' statistics have certainly
-        // arrived -- the sort runs beside up to nOverlap unfinished frames -- then every 32nd).
-        // The table is one of kOrderTables rotating buffers (> frames in flight): a trace kernel still in flight keeps reading the
-        // one it was given.
-        unsigned* table = g.dChunkOrder[g.orderSeq % Context::kOrderTables];
-        if (g.orderSeq <= (unsigned long long)(2 * nOverlap + 2) || (g.orderSeq & 31ull) == 0ull) {
-            HIPCHK(tptLaunchChunkOrder(g.dChunkCost, g.dChunkSnap[slot], table, a.numChunks, ts));
-            HIPCHK(hipEventRecord(g.evOrder, ts));
-            g.orderStream = ts;
-            g.orderDone = false;
-        } else {
-            // reuse the most recent table -- which another stream's sort kernel may still be writing
-            table = g.dChunkOrder[g.lastOrderTable];
-            if (!g.orderDone && g.orderStream != ts) {
-                if (hipEventQuery(g.evOrder) == hipSuccess)
-                    g.orderDone = true;
-                else
-                    HIPCHK(hipStreamWaitEvent(ts, g.evOrder, 0));
-                (void)hipGetLastError();
-            }
-        }
-        g.lastOrderTable = (int)(table == g.dChunkOrder[g.orderSeq % Context::kOrderTables] ? g.orderSeq % Context::kOrderTables : g.lastOrderTable);
-        a.chunkOrder = table;
-    }
-    if (useOrder) g.orderSeq++;
+    const int slot = P.slot;
+    const bool pipelined = P.nOverlap > 1;
+    hipStream_t ts = pipelined ? g.traceStream[slot] : g.stream;
+    if (pipelined && g.resolveRecorded[slot]) HIPCHK(hipStreamWaitEvent(ts, g.evResolve[slot], 0)); // colour buffer free again
+    if ((rc = enqueueSceneUpload(ts))) return rc; // behind the wait above: nobody reads the set being replaced any more
+    if ((rc = enqueueChunkOrder(P, ts))) return rc;
     const bool timeIt = g.kernelTiming && g.ktUsed < g.ktStart.size();
     if (timeIt) HIPCHK(hipEventRecord(g.ktStart[g.ktUsed], ts));
-    if (queued)
-        HIPCHK(tptLaunchTraceQueue(a, ldsScene, blocks, lds, ts));
-    else if (sorted)
-        HIPCHK(tptLaunchTraceSorted(a, g.foldMode, ldsScene, blocks, lds, ts));
+    if (P.queued)
+        HIPCHK(tptLaunchTraceQueue(a, P.ldsScene, P.blocks, P.lds, ts));
+    else if (P.sorted)
+        HIPCHK(tptLaunchTraceSorted(a, g.foldMode, P.ldsScene, P.blocks, P.lds, ts));
     else
-        HIPCHK(tptLaunchTrace(a, g.hs, g.foldMode, g.persist != 0, ldsScene, blocks, lds, ts));
+        HIPCHK(tptLaunchTrace(a, g.hs, g.foldMode, g.persist != 0, P.ldsScene, P.blocks, P.lds, ts));
     if (timeIt) {
         HIPCHK(hipEventRecord(g.ktStop[g.ktUsed], ts));
         g.ktUsed++;
     }
-    if (nOverlap > 1) HIPCHK(hipEventRecord(g.evTrace[slot], ts));
+    if (pipelined) HIPCHK(hipEventRecord(g.evTrace[slot], ts));
     if (g.uploadSrc) { // tptDraw: the previous image crosses PCIe while the trace kernel runs (it is on another stream)
         const float* src = g.uploadSrc;
         g.uploadSrc = nullptr;
-        int rcUp = uploadBackbuffer(src, w, h);
-        if (rcUp) return rcUp;
+        if ((rc = uploadBackbuffer(src, w, h))) return rc;
     }
-    if (nOverlap > 1) HIPCHK(hipStreamWaitEvent(g.stream, g.evTrace[slot], 0));
+    if (pipelined) HIPCHK(hipStreamWaitEvent(g.stream, g.evTrace[slot], 0));
     HIPCHK(tptLaunchResolve(deviceTile, a.frameColour, a.nLocalRows * w, a.fc.lerpFac, g.mirror, g.dRays, g.mirrorCounter, g.stream));
-    if (nOverlap > 1) {
+    if (pipelined) {
         HIPCHK(hipEventRecord(g.evResolve[slot], g.stream));
         g.resolveRecorded[slot] = true;
     }

@@ -108,7 +108,7 @@ typedef struct {
     int count;
     /* SoA (Maths.h:368-404), filled like UpdateTest does (Test.cpp:321-331) */
     float *cx, *cy, *cz, *sqR, *invR;
-    int emissive[4096 + 8];
+    int* emissive; /* s_EmissiveSpheres, Test.cpp:67 (sized to the scene here) */
     int emissiveCount;
     const TptoCamera* cam;
     int math_mode, fold_mode;
@@ -350,7 +350,8 @@ int64_t tpto_render(const TptoSphere* spheres, const TptoMaterial* mats, int cou
                     const TptoParams* p, float* backbuffer)
 {
     Scene* sc = (Scene*)calloc(1, sizeof(Scene));
-    if (count > 4096 + 8) count = 4096 + 8;
+    if (count < 0) count = 0;
+    sc->emissive = (int*)malloc(sizeof(int) * (size_t)(count > 0 ? count : 1));
     sc->spheres = spheres;
     sc->mats = mats;
     sc->count = count;
@@ -376,6 +377,7 @@ int64_t tpto_render(const TptoSphere* spheres, const TptoMaterial* mats, int cou
 #endif
     for (int y = y0; y < y1; ++y) rays += TraceRows(sc, p, y, y + 1, backbuffer);
     free(soa);
+    free(sc->emissive);
     free(sc);
     return rays;
 }

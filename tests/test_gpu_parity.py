@@ -184,7 +184,7 @@ def test_two_phase_filter_is_conservative_on_grazing_rays_gpu(tpt_defaults):
         id1, t1 = tpt.test_hit_spheres(rays, 1)
         assert np.array_equal(id0, id1) and np.array_equal(t0.view(np.uint32), t1.view(np.uint32))
         assert (id1 >= 0).mean() > 0.3
-    # 20000 spheres (five 256-group super-chunks; beyond the oracle's capacity): grouped render == all-exact-loop render
+    # 20000 spheres (five 256-group super-chunks): grouped render == all-exact-loop render
     tpt.set_camera(look_from=(0.0, 6.0, 20.0), look_at=(0.0, 0.0, 0.0), vfov=60.0, aperture=0.02, focus_dist=20.0)
     tpt.set_samples_per_pixel(2)
     ra, ba, _ = gpu_frames(tpt, 96, 54, 2)

@@ -125,10 +125,7 @@ def test_grouped_hit_world_equals_brute_force(emu, oracle, n):
     w, h, spp = 64, 36, 2
     cam = oracle.camera(STRESS_CAMERA["look_from"], STRESS_CAMERA["look_at"], (0, 1, 0), STRESS_CAMERA["vfov"], w / h,
                         STRESS_CAMERA["aperture"], STRESS_CAMERA["focus_dist"])
-    if n <= 4096:
-        ro, bo = oracle.render(s, m, cam, w, h, spp, 0, seed_mode=1)
-    else:  # the oracle holds at most 4104 spheres: the all-exact loop (checked against it above) is the reference here
-        ro, bo = emu_frames(emu, s, m, cam, w, h, spp, 1, FLAG_PROGRESSIVE, 1, 1, 0)
+    ro, bo = oracle.render(s, m, cam, w, h, spp, 0, seed_mode=1)
     import ctypes as C
     info = np.zeros(3, np.int32)
     emu.emu_group_info.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]

@@ -67,22 +67,3 @@ def test_display_conversion_matches_reference_formula(tpt_defaults, tmp_path):
     tpt.write_tga(path, got)
     assert os.path.getsize(path) == 18 + w * h * 4
 
-
-def test_shutdown_and_reinitialise(tpt_defaults, oracle):
-    """ShutdownTest releases every device resource and InitializeTest brings the context back (the reference's hosts call
-    the pair once, Test.cpp:240-253; a library may see it more often)."""
-    import numpy as np
-    from common import oracle_frames
-    from oracle_lib import SEED_PER_PIXEL
-    tpt = tpt_defaults
-    w, h = 96, 64
-    ro, bo, _ = oracle_frames(oracle, w, h, 4, 2, seed_mode=SEED_PER_PIXEL)
-    for cycle in range(3):
-        bb = np.zeros((h, w, 4), np.float32)
-        rays = 0
-        for f in range(2):
-            tpt.UpdateTest(0.0, f, w, h, 2)
-            rays += tpt.DrawTest(0.0, f, w, h, bb, 2)
-        assert rays == ro and bb.tobytes() == bo.tobytes()
-        tpt.ShutdownTest()
-        tpt.InitializeTest()

@@ -259,6 +259,7 @@ def test_device_resident_path_with_torch_tile(tpt_defaults, oracle):
     tpt = tpt_defaults
     w, h, frames = 256, 144, 4
     tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()  # the fill runs on torch's stream; the library's streams do not wait for it
     stream = torch.cuda.Stream()
     tpt.set_stream(stream.cuda_stream)
     r0 = tpt.ray_counter_read()
@@ -284,6 +285,7 @@ def test_seventy_pipelined_frames_at_config2(tpt_defaults, oracle, persist, over
     tpt.set_frame_overlap(overlap)
     w, h, frames = 1280, 720, 70
     tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()  # the fill runs on torch's stream; the library's streams do not wait for it
     r0 = tpt.ray_counter_read()
     for f in range(frames):
         tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
@@ -349,6 +351,7 @@ def test_tile_mirror_snapshot(tpt_defaults, oracle):
     tpt = tpt_defaults
     w, h, frames = 160, 96, 6
     tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()  # the fill runs on torch's stream; the library's streams do not wait for it
     mirrors = [torch.full((h + 1, w, 4), -1.0, dtype=torch.float32, device="cuda") for _ in range(3)]
     r0 = tpt.ray_counter_read()
     for f in range(frames):
@@ -383,6 +386,7 @@ def test_frame_overlap_is_bit_identical(tpt_defaults, oracle, overlap):
     if overlap == 16:
         w, h = 640, 360  # enough work per frame that many launches really are in flight (adaptive grid size kicks in)
     tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()  # the fill runs on torch's stream; the library's streams do not wait for it
     r0 = tpt.ray_counter_read()
     tpt.kernel_timing_begin(frames)
     for f in range(frames):
@@ -408,6 +412,7 @@ def test_animated_scene_async_upload_ring(tpt_defaults, oracle, overlap):
     w, h, frames = 96, 64, 80
     flags = FLAG_PROGRESSIVE | FLAG_ANIMATE
     tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()  # the fill runs on torch's stream; the library's streams do not wait for it
     r0 = tpt.ray_counter_read()
     for f in range(frames):
         t = 0.37 * f
@@ -460,6 +465,7 @@ def test_cost_ordered_chunks_table_is_a_permutation_and_image_unchanged(tpt_defa
     tpt.set_kernel_variant(0, 1, -1)  # the lane-refill kernel (the fallback of the path-queue kernel) owns this mechanism
     w, h, frames = 640, 360, 20
     tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()  # the fill runs on torch's stream; the library's streams do not wait for it
     r0 = tpt.ray_counter_read()
     for f in range(frames):
         tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)

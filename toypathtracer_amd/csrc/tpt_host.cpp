@@ -280,6 +280,7 @@ int enqueueSceneUpload(hipStream_t ts)
     if (!S.copyDone && S.uploadStream != ts) {
         if (hipEventQuery(S.evUploaded) == hipSuccess) S.copyDone = true;
         else HIPCHK(hipStreamWaitEvent(ts, S.evUploaded, 0));
+        (void)hipGetLastError(); // hipErrorNotReady from the query is not an error
     }
     return 0;
 }

@@ -44,7 +44,7 @@ struct Context {
     // Test.cpp:304-308,321-339) is uploaded asynchronously while earlier frames still read the older sets.
     // One device blob + one pinned host staging blob per set, laid out pairs | sph4 | invR | mats | lights.
     // A frame uploads at most one set, a set is reused after kSceneSets uploads, at most kMaxOverlap frames
-    // are in flight and the upload is stream-ordered behind the resolve of frame f-8: no kernel still reads the
+    // are in flight and the upload is stream-ordered behind the resolve of frame f - overlap: no kernel still reads the
     // set that is being overwritten.
     static const int kSceneSets = 2 * kMaxOverlap;
     struct SceneSet {

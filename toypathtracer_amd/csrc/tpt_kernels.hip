@@ -1,22 +1,24 @@
 // tpt_kernels.hip -- gfx950 (MI355X / CDNA4) kernels of the path tracer.
 //
-// One kernel family replaces the reference's DrawTest fan-out (Cpp/Source/Test.cpp:344-367:
-// enkiTS task set over rows -> TraceRowJob :266-300).  Mapping to the hardware:
+// They replace the reference's DrawTest fan-out (Cpp/Source/Test.cpp:344-367: enkiTS task set over rows ->
+// TraceRowJob :266-300).  All of them run the same per-lane code (tpt_trace.h: hitSpheres + lanePost, one ray per
+// step) and produce the same bits; they differ in how rays are mapped onto lanes:
 //
-//   * work item  = one pixel (PER_PIXEL seed mode) or one row (ROW_SERIAL, the reference's
-//     Test.cpp:280 RNG stream; debugging / bit-for-bit reproduction of the CPU image);
-//   * lane       = runs the flattened Trace/Scatter state machine of tpt_trace.h, one ray per step;
-//   * wave (64)  = 8x8 pixel tiles, so the camera rays of a wave are coherent;
-//   * persistent variant: each wave pulls chunks of 256 pixels from a global atomic counter and
-//     RE-FILLS idle lanes with the next pixel of its chunk (ballot + prefix count), so lanes whose
-//     path ended early (sky after one ray) do not wait for the 11-bounce neighbours.  Chunks are
-//     numbered bottom-up (y = 0 is the expensive, sphere-covered bottom of the image; the cheap
-//     sky rows come last), which keeps the tail of the launch short.
-//   * scene: phase-1 sphere pairs are read with scalar loads (wave-uniform), the {centre, r^2}
-//     records, 1/r and the light list are staged into LDS once per workgroup for the per-lane
-//     phase-2 gather; materials are read from global memory (L1/L2 resident, only at a hit).
-//   * output: float4 accumulation buffer, RGB read-modify-write per pixel (alpha untouched),
-//     ray counts reduced per wave (shuffle) -> one 64-bit atomic per wave.
+//   * tptTraceQueueKernel   (default)  workgroups of 8 waves own 1024 paths whose state lives in LDS; waves pop
+//                                      batches of paths that need the SAME code from per-class rings, so Scatter and the
+//                                      intersections run at (nearly) full lane utilisation;
+//   * tptTraceKernel        PERSIST    one-wave workgroups pull 8x8-pixel chunks from a global counter and re-fill idle
+//                                      lanes with the next pixel (fallback for row-serial seeds / forward fold / simple
+//                                      HitSpheres; cost-ordered chunks);  !PERSIST: one thread per pixel;
+//   * tptTraceSortedKernel             4 waves regroup their lanes by class through LDS after every intersection.
+//
+//   * work item  = one pixel (PER_PIXEL seed mode) or one row (ROW_SERIAL, the reference's Test.cpp:280 RNG stream;
+//     bit-for-bit reproduction of the CPU image);
+//   * scene: phase-1 sphere pairs are read with scalar loads (wave-uniform); the {centre, r^2} records, 1/r, the light
+//     list and the materials are staged into LDS once per workgroup when they fit (large scenes: global memory + the
+//     grouped traversal of tpt_trace.h);
+//   * output: the frame's colour per pixel (one 16-B store), blended into the float4 accumulation tile by
+//     tptResolveKernel (RGB read-modify-write, alpha untouched); ray counts reduced per wave -> one 64-bit atomic.
 //
 // No MFMA: there is no dense contraction in this path (46-long select/min reduction per lane).
 #include "tpt_device.h"

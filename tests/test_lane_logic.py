@@ -172,7 +172,7 @@ def test_grouped_hit_world_breaks_ties_by_lowest_index(emu):
 
 
 def test_filters_never_miss_in_an_adversarial_search(tmp_path):
-    """tests/adversarial_filter.cpp: 60 M near-tangent ray/sphere configurations over six decades of scale (2 G were run
+    """tests/adversarial_filter.cpp: 60 M near-tangent ray/sphere configurations over six decades of scale (10^10 were run
     once by hand: 0 misses); neither the sphere filter nor the group-bound filter may reject what the reference accepts."""
     import subprocess
     exe = str(tmp_path / "adv")

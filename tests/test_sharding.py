@@ -76,8 +76,8 @@ def _worker(rank, world, port, w, h, stripe, q, mirror=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,h,stripe,mirror", [(2, 42, 4, False), (3, 50, 8, False), (2, 42, 4, True)],
-                         ids=["2ranks", "3ranks_uneven", "2ranks_mirrored_snapshot"])
+@pytest.mark.parametrize("world,h,stripe,mirror", [(2, 42, 4, False), (3, 50, 8, False), (2, 42, 4, True), (8, 100, 8, True)],
+                         ids=["2ranks", "3ranks_uneven", "2ranks_mirrored_snapshot", "8ranks_uneven_mirrored_snapshot"])
 def test_gather_reassembles_the_single_process_image(oracle, world, h, stripe, mirror):
     from oracle_lib import SEED_PER_PIXEL
     w = 64

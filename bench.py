@@ -105,6 +105,10 @@ def main():
                     help="trace kernels of up to this many consecutive frames may be in flight (0 = auto: 16, or 8 when the frame is "
                          "sharded over more than 2 ranks -- with small tiles the per-packet latency of many active queues costs more "
                          "than the extra overlap buys)")
+    ap.add_argument("--prime", type=int, default=-1,
+                    help="untimed frames rendered BEFORE the warm-up so that the frame pipeline (buffers of all slots, the library's "
+                         "estimate of how deep this caller pipelines) is in its steady state when warm-up and timing start; "
+                         "-1 = as many as frames may be in flight; reported as config.untimed_priming_frames")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -171,14 +175,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for f in range(args.warmup):
+    if args.prime < 0:
+        args.prime = args.overlap
+    for f in range(args.prime):  # untimed, not part of --warmup either (stated in the JSON line)
+        step(f)
+    fence()
+    for f in range(args.prime, args.prime + args.warmup):
         step(f)
     fence()
     rays0 = int(sf.ray_counter.item())
     api.kernel_timing_begin(args.steps)   # a HIP event pair around every trace launch, on the stream it is launched on
     api.timer_begin()                     # + one pair around the whole timed region on the context's stream
     t0 = time.perf_counter()
-    for f in range(args.warmup, args.warmup + args.steps):
+    for f in range(args.prime + args.warmup, args.prime + args.warmup + args.steps):
         step(f)
     pipeline_ms = api.timer_end()         # records + synchronises the end event on the render stream
     fence()
@@ -220,6 +229,7 @@ def main():
             "config": {"workload": label, "width": width, "height": height, "spp": spp, "spheres": n_spheres,
                        "seed_mode": "per_pixel", "fold": "forward" if args.fold else "recursive",
                        "hit_spheres": ["two_phase" + ("+groups" if n_spheres >= 256 else ""), "simple", "two_phase_brute_force"][args.hit_spheres], "kernel": ["thread_per_pixel", "persistent_waves", "lane_sorting", "path_queues"][args.persistent], "frame_overlap": args.overlap,
+                       "untimed_priming_frames": args.prime,
                        "flags": "progressive|animate" if args.animate else "progressive",
                        "sharding": "none" if world == 1 else "row stripes of %d, round-robin over %d ranks, pipelined gather to rank 0" % (args.stripe_rows, world),
                        "device": api.device_name(), "grid_blocks": info["grid_blocks"], "blocks_per_cu": info["blocks_per_cu"],

@@ -10,8 +10,8 @@ using namespace tpt;
 static inline double urand(uint64_t& s) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (double)(s >> 11) * (1.0 / 9007199254740992.0); }
 int main(int argc, char** argv) {
     long long N = argc > 1 ? atoll(argv[1]) : 200000000LL;
-    long long bad = 0, refpos = 0, filtpos = 0, badGroup = 0;
-#pragma omp parallel reduction(+:bad,refpos,filtpos,badGroup)
+    long long bad = 0, refpos = 0, filtpos = 0, badGroup = 0, badMatrix = 0, matrixpos = 0;
+#pragma omp parallel reduction(+:bad,refpos,filtpos,badGroup,badMatrix,matrixpos)
     {
         uint64_t s = 0x9E3779B97F4A7C15ull * (omp_get_thread_num() + 1);
 #pragma omp for schedule(static)
@@ -40,6 +40,16 @@ int main(int argc, char** argv) {
             bool filt = memberFilter(sp, of, dk);
             refpos += ref; filtpos += filt;
             if (ref && !filt) bad++;
+            // matrix-core filter (phase1Matrix): the sphere alone in a table, same a_k / b_k / fmaf chain as the device
+            {
+                float am[TPT_MX_K], bm[TPT_MX_K], cm = 0.0f;
+                matrixSphereSide(sp.x, sp.y, sp.z, sp.w, am);
+                matrixRaySide(of, df, bm);
+                for (int k = 0; k < TPT_MX_K; ++k) cm = fma1(am[k], bm[k], cm);
+                const bool mf = (f2u(cm) >> 31) == 0u;
+                matrixpos += mf;
+                if (ref && !mf) badMatrix++;
+            }
             // group filter: a bounding sphere R = a + r around a centre displaced by a (rho = a / r up to 64)
             double rho = 64 * urand(s), a = rho * r, R = (a + r) * 1.00001;
             double u[3] = {2 * urand(s) - 1, 2 * urand(s) - 1, 2 * urand(s) - 1};
@@ -55,6 +65,7 @@ int main(int argc, char** argv) {
             if (ref && !gf) badGroup++;
         }
     }
-    printf("trials %lld  reference accepts %lld  filter passes %lld  FILTER MISSES %lld  GROUP FILTER MISSES %lld\n", N, refpos, filtpos, bad, badGroup);
-    return bad || badGroup ? 1 : 0;
+    printf("trials %lld  reference accepts %lld  filter passes %lld  matrix filter passes %lld  FILTER MISSES %lld  GROUP FILTER MISSES %lld  MATRIX FILTER MISSES %lld\n",
+           N, refpos, filtpos, matrixpos, bad, badGroup, badMatrix);
+    return bad || badGroup || badMatrix ? 1 : 0;
 }

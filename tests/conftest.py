@@ -28,6 +28,31 @@ def ref():
 
 
 @pytest.fixture(scope="session")
+def emu():
+    """tests/lane_emu.cpp: the per-lane device logic compiled for the host (test harness only)."""
+    import ctypes as C
+    import subprocess
+    out_dir = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    so = os.path.join(out_dir, "liblane_emu.so")
+    src = os.path.join(ROOT, "tests", "lane_emu.cpp")
+    inc = os.path.join(ROOT, "toypathtracer_amd", "csrc")
+    deps = [src] + [os.path.join(inc, f) for f in ("tpt_math.h", "tpt_trace.h", "tpt_scene.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
+                               "-I", inc, src, "-o", so])
+    lib = C.CDLL(so)
+    lib.emu_render.restype = C.c_int64
+    lib.emu_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 6 + [C.c_uint] + [C.c_int] * 3 + [C.c_void_p]
+    lib.emu_default_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    lib.emu_default_camera.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    for f in (lib.emu_sinf, lib.emu_cosf, lib.emu_pow5f):
+        f.restype = C.c_float
+        f.argtypes = [C.c_float]
+    return lib
+
+
+@pytest.fixture(scope="session")
 def tpt():
     """The product, initialised on the GPU (gpu tests only). Fails loudly if the HIP library is missing."""
     from toypathtracer_amd import api

@@ -57,6 +57,9 @@ int64_t emu_render_ex(const void* spheres, const void* mats, int count, const vo
                 if (hs == HS_SIMPLE)
                     done = fold == FOLD_FORWARD ? laneStep<HS_SIMPLE, FOLD_FORWARD>(L, sv, fc, stack)
                                                 : laneStep<HS_SIMPLE, FOLD_RECURSIVE>(L, sv, fc, stack);
+                else if (hs == HS_MATRIX && sv.mxR1 >= 0) // phase 1 = the matrix-core filter's restatement
+                    done = fold == FOLD_FORWARD ? laneStep<HS_MATRIX, FOLD_FORWARD>(L, sv, fc, stack)
+                                                : laneStep<HS_MATRIX, FOLD_RECURSIVE>(L, sv, fc, stack);
                 else
                     done = fold == FOLD_FORWARD ? laneStep<HS_TWO_PHASE_GROUPS, FOLD_FORWARD>(L, sv, fc, stack)
                                                 : laneStep<HS_TWO_PHASE_GROUPS, FOLD_RECURSIVE>(L, sv, fc, stack);
@@ -119,9 +122,27 @@ void emu_hit_spheres(const void* spheres, const void* mats, int count, int hs, c
     for (int i = 0; i < n; ++i) {
         f3 o = mk3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]), d = mk3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
         float t;
-        outId[i] = hs == 1 ? hitSpheres<HS_SIMPLE>(sv, o, d, TPT_MIN_T, TPT_MAX_T, t) : hitSpheres<HS_TWO_PHASE_GROUPS>(sv, o, d, TPT_MIN_T, TPT_MAX_T, t);
+        outId[i] = hs == 1                       ? hitSpheres<HS_SIMPLE>(sv, o, d, TPT_MIN_T, TPT_MAX_T, t)
+                   : (hs == 3 && sv.mxR1 >= 0) ? hitSpheres<HS_MATRIX>(sv, o, d, TPT_MIN_T, TPT_MAX_T, t)
+                                               : hitSpheres<HS_TWO_PHASE_GROUPS>(sv, o, d, TPT_MIN_T, TPT_MAX_T, t);
         outT[i] = t;
     }
+}
+
+// Candidate masks of the matrix-core filter's restatement (phase1MatrixRef: same table, same ray vector, the fmaf chain
+// the MFMA runs): the GPU test compares the device's masks with these bit for bit.  Returns mxR1 (< 0: no table).
+int emu_matrix_masks(const void* spheres, const void* mats, int count, const float* rays, int n, unsigned long long* outMask)
+{
+    std::vector<SpherePOD> S((const SpherePOD*)spheres, (const SpherePOD*)spheres + count);
+    std::vector<MaterialPOD> M((const MaterialPOD*)mats, (const MaterialPOD*)mats + count);
+    PackedScene P;
+    packScene(S, M, P);
+    if (P.mxR1 < 0) return -1;
+    for (int i = 0; i < n; ++i) {
+        f3 o = mk3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]), d = mk3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
+        outMask[i] = phase1MatrixRef(P.amat.data(), P.mxR1, P.nSpheres, o, d);
+    }
+    return P.mxR1;
 }
 
 } // extern "C"

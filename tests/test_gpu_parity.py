@@ -505,3 +505,52 @@ def test_config5_stress_scene_full_size_properties(tpt_defaults, oracle):
     tpt.set_kernel_variant(0, 1, -1)  # lane-refill kernel on the same frame
     r3, b3, _ = gpu_frames(tpt, w, h, 1)
     assert r3 == r1 and b3.tobytes() == b1.tobytes()
+
+
+# ---- phase 1 on the matrix cores
+def test_matrix_filter_masks_equal_the_restatement(tpt_defaults, emu, oracle):
+    """The candidate masks v_mfma_f32_32x32x2_f32 + the lane swaps produce on the device are, bit for bit, those of the
+    host restatement (same table, same ray vector, fmaf chain in k order) -- which the CPU suite proves conservative.
+    Checks the A/B/accumulator layouts, the padding rows and the mask assembly for one and two sphere tiles."""
+    import ctypes as C
+    from common import grazing_rays
+    from toypathtracer_amd.scenes import stress_scene
+    tpt = tpt_defaults
+    emu.emu_matrix_masks.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    emu.emu_matrix_masks.restype = C.c_int
+    rng = np.random.default_rng(5)
+    scenes = [oracle.default_scene()] + [stress_scene(n, 8) for n in (1, 3, 17, 32, 33, 40, 47, 56, 64)]
+    for (s, m) in scenes:
+        tpt.set_scene(s, m)
+        n = 6400 + 13  # not a multiple of 64
+        g = grazing_rays(s, n // 2)
+        o = rng.uniform(-12, 12, (n - n // 2, 3))
+        d = rng.normal(size=(n - n // 2, 3))
+        d /= np.linalg.norm(d, axis=1, keepdims=True)
+        d = d.astype(np.float32)
+        d = (d / np.linalg.norm(d.astype(np.float64), axis=1, keepdims=True)).astype(np.float32)
+        rays = np.concatenate([g, np.concatenate([o.astype(np.float32), d], 1)], 0).astype(np.float32)
+        want = np.zeros(n, np.uint64)
+        assert emu.emu_matrix_masks(s.ctypes.data, m.ctypes.data, len(s), rays.ctypes.data, n, want.ctypes.data) >= 0
+        got = tpt.test_matrix_filter(rays)
+        assert np.array_equal(got, want), len(s)
+    tpt.set_scene(None)
+
+
+@pytest.mark.parametrize("n", [1, 3, 32, 33, 47, 64, 65])
+def test_small_scenes_bit_exact(tpt_defaults, oracle, n):
+    """Scenes of 1..64 spheres take the matrix-core filter in the path-queue kernel (65: back to the packed VALU filter);
+    image and ray count against the oracle, and against the VALU filter (variant 3)."""
+    from toypathtracer_amd.scenes import stress_scene
+    tpt = tpt_defaults
+    s, m = stress_scene(n, 8)
+    w, h, spp = 200, 120, 2
+    tpt.set_scene(s, m)
+    tpt.set_samples_per_pixel(spp)
+    cam = oracle.default_camera(w, h)
+    ro, bo = oracle.render(s, m, cam, w, h, spp, 0, seed_mode=SEED_PER_PIXEL)
+    for hs in (0, 3):
+        tpt.set_kernel_variant(hs, 3, -1)
+        rays, bb, _ = gpu_frames(tpt, w, h, 1)
+        assert rays == ro and bb.tobytes() == bo.tobytes(), (n, hs)
+    tpt.set_scene(None)

@@ -15,28 +15,6 @@ from oracle_lib import CAMERA_DT, FLAG_PROGRESSIVE, MATERIAL_DT, SPHERE_DT, ROOT
 HS = {"two_phase": 0, "simple": 1}
 
 
-@pytest.fixture(scope="module")
-def emu():
-    out_dir = os.path.join(ROOT, "tests", "_build")
-    os.makedirs(out_dir, exist_ok=True)
-    so = os.path.join(out_dir, "liblane_emu.so")
-    src = os.path.join(ROOT, "tests", "lane_emu.cpp")
-    inc = os.path.join(ROOT, "toypathtracer_amd", "csrc")
-    deps = [src] + [os.path.join(inc, f) for f in ("tpt_math.h", "tpt_trace.h", "tpt_scene.h")]
-    if not os.path.exists(so) or any(os.path.getmtime(d) > os.path.getmtime(so) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-unknown-pragmas",
-                               "-I", inc, src, "-o", so])
-    lib = C.CDLL(so)
-    lib.emu_render.restype = C.c_int64
-    lib.emu_render.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 6 + [C.c_uint] + [C.c_int] * 3 + [C.c_void_p]
-    lib.emu_default_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-    lib.emu_default_camera.argtypes = [C.c_void_p, C.c_int, C.c_int]
-    for f in (lib.emu_sinf, lib.emu_cosf, lib.emu_pow5f):
-        f.restype = C.c_float
-        f.argtypes = [C.c_float]
-    return lib
-
-
 def emu_frames(emu, s, m, cam, w, h, spp, frames, flags, seed, hs, fold):
     bb = np.zeros((h, w, 4), np.float32)
     rays = 0
@@ -105,11 +83,13 @@ def test_two_phase_filter_is_conservative_on_grazing_rays(emu, oracle):
     for (s, m), n in ((oracle.default_scene(), 400000), (stress_scene(4096, 64), 20000)):
         rays = grazing_rays(s, n)
         out = []
-        for hs in (0, 1, 2):  # 0: two-phase (grouped for the 4096-sphere scene), 1: all-exact loop, 2: two-phase flat
+        # 0: two-phase (grouped for the 4096-sphere scene), 1: all-exact loop, 2: two-phase flat, 3: matrix-core filter's
+        # restatement as phase 1 (<= 64 spheres; the 4096-sphere scene has no table and takes the VALU filter)
+        for hs in (0, 1, 2, 3):
             ids, ts = np.empty(n, np.int32), np.empty(n, np.float32)
             emu.emu_hit_spheres(s.ctypes.data, m.ctypes.data, len(s), hs, rays.ctypes.data, n, ids.ctypes.data, ts.ctypes.data)
             out.append((ids, ts))
-        for k in (0, 2):
+        for k in (0, 2, 3):
             assert np.array_equal(out[k][0], out[1][0])
             assert np.array_equal(out[k][1].view(np.uint32), out[1][1].view(np.uint32))
         assert (out[1][0] >= 0).mean() > 0.3  # the generator does produce hits (and near misses)
@@ -180,4 +160,47 @@ def test_filters_never_miss_in_an_adversarial_search(tmp_path):
                            "-I", os.path.join(ROOT, "toypathtracer_amd", "csrc"), os.path.join(ROOT, "tests", "adversarial_filter.cpp"), "-o", exe])
     out = subprocess.run([exe, "60000000"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout
-    assert "FILTER MISSES 0" in out.stdout and "GROUP FILTER MISSES 0" in out.stdout
+    assert "FILTER MISSES 0" in out.stdout and "GROUP FILTER MISSES 0" in out.stdout and "MATRIX FILTER MISSES 0" in out.stdout
+
+
+def test_matrix_filter_restatement_renders_the_oracle_image(emu, oracle):
+    """Phase 1 on the matrix cores (tpt_trace.h, phase1Matrix) is a different conservative filter: expanded around the
+    coordinate origin, evaluated as a 12-term fmaf chain.  With its host restatement as phase 1 the lane logic must still
+    render the oracle's image bit for bit -- default scene (46 spheres: two sphere tiles, R1 = 8) and small scenes that
+    fill one tile, one tile exactly (32), and both completely (64)."""
+    from toypathtracer_amd.scenes import stress_scene
+    w, h, spp = 96, 54, 2
+    s, m = oracle.default_scene()
+    cam = oracle.default_camera(w, h)
+    ro, bo = oracle.render(s, m, cam, w, h, spp, 0, seed_mode=1)
+    re, be = emu_frames(emu, s, m, cam, w, h, spp, 1, FLAG_PROGRESSIVE, 1, 3, 0)
+    assert re == ro and be.tobytes() == bo.tobytes()
+    for n in (3, 32, 33, 64):
+        s, m = stress_scene(n, 8)
+        ro, bo = oracle.render(s, m, cam, w, h, spp, 0, seed_mode=1)
+        re, be = emu_frames(emu, s, m, cam, w, h, spp, 1, FLAG_PROGRESSIVE, 1, 3, 0)
+        assert re == ro and be.tobytes() == bo.tobytes(), n
+
+
+def test_matrix_filter_mask_layout(emu, oracle):
+    """The candidate mask lists the spheres in ascending index (bit 63 - p): every sphere the exact test hits must have
+    its bit set, padding bits are clear, and a far-away ray pointing away from everything has (almost) no candidates."""
+    import ctypes as C
+    from common import grazing_rays
+    emu.emu_matrix_masks.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    emu.emu_matrix_masks.restype = C.c_int
+    emu.emu_hit_spheres.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    emu.emu_hit_spheres.restype = None
+    s, m = oracle.default_scene()
+    n = 20000
+    rays = grazing_rays(s, n)
+    masks = np.zeros(n, np.uint64)
+    assert emu.emu_matrix_masks(s.ctypes.data, m.ctypes.data, 46, rays.ctypes.data, n, masks.ctypes.data) == 8
+    ids, ts = np.empty(n, np.int32), np.empty(n, np.float32)
+    emu.emu_hit_spheres(s.ctypes.data, m.ctypes.data, 46, 1, rays.ctypes.data, n, ids.ctypes.data, ts.ctypes.data)
+    hit = ids >= 0
+    bit = (masks[hit] >> (np.uint64(63) - ids[hit].astype(np.uint64))) & np.uint64(1)
+    assert bit.all()
+    assert (masks & np.uint64((1 << 18) - 1)).max() == 0  # bits of spheres 46..63 never set
+    counts = np.array([bin(int(x)).count("1") for x in masks[:2000]])
+    assert counts.mean() < 6  # a filter, not a pass-through

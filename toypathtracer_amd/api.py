@@ -79,7 +79,7 @@ def load_library():
         "tptSetRayCounter": [p], "tptSetTileMirror": [p, p], "tptSetFrameOverlap": [i], "tptDisplayRGBA8": [p, i, i, p], "tptKernelTimingBegin": [i],
         "tptKernelTimingEnd": [C.POINTER(f), C.POINTER(i)],
         "tptSynchronize": [], "tptTimerBegin": [], "tptTimerEnd": [C.POINTER(f)], "tptSetKernelVariant": [i, i, i],
-        "tptDebugStats": [p, i], "tptDebugChunkOrder": [p, p, i], "tptTestMath": [i, p, p, p, i], "tptTestHitSpheres": [i, p, p, p, i], "tptGetLaunchInfo": [C.POINTER(i)] * 4,
+        "tptDebugStats": [p, i], "tptDebugChunkOrder": [p, p, i], "tptTestMath": [i, p, p, p, i], "tptTestHitSpheres": [i, p, p, p, i], "tptTestMatrixFilter": [p, p, i], "tptGetLaunchInfo": [C.POINTER(i)] * 4,
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -150,7 +150,7 @@ def set_fold_mode(mode):
     _chk(load_library().tptSetFoldMode(mode), "tptSetFoldMode")
 
 
-def set_kernel_variant(hit_spheres=0, persistent=1, lds_scene=-1):
+def set_kernel_variant(hit_spheres=0, persistent=3, lds_scene=-1):
     _chk(load_library().tptSetKernelVariant(hit_spheres, persistent, lds_scene), "tptSetKernelVariant")
 
 
@@ -305,3 +305,12 @@ def test_hit_spheres(rays, hit_spheres=0):
     _chk(load_library().tptTestHitSpheres(hit_spheres, rays.ctypes.data, ids.ctypes.data, ts.ctypes.data, n),
          "tptTestHitSpheres")
     return ids, ts
+
+
+def test_matrix_filter(rays):
+    """Candidate masks (sphere p at bit 63 - p) of the matrix-core phase-1 filter for n rays, current scene."""
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+    n = rays.shape[0]
+    masks = np.zeros(n, np.uint64)
+    _chk(load_library().tptTestMatrixFilter(rays.ctypes.data, masks.ctypes.data, n), "tptTestMatrixFilter")
+    return masks

@@ -23,7 +23,7 @@ using namespace tpt;
 namespace {
 
 struct Context {
-    static const int kMaxOverlap = 16;              // frames in flight (trace streams, colour buffers, ...)
+    static const int kMaxOverlap = 32;              // frames in flight (trace streams, colour buffers, ...)
     static const int kOrderTables = kMaxOverlap + 2; // rotating chunk-order tables: more than frames in flight
     bool inited = false;
     int device = 0, numCUs = 0;
@@ -53,6 +53,8 @@ struct Context {
         size_t cap = 0, bytes = 0;
         size_t offSph4 = 0, offInvR = 0, offMats = 0, offLights = 0;
         size_t offGPairs = 0, offGSph = 0, offGId = 0, offBSph = 0, offBId = 0; // grouped representation (large scenes)
+        size_t offAmat = 0; // matrix-core filter table (small scenes)
+        int mxR1 = -1;
         int nSpheres = 0, nPairs = 0, nLights = 0;
         int nGroups = 0, nGroupPairs = 0, nBig = 0;
         hipEvent_t evUploaded = nullptr;
@@ -67,12 +69,14 @@ struct Context {
     int seedMode = SEED_PER_PIXEL;
     int foldMode = FOLD_RECURSIVE;
     int allowGroups = 1; // hitSpheres variant 2 = two-phase, brute force even for large scenes
+    int useMatrix = 1;   // phase 1 of HitSpheres on the matrix cores where it applies (hitSpheres variant 3 = VALU filter everywhere)
     int hs = HS_TWO_PHASE, persist = 3, ldsScene = -1; // persist 3 = path queues (falls back to 1 where they do not apply)
     int stripeRows = 0, numParts = 1, part = 0;
     int maxBlocksPerCU = 0, chunkOverride = 0; // tuning knobs (env TPT_MAX_BLOCKS_PER_CU, TPT_CHUNK)
     int gridFill = 0;                           // env TPT_GRID_FILL: % of the resident slots all in-flight launches ask for
     int gridDiv = 0;                            // env TPT_GRID_DIV: launch resident/gridDiv workgroups per frame; 0 = adaptive
     unsigned long long oldestPending = 0;       // adaptive grid: oldest frame whose trace kernel may still be running
+    int streamDepth = 1, prevInFlight = -1;     // adaptive grid: deepest pipeline the caller has built / in flight at the previous enqueue
     int ldsStackLevels = 6;                     // recursive fold: bounce-stack levels kept in LDS (env TPT_LDS_STACK_LEVELS)
 
     float* mirror = nullptr;                    // tptSetTileMirror: second destination of the resolve kernel
@@ -83,7 +87,9 @@ struct Context {
     long long lastTotal = 0;
 
     f4* dStack[kMaxOverlap] = {};       // recursive fold: global bounce stacks / spill levels (one per in-flight frame)
-    size_t stackCap[kMaxOverlap] = {};
+    size_t stackCap = 0, colourCap = 0, pathCap = 0; // bytes per slot; all reserved slots have the same capacities
+    int slotsReserved = 0;              // slots [0, slotsReserved) hold buffers of those capacities
+    int slotReservations = 0;           // how often the slot buffers were (re-)allocated (tptGetPipelineInfo)
     // cost-ordered chunk distribution (persistent kernel)
     unsigned* dChunkCost = nullptr;
     unsigned* dChunkOrder[kOrderTables] = {};
@@ -96,7 +102,6 @@ struct Context {
     unsigned long long orderSeq = 0;
     int lastOrderTable = 0;
     f4* dPath[kMaxOverlap] = {};        // path-queue kernel: cold path state (one per in-flight frame)
-    size_t pathCap[kMaxOverlap] = {};
     float* dFrame = nullptr; // device tile behind the host-pointer DrawTest
     const float* uploadSrc = nullptr; // tptDraw: host backbuffer whose rows tptDrawDevice uploads once the trace is launched
     size_t frameCap = 0;
@@ -108,7 +113,6 @@ struct Context {
     hipEvent_t evTrace[kMaxOverlap] = {}, evResolve[kMaxOverlap] = {};
     bool resolveRecorded[kMaxOverlap] = {};
     f4* dColour[kMaxOverlap] = {};
-    size_t colourCap[kMaxOverlap] = {};
     unsigned long long frameSeq = 0;
 
     // per-launch timing of the trace kernel: hipEvent pairs on the stream each launch goes to
@@ -193,7 +197,8 @@ int stageScene()
     const size_t offSph4 = align256(bPairs), offInvR = offSph4 + align256(bSph4), offMats = offInvR + align256(bInvR),
                  offLights = offMats + align256(bMats), offGPairs = offLights + align256(bLights + 32),
                  offGSph = offGPairs + align256(bGPairs), offGId = offGSph + align256(bGSph), offBSph = offGId + align256(bGId),
-                 offBId = offBSph + align256(bBSph), total = offBId + align256(bBId + 32);
+                 offBId = offBSph + align256(bBSph), offAmat = offBId + align256(bBId + 32);
+    const size_t bAmat = (g.useMatrix && P.mxR1 >= 0) ? P.amat.size() * sizeof(float) : 0, total = offAmat + align256(bAmat + 32);
     if (!S.evUploaded) HIPCHK(hipEventCreateWithFlags(&S.evUploaded, kOrderingEvent));
     // the previous copy out of this staging blob (kSceneSets uploads ago) must have left the host before we overwrite it:
     // only ever waits when the host has run more than 16 animated frames ahead of the GPU
@@ -220,7 +225,10 @@ int stageScene()
         if (bBSph) memcpy(S.stage + offBSph, P.bsph.data(), bBSph);
         if (bBId) memcpy(S.stage + offBId, P.bid.data(), bBId);
     }
-    S.bytes = offBId + bBId;
+    if (bAmat) memcpy(S.stage + offAmat, P.amat.data(), bAmat);
+    S.bytes = offAmat + bAmat;
+    S.offAmat = offAmat;
+    S.mxR1 = bAmat ? P.mxR1 : -1;
     S.offSph4 = offSph4; S.offInvR = offInvR; S.offMats = offMats; S.offLights = offLights;
     S.offGPairs = offGPairs; S.offGSph = offGSph; S.offGId = offGId; S.offBSph = offBSph; S.offBId = offBId;
     S.nSpheres = P.nSpheres; S.nPairs = P.nPairs; S.nLights = P.nLights;
@@ -259,6 +267,8 @@ SceneView deviceView()
     sv.nGroups = S->nGroups;
     sv.nGroupPairs = S->nGroupPairs;
     sv.nBig = S->nBig;
+    sv.amat = reinterpret_cast<const float*>(S->dev + S->offAmat);
+    sv.mxR1 = S->mxR1;
     return sv;
 }
 
@@ -349,7 +359,8 @@ int tptInitialize(void)
     const char* env = getenv("TPT_DEVICE");
     if (!env) env = getenv("LOCAL_RANK");
     if (env) dev = atoi(env);
-    if (dev < 0 || dev >= count) dev = dev % count;
+    if (dev < 0) return fail("tptInitialize: negative device index in TPT_DEVICE / LOCAL_RANK");
+    if (dev >= count) dev = dev % count;
     HIPCHK(hipSetDevice(dev));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, dev));
@@ -363,7 +374,9 @@ int tptInitialize(void)
     HIPCHK(hipEventCreate(&g.ev0));
     HIPCHK(hipEventCreate(&g.ev1));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dWork), 64 * Context::kMaxOverlap));
-    HIPCHK(hipMemset(g.dWork, 0, 64 * Context::kMaxOverlap));
+    // (memsets go to the stream that orders them against the first kernels: every stream of this context is
+    //  non-blocking, the legacy null stream would order nothing)
+    HIPCHK(hipMemsetAsync(g.dWork, 0, 64 * Context::kMaxOverlap, g.stream));
     for (int k = 0; k < Context::kMaxOverlap; ++k) {
         HIPCHK(hipStreamCreateWithFlags(&g.traceStream[k], hipStreamNonBlocking));
         HIPCHK(hipEventCreateWithFlags(&g.evTrace[k], kOrderingEvent));
@@ -373,7 +386,8 @@ int tptInitialize(void)
     g.frameSeq = 0;
     g.oldestPending = 0;
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dRaysOwn), 64));
-    HIPCHK(hipMemset(g.dRaysOwn, 0, 64));
+    HIPCHK(hipMemsetAsync(g.dRaysOwn, 0, 64, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
     g.dRays = g.dRaysOwn;
     g.lastTotal = 0;
     if (g.spheres.empty()) defaultScene(g.spheres, g.mats);
@@ -418,10 +432,11 @@ int tptShutdown(void)
         if (g.evTrace[k]) (void)hipEventDestroy(g.evTrace[k]);
         if (g.evResolve[k]) (void)hipEventDestroy(g.evResolve[k]);
         (void)hipFree(g.dColour[k]);
-        (void)hipFree(g.dStack[k]); g.dStack[k] = nullptr; g.stackCap[k] = 0;
-        (void)hipFree(g.dPath[k]); g.dPath[k] = nullptr; g.pathCap[k] = 0;
-        g.traceStream[k] = nullptr; g.evTrace[k] = nullptr; g.evResolve[k] = nullptr; g.dColour[k] = nullptr; g.colourCap[k] = 0;
+        (void)hipFree(g.dStack[k]); g.dStack[k] = nullptr;
+        (void)hipFree(g.dPath[k]); g.dPath[k] = nullptr;
+        g.traceStream[k] = nullptr; g.evTrace[k] = nullptr; g.evResolve[k] = nullptr; g.dColour[k] = nullptr;
     }
+    g.stackCap = g.colourCap = g.pathCap = 0; g.slotsReserved = 0; g.slotReservations = 0;
     (void)hipEventDestroy(g.ev0); (void)hipEventDestroy(g.ev1);
     if (g.evOrder) { (void)hipEventDestroy(g.evOrder); g.evOrder = nullptr; }
     (void)hipStreamDestroy(g.ownStream);
@@ -431,6 +446,7 @@ int tptShutdown(void)
     g.occCache.clear();
     g.mirror = nullptr; g.mirrorCounter = nullptr; g.uploadSrc = nullptr;
     g.orderDone = true; g.orderStream = nullptr; g.oldestPending = 0; g.frameSeq = 0;
+    g.streamDepth = 1; g.prevInFlight = -1;
     return 0;
 }
 
@@ -496,7 +512,7 @@ int tptKernelTimingEnd(float* outSumMs, int* outLaunches)
 
 int tptSetFrameOverlap(int frames)
 {
-    if (frames < 1 || frames > Context::kMaxOverlap) return fail("tptSetFrameOverlap: 1..16");
+    if (frames < 1 || frames > Context::kMaxOverlap) return fail("tptSetFrameOverlap: 1..32");
     if (g.inited) {
         HIPCHK(hipStreamSynchronize(g.stream));
         for (int k = 0; k < Context::kMaxOverlap; ++k)
@@ -505,6 +521,7 @@ int tptSetFrameOverlap(int frames)
     g.overlap = frames;
     g.frameSeq = 0;
     g.oldestPending = 0;
+    g.streamDepth = 1; g.prevInFlight = -1;
     for (int k = 0; k < Context::kMaxOverlap; ++k) g.resolveRecorded[k] = false;
     return 0;
 }
@@ -512,10 +529,11 @@ int tptSetFrameOverlap(int frames)
 int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene)
 {
     g.hs = hitSpheres == 1 ? HS_SIMPLE : HS_TWO_PHASE;
-    const int allow = hitSpheres == 2 ? 0 : 1;
-    if (allow != g.allowGroups) {
+    const int allow = hitSpheres == 2 ? 0 : 1, matrix = hitSpheres == 3 ? 0 : 1;
+    if (allow != g.allowGroups || matrix != g.useMatrix) {
         g.allowGroups = allow;
-        g.sceneDirty = true; // the staged scene set carries (or not) the grouped arrays
+        g.useMatrix = matrix;
+        g.sceneDirty = true; // the staged scene set carries (or not) the grouped arrays / the matrix table
     }
     g.persist = persistent < 0 ? 0 : (persistent > 3 ? 3 : persistent);
     g.ldsScene = ldsScene < 0 ? -1 : (ldsScene ? 1 : 0);
@@ -600,17 +618,41 @@ struct FramePlan {
     int nOverlap = 1, slot = 0; // frames in flight allowed / this frame's slot (trace stream, colour buffer, ...)
 };
 
-// Grow one of the per-slot device buffers (colour, bounce stack, path state).  Nothing may still use the old one.
-template <class T>
-int growSlotBuffer(T*& p, size_t& capBytes, size_t needBytes, int slot)
+// Per-slot device buffers (frame colour, bounce stacks, path colour sums) are allocated for ALL slots of the pipeline at
+// once, sized for the largest grid this kernel can ever be launched with at this frame shape -- never on the per-frame
+// path: a lazily grown slot drained the whole pipeline (two stream syncs + hipFree/hipMalloc) on every first use, and with
+// fewer warm-up frames than slots those drains landed inside the caller's timed region (round-1 driver bench: 17 instead
+// of 35 Gray/s).  A re-allocation happens only when the frame shape / kernel variant / overlap asks for MORE than any
+// earlier frame did; it synchronises everything once.
+int syncAllStreams();
+int reserveSlotBuffers(int nSlots, size_t colourBytes, size_t stackBytes, size_t pathBytes)
 {
-    if (needBytes <= capBytes) return 0;
-    HIPCHK(hipStreamSynchronize(g.stream));
-    HIPCHK(hipStreamSynchronize(g.traceStream[slot]));
-    if (p) HIPCHK(hipFree(p));
-    p = nullptr;
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&p), needBytes));
-    capBytes = needBytes;
+    if (nSlots <= g.slotsReserved && colourBytes <= g.colourCap && stackBytes <= g.stackCap && pathBytes <= g.pathCap) return 0;
+    int rc = syncAllStreams();
+    if (rc) return rc;
+    const size_t cb = colourBytes > g.colourCap ? colourBytes : g.colourCap, sb = stackBytes > g.stackCap ? stackBytes : g.stackCap,
+                 pb = pathBytes > g.pathCap ? pathBytes : g.pathCap;
+    const int n = nSlots > g.slotsReserved ? nSlots : g.slotsReserved;
+    for (int k = 0; k < n; ++k) {
+        const bool fresh = k >= g.slotsReserved;
+        if (fresh || cb > g.colourCap) {
+            if (g.dColour[k]) HIPCHK(hipFree(g.dColour[k]));
+            g.dColour[k] = nullptr;
+            if (cb) HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dColour[k]), cb));
+        }
+        if (fresh || sb > g.stackCap) {
+            if (g.dStack[k]) HIPCHK(hipFree(g.dStack[k]));
+            g.dStack[k] = nullptr;
+            if (sb) HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dStack[k]), sb));
+        }
+        if (fresh || pb > g.pathCap) {
+            if (g.dPath[k]) HIPCHK(hipFree(g.dPath[k]));
+            g.dPath[k] = nullptr;
+            if (pb) HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dPath[k]), pb));
+        }
+    }
+    g.colourCap = cb; g.stackCap = sb; g.pathCap = pb; g.slotsReserved = n;
+    g.slotReservations++;
     return 0;
 }
 
@@ -630,8 +672,12 @@ int chooseKernel(FramePlan& P)
     const size_t ldsV1 = tptLdsBytes(a, g.foldMode, P.ldsScene);
     P.sorted = g.persist == 2 && !P.rowSerial && g.hs == HS_TWO_PHASE; // lane-sorting kernel (PER_PIXEL seeds only)
     // path-queue kernel: PER_PIXEL seeds, recursive fold, two-phase HitSpheres
-    P.queued = g.persist == 3 && !P.rowSerial && g.hs == HS_TWO_PHASE && g.foldMode == FOLD_RECURSIVE;
+    // (it packs a pixel as x | y << 16 and a path id as 16 bits: larger frames take the lane-refill kernel)
+    P.queued = g.persist == 3 && !P.rowSerial && g.hs == HS_TWO_PHASE && g.foldMode == FOLD_RECURSIVE && a.fc.width <= 65535 &&
+               a.fc.height <= 65535;
     P.lds = P.queued ? tptQueueLdsBytes(a, P.ldsScene) : P.sorted ? tptSortedLdsBytes(a, g.foldMode, P.ldsScene) : ldsV1;
+    if ((size_t)a.scene.nLights * 32 > 96 * 1024)
+        return fail("tptDrawDevice: too many emissive spheres for the LDS light table (3072 at most)");
     if (P.lds > 160 * 1024) return fail("tptDrawDevice: scene too large for LDS staging; use tptSetKernelVariant(.., .., 0)");
     if (P.sorted || P.queued) a.ldsStackLevels = 0;
     const int key = (P.queued ? (1 << 30) : 0) | (P.sorted ? 16 : 0) | (g.hs ? 8 : 0) | (g.foldMode ? 4 : 0) | (g.persist ? 2 : 0) |
@@ -681,7 +727,18 @@ void sizeGrid(FramePlan& P)
         cap = resident / g.gridDiv;
     } else {
         const int fill = g.gridFill > 0 ? g.gridFill : (g.numParts > 1 ? 100 : 200);
-        const int k = framesInFlight(P.nOverlap) + 1;
+        // k = how many launches share the machine.  Not just what is in flight right now: a caller that streams frames
+        // (enqueue, enqueue, ..., synchronise once) starts every burst with an empty pipeline, and whole-machine grids
+        // for the first frames of a burst serialise them (each with its own tail) -- a 20-frame burst ran at 24 instead
+        // of 33 Gray/s.  So the deepest pipeline this caller has built is remembered (streamDepth) and only forgotten
+        // when two consecutive frames find the pipeline empty: that is a caller who synchronises every frame
+        // (the reference's DrawTest contract) and gets the whole machine.
+        const int inFlight = framesInFlight(P.nOverlap);
+        if (inFlight == 0 && g.prevInFlight == 0) g.streamDepth = 1;
+        if (inFlight + 1 > g.streamDepth) g.streamDepth = inFlight + 1;
+        g.prevInFlight = inFlight;
+        int k = g.streamDepth;
+        if (k > P.nOverlap) k = P.nOverlap;
         cap = (int)((long long)resident * fill / (100ll * k));
         if (cap > resident) cap = resident;
         const int floorBlocks = resident / (2 * (P.nOverlap > 1 ? P.nOverlap : 1));
@@ -694,31 +751,41 @@ void sizeGrid(FramePlan& P)
     a.totalWaves = (unsigned)(blocks * wavesPerBlock);
 }
 
+// Largest number of workgroups sizeGrid can ever pick for this kernel at this frame shape.
+int maxGridBlocks(const FramePlan& P)
+{
+    const KernelArgs& a = P.a;
+    if (!g.persist) return (a.numItems + TPT_BLOCK - 1) / TPT_BLOCK;
+    const int wavesPerBlock = P.threadsPerBlock / 64;
+    const int resident = g.numCUs * P.occ;
+    const int minChunk = P.rowSerial ? 1 : 64;
+    const int byWork = ((a.numItems + minChunk - 1) / minChunk + wavesPerBlock - 1) / wavesPerBlock;
+    int m = resident < byWork ? resident : byWork;
+    return m < 1 ? 1 : m;
+}
+
 // Per-slot buffers of this frame: colour, bounce-stack spill / per-path stacks, path colour sums.
 int ensureFrameBuffers(FramePlan& P, int w)
 {
     KernelArgs& a = P.a;
     const int slot = P.slot;
-    int rc = growSlotBuffer(g.dColour[slot], g.colourCap[slot], (size_t)a.nLocalRows * w * sizeof(f4), slot);
+    const int maxBlocks = maxGridBlocks(P);
+    const bool needStack = g.persist && g.foldMode == FOLD_RECURSIVE && a.ldsStackLevels < TPT_MAX_DEPTH;
+    const size_t maxColumns = (size_t)maxBlocks * (size_t)(P.queued ? tptQueuePathsPerBlock() : P.threadsPerBlock);
+    const size_t stackBytes = needStack ? maxColumns * (size_t)(TPT_MAX_DEPTH - a.ldsStackLevels) * sizeof(f4) : 0;
+    const size_t pathBytes = P.queued ? maxColumns * sizeof(f4) : 0; // one colour sum per path
+    int rc = reserveSlotBuffers(P.nOverlap, (size_t)a.nLocalRows * w * sizeof(f4), stackBytes, pathBytes);
     if (rc) return rc;
     a.frameColour = g.dColour[slot];
     a.work = g.dWork + 16 * slot;
     a.rayCounter = g.dRays;
     a.stackBuf = nullptr;
     a.stackStride = 0;
-    const int stackColumns = P.queued ? P.blocks * tptQueuePathsPerBlock() : P.blocks * P.threadsPerBlock;
-    if (g.persist && g.foldMode == FOLD_RECURSIVE && a.ldsStackLevels < TPT_MAX_DEPTH) {
-        rc = growSlotBuffer(g.dStack[slot], g.stackCap[slot], (size_t)stackColumns * (TPT_MAX_DEPTH - a.ldsStackLevels) * sizeof(f4), slot);
-        if (rc) return rc;
+    if (needStack) {
         a.stackBuf = g.dStack[slot];
-        a.stackStride = stackColumns;
+        a.stackStride = P.queued ? P.blocks * tptQueuePathsPerBlock() : P.blocks * P.threadsPerBlock;
     }
-    a.pathBuf = nullptr;
-    if (P.queued) {
-        rc = growSlotBuffer(g.dPath[slot], g.pathCap[slot], (size_t)P.blocks * tptQueuePathsPerBlock() * sizeof(f4), slot); // one colour sum per path
-        if (rc) return rc;
-        a.pathBuf = g.dPath[slot];
-    }
+    a.pathBuf = P.queued ? g.dPath[slot] : nullptr;
     return 0;
 }
 
@@ -764,7 +831,8 @@ int prepareChunkOrder(FramePlan& P)
     if (g.chunkCount != a.numChunks) { // new resolution / sharding: statistics start over
         int rc = syncAllStreams();
         if (rc) return rc;
-        HIPCHK(hipMemset(g.dChunkCost, 0, bytes));
+        HIPCHK(hipMemsetAsync(g.dChunkCost, 0, bytes, g.stream));
+        HIPCHK(hipStreamSynchronize(g.stream));
         g.chunkCount = a.numChunks;
         g.orderSeq = 0;
         g.orderDone = true;
@@ -1061,6 +1129,39 @@ int tptTestMath(int op, const float* a, const float* b, float* out, int n)
     HIPCHK(hipStreamSynchronize(g.stream));
     HIPCHK(hipMemcpy(out, dout, sizeof(float) * n, hipMemcpyDeviceToHost));
     (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    return 0;
+}
+
+// Phase 1 on the matrix cores alone: candidate masks (sphere p at bit 63 - p) of n host rays against the current scene
+// (<= 64 spheres).  The CPU tests hold the bit-exact restatement (phase1MatrixRef).
+int tptTestMatrixFilter(const float* rays, unsigned long long* outMask, int n)
+{
+    if (requireInit()) return -1;
+    if (!rays || !outMask || n <= 0) return fail("tptTestMatrixFilter: bad arguments");
+    if (g.sceneDirty || (g.curSet < 0 && g.pendingSet < 0)) {
+        int rc = stageScene();
+        if (rc) return rc;
+    }
+    {
+        int rc = enqueueSceneUpload(g.stream);
+        if (rc) return rc;
+    }
+    KernelArgs a;
+    memset(&a, 0, sizeof(a));
+    a.scene = deviceView();
+    if (a.scene.mxR1 < 0) return fail("tptTestMatrixFilter: the current scene has no matrix table (more than 64 spheres, or variant 3)");
+    const int nPad = (n + 63) / 64 * 64;
+    std::vector<float> padded((size_t)nPad * 6, 0.0f);
+    memcpy(padded.data(), rays, sizeof(float) * 6 * (size_t)n);
+    float* dr = nullptr;
+    unsigned long long* dm = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&dr), sizeof(float) * 6 * nPad));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&dm), sizeof(unsigned long long) * nPad));
+    HIPCHK(hipMemcpy(dr, padded.data(), sizeof(float) * 6 * nPad, hipMemcpyHostToDevice));
+    HIPCHK(tptLaunchMatrixFilterTest(a, dr, dm, nPad, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipMemcpy(outMask, dm, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
+    (void)hipFree(dr); (void)hipFree(dm);
     return 0;
 }
 

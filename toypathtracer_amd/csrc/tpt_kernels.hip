@@ -590,7 +590,15 @@ __device__ __forceinline__ void qPushByClass(volatile unsigned short* q, QueueCt
         const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)pos, c);
         if (cls == c) base = b;
     }
-    if (cls >= 0) q[cls * TPT_Q_P + ((base + (unsigned)__popcll(mine & ((1ull << lane) - 1ull))) & (TPT_Q_P - 1))] = (unsigned short)pathId;
+    if (cls >= 0) {
+        volatile unsigned short* slot = q + cls * TPT_Q_P + ((base + (unsigned)__popcll(mine & ((1ull << lane) - 1ull))) & (TPT_Q_P - 1));
+        // A consumer advances the head BEFORE it reads its slots, and ids can cycle through a ring any number of times
+        // while one consumer stalls between those two steps (FREE: pop, no pixel left, push again): the tail may lap a
+        // reserved-but-unread slot.  Publish only into a slot whose previous entry has been taken (sentinel restored).
+        while (*slot != 0xFFFFu) {
+        }
+        *slot = (unsigned short)pathId;
+    }
 }
 // Pops up to 64 ids (uniform count returned); lanes < count receive a path id.
 __device__ __forceinline__ int qPop(volatile unsigned short* q, unsigned* head, unsigned* tail, int lane, int& pathId)
@@ -687,6 +695,10 @@ tptTraceQueueKernel(const KernelArgs a)
     volatile unsigned short* q = reinterpret_cast<volatile unsigned short*>(smem + off);
     off += Q_COUNT * TPT_Q_P * 2;
     QueueCtl* ctl = reinterpret_cast<QueueCtl*>(smem + off);
+    off += (int)sizeof(QueueCtl) + 64 - (int)sizeof(QueueCtl) % 64;
+    // phase 1 on the matrix cores (scenes of <= 64 spheres): the A-operand table, 3 KB
+    const bool useMatrix = LDS_SCENE && a.scene.mxR1 >= 0;
+    float* ldsA = reinterpret_cast<float*>(smem + off);
 
     const int tid = threadIdx.x, lane = tid & 63;
     SceneView sv = a.scene;
@@ -702,6 +714,9 @@ tptTraceQueueKernel(const KernelArgs a)
     }
     for (int i = tid; i < a.scene.nLights * 2; i += TPT_Q_T) ldsLights[i] = a.scene.lights[i];
     sv.lights = ldsLights;
+    if (useMatrix)
+        for (int i = tid; i < 2 * 6 * 64; i += TPT_Q_T) ldsA[i] = a.scene.amat[i];
+    const int mxR1 = a.scene.mxR1;
     // every path starts in the FREE queue; all other queues empty (sentinel everywhere)
     for (int i = tid; i < Q_COUNT * TPT_Q_P; i += TPT_Q_T) q[i] = (unsigned short)(i < TPT_Q_P ? i : 0xFFFF);
     if (tid < 8) {
@@ -903,10 +918,16 @@ tptTraceQueueKernel(const KernelArgs a)
             float hitT = 0.0f;
             bool pending = ray;
             while (__ballot(pending) != 0ull) {
+                // phase 1 of HitSpheres for the whole wave on the matrix cores (every lane takes part; lanes without a ray
+                // feed whatever finite values they hold and ignore their mask)
+                uint64_t cand = 0ull;
+                if (LDS_SCENE && useMatrix) cand = phase1Matrix(ldsA, mxR1, L.orig, L.dir);
                 if (pending) {
                     TPT_STAT(ST_STEP);
                     float t;
-                    const int id = hitSpheres<LDS_SCENE ? HS_TWO_PHASE : HS_TWO_PHASE_GROUPS>(sv, L.orig, L.dir, TPT_MIN_T, TPT_MAX_T, t);
+                    const int id = (LDS_SCENE && useMatrix)
+                                       ? hitSpheresCandidates(sv, cand, L.orig, L.dir, TPT_MIN_T, TPT_MAX_T, t)
+                                       : hitSpheres<LDS_SCENE ? HS_TWO_PHASE : HS_TWO_PHASE_GROUPS>(sv, L.orig, L.dir, TPT_MIN_T, TPT_MAX_T, t);
                     myRays++;
                     if (L.kind == KIND_SHADOW) {
                         (void)lanePost<FOLD_RECURSIVE>(L, id, t, sv, fc, stack); // Test.cpp:123-132, then next light or bounce
@@ -988,6 +1009,17 @@ __global__ void tptHitTestKernel(const KernelArgs a, const float* __restrict__ r
     int id = hitSpheres<HS>(a.scene, o, d, TPT_MIN_T, TPT_MAX_T, t);
     outId[i] = id;
     outT[i] = t;
+}
+
+// matrix-core filter alone: n rays (n a multiple of 64; one wave per 64), candidate masks out
+__global__ void __launch_bounds__(64) tptMatrixFilterTestKernel(const KernelArgs a, const float* __restrict__ rays, unsigned long long* __restrict__ outMask, int n)
+{
+    __shared__ float ldsA[2 * 6 * 64];
+    for (int i = threadIdx.x; i < 2 * 6 * 64; i += 64) ldsA[i] = a.scene.amat[i];
+    __syncthreads();
+    const int i = blockIdx.x * 64 + threadIdx.x; // n is padded to whole waves by the caller
+    f3 o = mk3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]), d = mk3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
+    outMask[i] = phase1Matrix(ldsA, a.scene.mxR1, o, d);
 }
 
 } // namespace tpt
@@ -1128,6 +1160,7 @@ size_t tptQueueLdsBytes(const KernelArgs& a, bool ldsScene)
     if (ldsScene) bytes += (size_t)nPad * 16 + (((size_t)nPad * 4 + 15) & ~(size_t)15) + (size_t)a.scene.nSpheres * 48;
     bytes += (size_t)a.scene.nLights * 32;
     bytes += (size_t)TPT_Q_NF4 * TPT_Q_P * 16 + (size_t)Q_COUNT * TPT_Q_P * 2 + sizeof(QueueCtl) + 64;
+    if (ldsScene && a.scene.mxR1 >= 0) bytes += 2 * 6 * 64 * sizeof(float) + 64;
     return bytes;
 }
 hipError_t tptLaunchTraceQueue(const KernelArgs& a, bool ldsScene, int blocks, size_t lds, hipStream_t stream)
@@ -1176,6 +1209,11 @@ hipError_t tptLaunchResolve(float* tile, const f4* frameColour, int nPixels, flo
 hipError_t tptLaunchMathTest(int op, const float* a, const float* b, float* out, int n, hipStream_t stream)
 {
     hipLaunchKernelGGL(tptMathTestKernel, dim3((n + 255) / 256), dim3(256), 0, stream, op, a, b, out, n);
+    return hipGetLastError();
+}
+hipError_t tptLaunchMatrixFilterTest(const KernelArgs& a, const float* rays, unsigned long long* outMask, int n, hipStream_t stream)
+{
+    hipLaunchKernelGGL(tptMatrixFilterTestKernel, dim3(n / 64), dim3(64), 0, stream, a, rays, outMask, n);
     return hipGetLastError();
 }
 hipError_t tptLaunchHitTest(const KernelArgs& a, int hs, const float* rays, int* outId, float* outT, int n, hipStream_t stream)

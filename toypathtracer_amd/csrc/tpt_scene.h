@@ -125,7 +125,48 @@ struct PackedScene {
     std::vector<f4> bsph;      // the big spheres {centre, r^2} ...
     std::vector<int> bid;      // ... and their original indices (ascending)
     int nGroups = 0, nGroupPairs = 0, nBig = 0;
+    std::vector<float> amat; // [2][6][64] A operands of the matrix-core filter (phase1Matrix); empty: not available
+    int mxR1 = -1;
 };
+
+// a_k of one sphere for the matrix-core filter (tpt_trace.h, phase1Matrix): binary64, rounded once
+inline void matrixSphereSide(float fcx, float fcy, float fcz, float fr2, float* a)
+{
+    const double cx = fcx, cy = fcy, cz = fcz, r2 = fr2;
+    const double cc = cx * cx + cy * cy + cz * cz;
+    const double v[TPT_MX_K] = {cx * cx, cy * cy, cz * cz, 2 * cx * cy, 2 * cx * cz, 2 * cy * cz, 2 * cx, 2 * cy, 2 * cz,
+                                (r2 - cc) + cc / 65536.0 + r2 / 131072.0, 1.0, 0.0};
+    for (int k = 0; k < TPT_MX_K; ++k) a[k] = (float)v[k];
+}
+
+// Sphere side of the matrix-core filter (tpt_trace.h, phase1Matrix): a_k of every sphere, computed in binary64 and
+// rounded once, laid out as the lanes of v_mfma_f32_32x32x2_f32 read their A operand.  Scenes of up to 64 finite spheres.
+inline void buildMatrixTable(const std::vector<SpherePOD>& S, PackedScene& P)
+{
+    P.amat.clear();
+    P.mxR1 = -1;
+    const int n = (int)S.size();
+    if (n < 1 || n > 64) return;
+    for (int i = 0; i < n; ++i) {
+        const float r2 = S[i].radius * S[i].radius;
+        if (!(fabsf(S[i].cx) < 1e15f) || !(fabsf(S[i].cy) < 1e15f) || !(fabsf(S[i].cz) < 1e15f) || !(r2 < 1e30f)) return; // overflow / NaN: VALU filter
+    }
+    int R1 = 0;
+    if (n > 32) R1 = ((n - 32 + 1) / 2 + 3) / 4 * 4; // rows per half of tile 1, multiple of 4: capacity 2 (16 + R1) >= n
+    const float negInf = u2f(0xff800000u);
+    P.amat.assign(2 * 6 * 64, 0.0f);
+    // padding rows: a9 = -inf, everything else 0 -> the chain ends at -inf, sign set, never a candidate
+    for (int mt = 0; mt < 2; ++mt)
+        for (int row = 0; row < 32; ++row) P.amat[(size_t)(mt * 6 + 4) * 64 + 32 + row] = negInf; // k = 9: pair 4, upper half
+    for (int p = 0; p < n; ++p) {
+        int mt, row;
+        matrixSlot(p, R1, mt, row);
+        float a[TPT_MX_K];
+        matrixSphereSide(S[p].cx, S[p].cy, S[p].cz, S[p].radius * S[p].radius, a); // r^2 as the exact test sees it (Test.cpp:329)
+        for (int k = 0; k < TPT_MX_K; ++k) P.amat[(size_t)(mt * 6 + k / 2) * 64 + 32 * (k & 1) + row] = a[k];
+    }
+    P.mxR1 = R1;
+}
 
 // Large scenes: compact groups of <= TPT_GROUP small spheres (median splits) with bounding spheres, big spheres kept apart.
 // Leaves P ungrouped (nGroups = 0) when the scene is small or a bound would be too loose for the filter's slack
@@ -289,6 +330,7 @@ inline void packScene(std::vector<SpherePOD>& S, const std::vector<MaterialPOD>&
     }
     P.nLights = (int)P.emissive.size();
     buildGroups(S, P);
+    buildMatrixTable(S, P);
 }
 
 inline SceneView viewOf(const PackedScene& P)
@@ -310,6 +352,8 @@ inline SceneView viewOf(const PackedScene& P)
     sv.nGroups = P.nGroups;
     sv.nGroupPairs = P.nGroupPairs;
     sv.nBig = P.nBig;
+    sv.amat = P.amat.empty() ? nullptr : P.amat.data();
+    sv.mxR1 = P.mxR1;
     return sv;
 }
 

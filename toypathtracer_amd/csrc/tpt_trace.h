@@ -40,7 +40,7 @@ struct alignas(16) f4 {
 enum { MAT_LAMBERT = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2 }; // Test.cpp:38
 enum { SEED_ROW_SERIAL = 0, SEED_PER_PIXEL = 1 };            // Test.cpp:280 / ComputeShader.hlsl:380
 enum { FOLD_RECURSIVE = 0, FOLD_FORWARD = 1 };               // Test.cpp:216 nesting / front-to-back
-enum { HS_TWO_PHASE = 0, HS_SIMPLE = 1, HS_TWO_PHASE_GROUPS = 2 }; // _GROUPS: two-phase that also understands grouped scenes
+enum { HS_TWO_PHASE = 0, HS_SIMPLE = 1, HS_TWO_PHASE_GROUPS = 2, HS_MATRIX = 3 }; // _GROUPS: two-phase that also understands grouped scenes; _MATRIX: phase 1 on the matrix cores
 
 // Camera: byte-for-byte the reference layout (Maths.h:444-449, 88 B) so GetSceneDesc can memcpy it.
 struct CameraPOD {
@@ -72,6 +72,11 @@ struct SceneView {
     const f4* bsph;
     const int* bid;
     int nGroups, nGroupPairs, nBig;
+    // Matrix-core form of the phase-1 filter (scenes of <= 64 spheres; see phase1Matrix): amat = [2][6][64] f32, the A
+    // operands of the 2 x 6 v_mfma_f32_32x32x2_f32 a ray tile needs; mxR1 = rows per half of the second sphere tile that
+    // hold spheres (0, 4, ..., 16); mxR1 < 0: no table.
+    const float* amat;
+    int mxR1;
 };
 #ifndef TPT_GROUP
 #define TPT_GROUP 16 /* members per group, <= 32 */
@@ -181,6 +186,10 @@ TPT_HD PairPtr pairPtr(const float* p)
 // TPT_P1_K = 1 + 2^-18 once per ray (K^2 >= 1 + 2^-17; its own rounding, 1 u on nb, is covered by the slack).
 // (Coordinates are assumed to stay below ~1e18 so S does not overflow; padding records carry +inf -> never pass.)
 #define TPT_P1_K 1.000003814697265625f /* 1 + 2^-18 */
+TPT_HD float fma1(float a, float b, float c)
+{
+    return __builtin_fmaf(a, b, c);
+}
 TPT_HD v2f fma2(v2f a, v2f b, v2f c)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -244,6 +253,149 @@ TPT_HD int hitSpheresTwoPhase(const SceneView& sv, f3 o, f3 d, float tMin, float
     return id;
 }
 
+// ---------------------------------------------------------------- phase 1 on the matrix cores (scenes of <= 64 spheres)
+// The filter's discriminant is bilinear in a sphere vector and a ray vector once it is expanded around the coordinate
+// origin instead of the ray origin:
+//   D = (co.d)^2 - |co|^2 + r^2,  co = c - o
+//     = (c.d)^2 + c.(2 o - 2 (o.d) d) + (r^2 - |c|^2) + ((o.d)^2 - |o|^2)
+//     = sum_k a_k(sphere) b_k(ray),  k = 0..11:
+//        a = { cx^2, cy^2, cz^2, 2 cx cy, 2 cx cz, 2 cy cz,  2 cx, 2 cy, 2 cz,  r^2 - |c|^2 + m_s,  1,  0 }
+//        b = { dx^2, dy^2, dz^2,   dx dy,   dx dz,   dy dz,   ex,   ey,   ez,                  1,  q,  0 },
+//   e = o - (o.d) d,  q = (o.d)^2 - |o|^2 (1 - 2^-16),  m_s = 2^-16 |c|^2 + 2^-17 r^2.
+// That is a [spheres x 12] x [12 x rays] product: six v_mfma_f32_32x32x2_f32 per 32 x 32 tile (f32 in, f32 accumulate,
+// an fmaf chain in k order), on the matrix pipe -- which this VALU-bound kernel otherwise leaves idle -- instead of 10
+// packed VALU instructions per sphere pair.  What is left for the VALU: 17 instructions for b, 6 lane swaps to lay b
+// out as B operands, one v_alignbit per (sphere, ray) for the sign, one swap to bring a ray's two row groups together.
+// Still a CONSERVATIVE filter (phase 2 re-tests everything that passes with the reference's arithmetic): the expansion
+// cancels at the scale (|c| + |o|)^2 instead of |c - o|^2, so the slack is m = 2^-16 (|c|^2 + |o|^2) + 2^-17 r^2
+// >= 2^-17 ((|c| + |o|)^2 + r^2) = 128 u (...).  Needed: the reference's own rounding, 13 u (|co|^2 + r^2) (phase1Pair),
+// plus this evaluation's: <= 3 u per term for the rounded a_k, b_k and 12 u for the chain, on
+// T = sum |a_k b_k| <= 2 (|c| + |o|)^2 + r^2, plus 4 u |c||o| + 4 u |o|^2 for e and q, i.e. < 38 u ((|c| + |o|)^2 + r^2):
+// 51 u in all, 2.5 x below the slack (same safety factor as phase1Pair; tests/adversarial_filter.cpp searches for misses).
+// For a 0.5-radius sphere ten units from the origin that inflates r^2 by 0.3 %.
+#define TPT_MX_K 12
+TPT_HD void matrixRaySide(f3 o, f3 d, float* b)
+{
+    b[0] = d.x * d.x; b[1] = d.y * d.y; b[2] = d.z * d.z;
+    b[3] = d.x * d.y; b[4] = d.x * d.z; b[5] = d.y * d.z;
+    const float od = fma1(o.z, d.z, fma1(o.y, d.y, o.x * d.x));
+    b[6] = fma1(-od, d.x, o.x); b[7] = fma1(-od, d.y, o.y); b[8] = fma1(-od, d.z, o.z);
+    const float oo = fma1(o.z, o.z, fma1(o.y, o.y, o.x * o.x));
+    b[9] = 1.0f;
+    b[10] = fma1(od, od, -(oo * 0.9999847412109375f)); // 1 - 2^-16
+    b[11] = 0.0f;
+}
+// position of sphere p in the table: tile mt, row i of v_mfma_f32_32x32x2_f32's A operand.  The accumulator register r
+// of lane l holds row 8 (r / 4) + 4 (l / 32) + r % 4 of column l % 32: a lane's 16 + R1 sign bits, taken in register
+// order through tile 0 then tile 1, belong to spheres g n + 0 .. g n + n - 1 (g = l / 32, n = 16 + R1) -- so that the
+// assembled 64-bit mask lists the spheres in ascending index (phase 2's tie-break depends on that order).
+TPT_HD void matrixSlot(int p, int R1, int& mt, int& row)
+{
+    const int n = 16 + R1, g = p / n, q = p % n;
+    mt = q < 16 ? 0 : 1;
+    const int r = q < 16 ? q : q - 16;
+    row = 8 * (r / 4) + 4 * g + r % 4;
+}
+// Host restatement of phase1Matrix for the CPU tests: same table, same b, the fmaf chain the MFMA runs.
+TPT_HD uint64_t phase1MatrixRef(const float* amat, int R1, int nSpheres, f3 o, f3 d)
+{
+    float b[TPT_MX_K];
+    matrixRaySide(o, d, b);
+    uint64_t cand = 0;
+    for (int p = 0; p < nSpheres; ++p) {
+        int mt, row;
+        matrixSlot(p, R1, mt, row);
+        float c = 0.0f;
+        for (int k = 0; k < TPT_MX_K; ++k) c = fma1(amat[(mt * 6 + k / 2) * 64 + 32 * (k & 1) + row], b[k], c);
+        if ((f2u(c) >> 31) == 0u) cand |= 0x8000000000000000ull >> p;
+    }
+    return cand;
+}
+#if defined(__HIPCC__) && !defined(__HIP_DEVICE_COMPILE__)
+__device__ uint64_t phase1Matrix(const float* ldsA, int R1, f3 o, f3 d); // (host pass of a .hip file: declaration only)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef float v16f __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void swapHalves(float& x, float& y) // x <- {x.lo, y.lo}, y <- {x.hi, y.hi} (32-lane halves)
+{
+    auto r = __builtin_amdgcn_permlane32_swap(f2u(x), f2u(y), false, false);
+    x = u2f(r[0]);
+    y = u2f(r[1]);
+}
+// Candidate mask (sphere p at bit 63 - p) of the ray in this lane.  Must be called by ALL 64 lanes of the wave (lanes
+// without a ray pass anything finite and ignore the result).  ldsA: the scene's A-operand table in LDS.
+__device__ __forceinline__ uint64_t phase1Matrix(const float* ldsA, int R1, f3 o, f3 d)
+{
+    float b[TPT_MX_K];
+    matrixRaySide(o, d, b);
+    // B operand of k-pair kk for the ray tile nt: lane l holds b[2 kk + l / 32] of ray 32 nt + l % 32
+    float B0[6], B1[6];
+#pragma unroll
+    for (int kk = 0; kk < 6; ++kk) {
+        B0[kk] = b[2 * kk];
+        B1[kk] = b[2 * kk + 1];
+        swapHalves(B0[kk], B1[kk]);
+    }
+    const int lane = (int)(threadIdx.x & 63u);
+    uint32_t W0 = 0, W1 = 0; // sign bits of this lane's accumulator rows, ray tile 0 / 1
+    {
+        v16f c0 = {0}, c1 = {0};
+#pragma unroll
+        for (int kk = 0; kk < 6; ++kk) {
+            const float a = ldsA[kk * 64 + lane];
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, B0[kk], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, B1[kk], c1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            W0 = alignbit(W0, f2u(c0[r]), 31);
+            W1 = alignbit(W1, f2u(c1[r]), 31);
+        }
+    }
+    if (R1 > 0) {
+        v16f c0 = {0}, c1 = {0};
+#pragma unroll
+        for (int kk = 0; kk < 6; ++kk) {
+            const float a = ldsA[(6 + kk) * 64 + lane];
+            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, B0[kk], c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, B1[kk], c1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            if (R1 > 4 * r4) {
+#pragma unroll
+                for (int r = 4 * r4; r < 4 * r4 + 4; ++r) {
+                    W0 = alignbit(W0, f2u(c0[r]), 31);
+                    W1 = alignbit(W1, f2u(c1[r]), 31);
+                }
+            }
+        }
+    }
+    // rays 0..31 sit in ray tile 0, whose rows are split between lane j (row group 0) and lane j + 32 (row group 1);
+    // rays 32..63 likewise in tile 1: one swap gives every lane both row groups of its own ray
+    auto sw = __builtin_amdgcn_permlane32_swap(W0, W1, false, false);
+    const uint32_t G0 = sw[0], G1 = sw[1];
+    const int n = 16 + R1; // spheres per row group
+    const uint64_t rejected = ((uint64_t)G0 << (64 - n)) | ((uint64_t)G1 << (64 - 2 * n));
+    const uint64_t valid = n == 32 ? ~0ull : ~(~0ull >> (2 * n));
+    return ~rejected & valid;
+}
+#endif
+// phase 2 over a candidate mask (sphere p at bit 63 - p): the reference's arithmetic, ascending index
+TPT_HD int hitSpheresCandidates(const SceneView& sv, uint64_t cand, f3 o, f3 d, float tMin, float tMax, float& outT)
+{
+    float hitT = tMax;
+    int id = -1;
+    while (cand) {
+        const int i = __builtin_clzll(cand);
+        cand &= ~(0x8000000000000000ull >> i);
+        TPT_STAT(ST_PHASE2);
+        testSphere(sv.sph4[i], i, o, d, tMin, hitT, id);
+    }
+    outT = hitT;
+    return id;
+}
+
 // ---------------------------------------------------------------- grouped HitWorld (large scenes)
 // Same result as the flat loops, sphere for sphere: every sphere the reference's test accepts is still tested with
 // the reference's arithmetic (testSphere's), only the ORDER differs -- so the winner among equal t is chosen
@@ -265,10 +417,6 @@ TPT_HD void testSphereTie(f4 s, int i, f3 o, f3 d, float tMin, float& hitT, int&
             hitT = t;
         }
     }
-}
-TPT_HD float fma1(float a, float b, float c)
-{
-    return __builtin_fmaf(a, b, c);
 }
 // per-lane version of phase1Pair's conservative filter for one sphere (dk = direction scaled by TPT_P1_K)
 TPT_HD bool memberFilter(f4 s, f3 o, f3 dk)
@@ -381,6 +529,10 @@ template <int HS>
 TPT_HD int hitSpheres(const SceneView& sv, f3 o, f3 d, float tMin, float tMax, float& outT)
 {
     if (HS == HS_SIMPLE) return hitSpheresSimple(sv, o, d, tMin, tMax, outT);
+#if !defined(__HIP_DEVICE_COMPILE__)
+    // host tests: the matrix filter's restatement (on the device the kernels call phase1Matrix wave-wide themselves)
+    if (HS == HS_MATRIX && sv.mxR1 >= 0) return hitSpheresCandidates(sv, phase1MatrixRef(sv.amat, sv.mxR1, sv.nSpheres, o, d), o, d, tMin, tMax, outT);
+#endif
     // (kernels that stage the scene in LDS are instantiated without the grouped code: such scenes are small and never
     //  grouped, and the extra registers cost the 46-sphere kernel 4 %)
     if (HS == HS_TWO_PHASE_GROUPS && sv.nGroups > 0) return hitSpheresGrouped(sv, o, d, tMin, tMax, outT);

@@ -50,29 +50,57 @@ FLAG_PROGRESSIVE = 2
 FLAG_ANIMATE = 1
 
 
-def cpu_baseline(width, height, spp, budget_s=10.0):
-    """Times the checker/reference on the host cores (reported baseline, never the product path)."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def time_reference_build(variant, width, height, spp, budget_s):
+    """One build of the pristine reference (oracle/_ref), all host threads via its own enkiTS scheduler."""
+    from oracle_lib import Ref
+    ref = Ref.get(variant)
+    ref.set_spp(spp)
+    bb = np.zeros((height, width, 4), np.float32)
+    for f in range(2):  # 2 warm-up frames discarded (BASELINE.md section 3)
+        ref.update(0.0, f, width, height, FLAG_PROGRESSIVE)
+        ref.draw(0.0, f, width, height, bb, FLAG_PROGRESSIVE)
+    rays, frames, t0 = 0, 0, time.perf_counter()
+    while True:
+        ref.update(0.0, frames + 2, width, height, FLAG_PROGRESSIVE)
+        rays += ref.draw(0.0, frames + 2, width, height, bb, FLAG_PROGRESSIVE)
+        frames += 1
+        if (time.perf_counter() - t0 > budget_s and frames >= 10) or frames >= 200:
+            break
+    dt = time.perf_counter() - t0
+    return rays / dt / 1e6, frames, dt
+
+
+def cpu_baseline(width, height, spp, budget_s=5.0):
+    """Times the checker/reference on the host cores (reported baseline, never the product path): the three builds
+    BASELINE.md section 3 / SURVEY 8(d) ask for, CPU model and thread count stated."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from oracle_lib import Oracle, Ref
     cores = os.cpu_count() or 1
+    model = cpu_model()
+    builds = {"simd": "SIMD path as in the repo, -O2 -msse4.1 -ffp-contract=off (image bit-identical to the scalar path)",
+              "fast": "SIMD path as shipped, -O3 -ffast-math -mavx2 -mfma (different bits)",
+              "scalar": "scalar path (-D__EMSCRIPTEN__, Config.h:9-13), -O2 -ffp-contract=off: the parity target"}
     if Ref.available("simd"):
-        ref = Ref.get("simd")
-        ref.set_spp(spp)
-        bb = np.zeros((height, width, 4), np.float32)
-        rays, frames, t0 = 0, 0, time.perf_counter()
-        ref.update(0.0, 0, width, height, FLAG_PROGRESSIVE)
-        ref.draw(0.0, 0, width, height, bb, FLAG_PROGRESSIVE)  # warm-up frame (threads start)
-        t0 = time.perf_counter()
-        while True:
-            ref.update(0.0, frames + 1, width, height, FLAG_PROGRESSIVE)
-            rays += ref.draw(0.0, frames + 1, width, height, bb, FLAG_PROGRESSIVE)
-            frames += 1
-            if time.perf_counter() - t0 > budget_s or frames >= 200:
-                break
-        dt = time.perf_counter() - t0
-        return dict(value=rays / dt / 1e6, unit="Mray/s", cores=cores, kind="reference",
-                    sample="%d frames of %dx%dx%dspp, pristine reference SIMD path + enkiTS (oracle/_ref/libtpt_ref.so, "
-                           "-O2 -msse4.1 -ffp-contract=off), %.1f s" % (frames, width, height, spp, dt))
+        res = {}
+        for v in ("simd", "fast", "scalar"):
+            if Ref.available(v):
+                mr, frames, dt = time_reference_build(v, width, height, spp, budget_s)
+                res[v] = dict(value=mr, frames=frames, seconds=dt, build=builds[v])
+        return dict(value=res["simd"]["value"], unit="Mray/s", cores=cores, cpu_model=model, kind="reference",
+                    sample="%d frames of %dx%dx%dspp after 2 warm-up frames, pristine reference (oracle/_ref/libtpt_ref.so: %s) "
+                           "+ enkiTS on %d hardware threads, %.1f s" % (res["simd"]["frames"], width, height, spp, builds["simd"], cores,
+                                                                        res["simd"]["seconds"]),
+                    builds={k: dict(value=v["value"], frames=v["frames"], build=v["build"]) for k, v in res.items()})
     o = Oracle.get()
     s, m = o.default_scene()
     cam = o.default_camera(width, height)
@@ -83,8 +111,37 @@ def cpu_baseline(width, height, spp, budget_s=10.0):
         rays += r
         frames += 1
     dt = time.perf_counter() - t0
-    return dict(value=rays / dt / 1e6, unit="Mray/s", cores=cores, kind="port",
+    return dict(value=rays / dt / 1e6, unit="Mray/s", cores=cores, cpu_model=model, kind="port",
                 sample="%d frames of %dx%dx%dspp, oracle/tpt_oracle.c (OpenMP over rows), %.1f s" % (frames, width, height, spp, dt))
+
+
+def drawtest_host_path(api, width, height, frames=24):
+    """The reference's own contract: synchronous DrawTest on a HOST backbuffer (upload + trace + blend + download)."""
+    bb = np.zeros((height, width, 4), np.float32)
+    for f in range(4):
+        api.UpdateTest(0.0, f, width, height, FLAG_PROGRESSIVE)
+        api.DrawTest(0.0, f, width, height, bb, FLAG_PROGRESSIVE)
+    rays, t0 = 0, time.perf_counter()
+    for f in range(4, 4 + frames):
+        api.UpdateTest(0.0, f, width, height, FLAG_PROGRESSIVE)
+        rays += api.DrawTest(0.0, f, width, height, bb, FLAG_PROGRESSIVE)
+    dt = time.perf_counter() - t0
+    return dt / frames * 1e3, rays / dt / 1e6
+
+
+def row_serial_rate(api, width, height, frames=3):
+    """ROW_SERIAL seeds: the reference's exact image (one RNG stream per row: one lane per row)."""
+    api.set_seed_mode(0)
+    bb = np.zeros((height, width, 4), np.float32)
+    api.UpdateTest(0.0, 0, width, height, FLAG_PROGRESSIVE)
+    api.DrawTest(0.0, 0, width, height, bb, FLAG_PROGRESSIVE)
+    rays, t0 = 0, time.perf_counter()
+    for f in range(1, 1 + frames):
+        api.UpdateTest(0.0, f, width, height, FLAG_PROGRESSIVE)
+        rays += api.DrawTest(0.0, f, width, height, bb, FLAG_PROGRESSIVE)
+    dt = time.perf_counter() - t0
+    api.set_seed_mode(1)
+    return dt / frames * 1e3, rays / dt / 1e6
 
 
 def main():
@@ -95,7 +152,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--stripe-rows", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--hit-spheres", type=int, default=0, help="0 two-phase, grouped traversal for >= 256 spheres (default); 1 simple loop; 2 two-phase brute force")
+    ap.add_argument("--no-extras", action="store_true", help="skip the host-pointer DrawTest and ROW_SERIAL legs after the timed region")
+    ap.add_argument("--hit-spheres", type=int, default=0, help="0 two-phase, grouped traversal for >= 256 spheres (default); 1 simple loop; 2 two-phase brute force; 3 as 0 without the matrix-core filter table (only matters for -DTPT_MATRIX_FILTER=1 builds)")
     ap.add_argument("--persistent", type=int, default=3, help="3 path queues (default) 1 persistent waves with lane refill 0 thread-per-pixel 2 lane-sorting")
     ap.add_argument("--fold", type=int, default=0, help="0 recursive (reference order, default) 1 forward")
     ap.add_argument("--lds-scene", type=int, default=-1)
@@ -228,7 +286,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "width": width, "height": height, "spp": spp, "spheres": n_spheres,
                        "seed_mode": "per_pixel", "fold": "forward" if args.fold else "recursive",
-                       "hit_spheres": ["two_phase" + ("+groups" if n_spheres >= 256 else ""), "simple", "two_phase_brute_force"][args.hit_spheres], "kernel": ["thread_per_pixel", "persistent_waves", "lane_sorting", "path_queues"][args.persistent], "frame_overlap": args.overlap,
+                       "hit_spheres": ["two_phase" + ("+groups" if n_spheres >= 256 else ""), "simple", "two_phase_brute_force", "two_phase"][args.hit_spheres], "kernel": ["thread_per_pixel", "persistent_waves", "lane_sorting", "path_queues"][args.persistent], "frame_overlap": args.overlap,
                        "untimed_priming_frames": args.prime,
                        "flags": "progressive|animate" if args.animate else "progressive",
                        "sharding": "none" if world == 1 else "row stripes of %d, round-robin over %d ranks, pipelined gather to rank 0" % (args.stripe_rows, world),
@@ -238,34 +296,47 @@ def main():
             "trace_launch_ms_avg": k_ms,
             "pipeline_ms_per_step": p_ms,
             "pipeline_Mray_s": rays_per_launch * world / (p_ms * 1e-3) / 1e6,
-            "roofline": {"bound": "hbm", "achieved": hbm_write_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": hbm_write_gbs / PEAK_HBM_GBS, "traffic": traffic,
-                         "traffic_note": ("bytes per trace launch on the L2's fabric side (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes, "
-                                          "profiles/pmc_traffic.json; Infinity-Cache hits included).  Beyond the 16 B/pixel image write it is the "
-                                          "per-path bounce stack and colour sums of the bit-exact recursive fold (16-B records, paths migrate between "
-                                          "waves so they cannot live in a wave's LDS slice), not re-reads of the image; 13 % of HBM peak at this rate"
-                                          if args.persistent == 3 else "see profiles/pmc_traffic.json"),
-                         "achieved_read_plus_write": 2 * hbm_write_gbs,
-                         "achieved_per_pipeline_slot": hbm_write_gbs * k_ms / p_ms, "launch_ms_avg": k_ms, "launches": launches,
-                         "note": "north_star's HBM-write roofline (W*H*16 B per frame / average launch duration); up to %d launches share "
-                                 "the GPU at once, so the per-launch figure understates the chip by that factor: *_per_pipeline_slot divides by "
-                                 "the time a frame occupies the pipeline instead.  The kernel is FP32-VALU bound (arithmetic intensity ~440 "
-                                 "flop/B), see roofline_valu" % args.overlap,
+            # roofline.frac is the chip-level figure: the frame's algorithmic bytes over the time a frame occupies the
+            # pipeline (ms_per_step measured by HIP events on the render stream) -- up to `frame_overlap` launches share
+            # the GPU, so bytes / one launch's own duration (frac_per_launch) understates the chip by that factor
+            "roofline": {"bound": "hbm", "achieved": hbm_write_gbs * k_ms / p_ms, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": hbm_write_gbs * k_ms / p_ms / PEAK_HBM_GBS, "traffic": (traffic or {}).get("bytes_per_launch") if isinstance(traffic, dict) else traffic,
+                         "traffic_static": True,
+                         "traffic_note": ("NOT measured in this run: bytes per trace launch on the L2's fabric side (WRITE_SIZE + 2 x FETCH_SIZE, "
+                                          "separate rocprofv3 --pmc passes of this same command, profiles/pmc_traffic.json names the run)"),
+                         "achieved_per_launch": hbm_write_gbs, "frac_per_launch": hbm_write_gbs / PEAK_HBM_GBS,
+                         "achieved_read_plus_write": 2 * hbm_write_gbs * k_ms / p_ms, "launch_ms_avg": k_ms, "launches": launches,
+                         "note": "north_star's HBM-write roofline (W*H*16 B per frame).  The kernel is FP32-VALU bound (arithmetic "
+                                 "intensity ~440 flop/B against a machine balance of ~20): see roofline_valu, the binding one",
                          "kernel": ["tptTraceKernel", "tptTraceKernel", "tptTraceSortedKernel", "tptTraceQueueKernel"][args.persistent]},
-            "roofline_valu": {"bound": "valu_fp32", "achieved": valu_tflops, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                              "frac": valu_tflops / PEAK_FP32_TFLOPS,
-                              "achieved_per_pipeline_slot": valu_tflops * k_ms / p_ms,
-                              "frac_per_pipeline_slot": valu_tflops * k_ms / p_ms / PEAK_FP32_TFLOPS,
-                              "note": "algorithmic flops = rays x 17 flop x spheres (SURVEY 8d: the reference's own per-test count); peak counts "
-                                      "FMA as 2 flop.  The exact arithmetic (phase 2 of HitSpheres, Scatter) may not contract to FMA (parity); "
-                                      "phase 1 is a conservative filter and does use FMA (10 packed ops per sphere pair instead of 16)"
+            "roofline_valu": {"bound": "valu_fp32", "achieved": valu_tflops * k_ms / p_ms, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                              "frac": valu_tflops * k_ms / p_ms / PEAK_FP32_TFLOPS,
+                              "achieved_per_launch": valu_tflops, "frac_per_launch": valu_tflops / PEAK_FP32_TFLOPS,
+                              "note": "algorithmic flops = rays x 17 flop x spheres (SURVEY 8d: the reference's own per-test count) over the "
+                                      "pipeline time per frame; peak counts FMA as 2 flop.  The exact arithmetic (phase 2 of HitSpheres, Scatter) "
+                                      "may not contract to FMA (parity); phase 1 is a conservative filter"
                                       + ("; this scene is traversed through sphere groups, so the figure is the brute-force-EQUIVALENT rate "
                                          "(most of those tests are never executed)" if (n_spheres >= 256 and args.hit_spheres == 0) else "")},
         }
+        if world == 1 and not args.no_extras:
+            # the same workload through the reference's own contract (host backbuffer, synchronous) and in its own seed mode
+            api.set_ray_counter(None)
+            api.set_stream(None)
+            api.set_tile_mirror(None)
+            api.set_row_shard(0, 1, 0)
+            ms, mr = drawtest_host_path(api, width, height)
+            out["drawtest_host_ms"], out["drawtest_host_Mray_s"] = ms, mr
+            out["drawtest_host_note"] = ("synchronous DrawTest(host float* backbuffer) per frame: backbuffer upload + trace + blend + download "
+                                         "over PCIe, one frame in flight -- the reference's own calling contract; never the headline value")
+            if scene == "default" and width * height <= 1280 * 720:
+                ms, mr = row_serial_rate(api, width, height)
+                out["row_serial_ms"], out["row_serial_Mray_s"] = ms, mr
+                out["row_serial_note"] = "seed mode 0: the reference's per-row RNG streams (bit-identical CPU image), one lane per image row"
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(width, height, spp)
         print(json.dumps(out), flush=True)
 
+    api.set_tile_mirror(None)
     api.set_ray_counter(None)
     api.set_stream(None)
     api.ShutdownTest()

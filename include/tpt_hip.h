@@ -96,7 +96,9 @@ int tptDrawDevice(float time, int frameCount, int screenWidth, int screenHeight,
  * paths) overlaps the following frames, and each launch takes only its share of the machine (2/frames-in-flight of
  * the resident workgroups; a caller that synchronises every frame gets whole-machine launches).
  * Needs one hardware queue per in-flight kernel: tptInitialize sets GPU_MAX_HW_QUEUES=32 if the HIP runtime has
- * not been initialised yet (ROCm's default of 4 makes 3 streams slower than 2). */
+ * not been initialised yet (ROCm's default of 4 makes 3 streams slower than 2), then MEASURES how many streams really
+ * run side by side and clamps the pipeline to that (tptGetPipelineInfo).  Twice as many frames may be ENQUEUED ahead
+ * (frames f and f + frames share a stream). */
 int tptSetFrameOverlap(int frames);
 /* Display conversion of a device-resident FULL image (w*h float4, row 0 = bottom) into w*h RGBA8 in device memory,
  * top row first: the reference's own conversion for its C++ path, Cpp/Emscripten/main.cpp:63-79
@@ -143,8 +145,18 @@ int tptTestMath(int op, const float* a, const float* b, float* out, int n);
 /* intersect n host rays ([n][6] = origin, UNIT direction -- the reference asserts it, Maths.h:337; the two-phase
  * filter's error bound assumes it) with the current scene on the GPU */
 int tptTestHitSpheres(int hitSpheres, const float* rays, int* outId, float* outT, int n);
+/* phase 1 of HitSpheres evaluated on the matrix cores (v_mfma_f32_32x32x2_f32 over a 12-term expansion of the filter's
+ * discriminant; scenes of <= 64 spheres): candidate masks, sphere p at bit 63 - p, of n host rays.  A measured-and-rejected
+ * variant kept as a unit-tested building block; the shipped kernels run the packed-VALU filter. */
+int tptTestMatrixFilter(const float* rays, unsigned long long* outMask, int n);
 /* kernel resource facts for DESIGN/bench: occupancy (blocks/CU), LDS bytes/block, grid size of the last launch */
 int tptGetLaunchInfo(int* outBlocksPerCU, int* outLdsBytes, int* outGridBlocks, int* outNumCUs);
+/* Facts about the frame pipeline: hardware queues the runtime really runs side by side for this process (measured at
+ * tptInitialize with one spinning wave per trace stream: GPU_MAX_HW_QUEUES only counts if it was set before the HIP
+ * runtime started), the frames-in-flight limit that results (tptSetFrameOverlap's value clamped to what those queues can
+ * carry), the deepest pipeline the caller has built so far (decides the grid of a launch), and how often the per-slot
+ * buffers were (re-)allocated (once per frame shape; never on the steady-state path). */
+int tptGetPipelineInfo(int* outHwQueues, int* outOverlapEffective, int* outStreamDepth, int* outSlotReservations);
 /* profiling builds only (-DTPT_STATS): 128 counters, wave-level entries [i] / lane counts [32+i] of the
  * state machine's blocks (enum ST_* in tpt_trace.h); the shipped build returns an error. */
 int tptDebugStats(unsigned long long* out128, int reset);

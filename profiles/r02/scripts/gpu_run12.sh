@@ -1,0 +1,18 @@
+#!/bin/bash
+# r02 run 12: frame table with relaxed loads (no system-scope acquire = no L2 invalidation per frame transition)
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+cd "$R"
+summ() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%8.1f Mray/s  %.4f ms/step  launch %.3f ms pipe %.4f grid %d  host %s' % (d['value'], d['ms_per_step'], d['trace_launch_ms_avg'], d['pipeline_ms_per_step'], d['config']['grid_blocks'], d.get('drawtest_host_ms')))"; }
+echo "== bench"
+for h in 3 0 1 8; do
+for args in "--steps 20 --warmup 5" "--steps 200 --warmup 20"; do echo "-- TPT_HELP=$h $args"; TPT_HELP=$h timeout 300 python bench.py --no-cpu-baseline --no-extras $args 2>&1 | tail -1 | summ; done; done
+echo "-- natural chunk order"; for h in 3 0; do TPT_CLAIM_STRIDE=1 TPT_HELP=$h timeout 300 python bench.py --no-cpu-baseline --no-extras --steps 200 --warmup 20 2>&1 | tail -1 | summ; done
+echo "-- group1 variant"; for h in 3 0; do TPT_LIB=$R/tools/_variants/group1/libtoypathtracer_hip.so TPT_HELP=$h timeout 300 python bench.py --no-cpu-baseline --no-extras --steps 200 --warmup 20 2>&1 | tail -1 | summ; done
+echo "-- group1 + natural"; for h in 3 0; do TPT_CLAIM_STRIDE=1 TPT_LIB=$R/tools/_variants/group1/libtoypathtracer_hip.so TPT_HELP=$h timeout 300 python bench.py --no-cpu-baseline --no-extras --steps 200 --warmup 20 2>&1 | tail -1 | summ; done
+for h in 3; do
+cd /tmp && TPT_HELP=$h timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$R/gpurun_out/burst4_h$h" -o t -- python "$R/tools/burst_trace.py" 20 > /dev/null 2>&1
+cd "$R"; echo "== TPT_HELP=$h"; python tools/burst_trace.py --analyse gpurun_out/burst4_h$h | head -50
+done
+echo "== quick parity"
+timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "per_pixel_bit_exact or config2_1280 or overlap or seventy or animated" 2>&1 | tail -3

@@ -24,7 +24,9 @@ CASES = [
     (640, 360, 4, 1, FLAG_PROGRESSIVE, 0.0),   # BASELINE.md golden a299de4a
     (640, 360, 1, 1, FLAG_PROGRESSIVE, 0.0),   # BASELINE.json config 1, golden 641c3e8f
     (1280, 720, 4, 1, FLAG_PROGRESSIVE, 0.0),  # rays 16 809 105
+    (1280, 720, 4, 2, FLAG_PROGRESSIVE, 0.0),  # BASELINE.md golden 609aacda, rays 33 632 052
     (1280, 720, 4, 3, FLAG_PROGRESSIVE, 0.0),  # golden 16cce49a
+    (1280, 720, 4, 10, FLAG_PROGRESSIVE, 0.0), # BASELINE.md golden 46afd557, rays 168 141 976
     (320, 180, 8, 2, FLAG_PROGRESSIVE, 0.0),
     (200, 100, 16, 2, FLAG_PROGRESSIVE, 0.0),
     (203, 117, 4, 2, FLAG_PROGRESSIVE, 0.0),   # sizes not divisible by 8

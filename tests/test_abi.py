@@ -72,3 +72,22 @@ def test_product_never_references_oracle():
                             if re.search(r"#include|import |CDLL|dlopen|-l", line) and re.search(r"oracle|libtpt_ref", line):
                                 bad.append((f, line))
     assert not bad, bad
+
+
+def test_host_written_against_the_reference_header_links(tmp_path):
+    """Link-level drop-in, from the other side: examples/headless_host.cpp compiled against the REFERENCE's own Test.h
+    (-DUSE_REFERENCE_HEADER -I /root/reference/Cpp/Source, nothing of this repo's include/ on the path) links against
+    libtoypathtracer_hip.so with no unresolved symbol.  Compile + link only (no GPU here); /root/reference exists in the
+    build container only."""
+    from toypathtracer_amd import api
+    ref_src = "/root/reference/Cpp/Source"
+    if not os.path.exists(os.path.join(ref_src, "Test.h")):
+        pytest.skip("/root/reference not present")
+    exe = str(tmp_path / "host_ref_header")
+    lib_dir = os.path.dirname(api.library_path())
+    subprocess.check_call(["g++", "-O1", "-std=c++11", "-DUSE_REFERENCE_HEADER", "-I", ref_src,
+                           os.path.join(ROOT, "examples", "headless_host.cpp"), "-L", lib_dir, "-ltoypathtracer_hip",
+                           "-Wl,-rpath," + lib_dir, "-Wl,--no-undefined", "-o", exe])
+    out = subprocess.check_output(["nm", "-u", exe]).decode()
+    for sym in api.CXX_ABI_SYMBOLS[:4]:  # InitializeTest, ShutdownTest, UpdateTest, DrawTest are what the host calls
+        assert sym in out, sym

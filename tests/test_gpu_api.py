@@ -67,3 +67,69 @@ def test_display_conversion_matches_reference_formula(tpt_defaults, tmp_path):
     tpt.write_tga(path, got)
     assert os.path.getsize(path) == 18 + w * h * 4
 
+
+
+_LATE_HOST = r'''
+import json, os, sys, time
+os.environ.pop("GPU_MAX_HW_QUEUES", None)
+import torch
+torch.zeros(1, device="cuda").sum().item()          # the host initialises HIP FIRST: the runtime starts with its default queues
+cap = sys.argv[1]
+if cap != "auto":
+    os.environ["TPT_OVERLAP_CAP"] = cap
+sys.path.insert(0, sys.argv[2])
+from toypathtracer_amd import api                    # (sets GPU_MAX_HW_QUEUES=32 -- too late for this process)
+api.InitializeTest()
+w, h = 1280, 720
+tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+def burst(f0, n):
+    r0 = api.ray_counter_read()
+    t0 = time.perf_counter()
+    for f in range(f0, f0 + n):
+        api.UpdateTest(0.0, f, w, h, 2); api.draw_device(0.0, f, w, h, tile.data_ptr(), 2)
+    rays = api.ray_counter_read() - r0
+    return rays / (time.perf_counter() - t0) / 1e6
+burst(0, 30)
+rate = max(burst(30, 60), burst(90, 60))
+print(json.dumps(dict(rate=rate, **api.pipeline_info())))
+api.ShutdownTest()
+'''
+
+
+def test_host_that_initialised_hip_first_still_gets_a_working_pipeline(tmp_path):
+    """GPU_MAX_HW_QUEUES is read when the HIP runtime starts; a host (or torch) that touched HIP before this library was
+    loaded keeps the default of 4 hardware queues, on which 16 frames in flight run slower than 2.  tptInitialize measures
+    how many streams really run side by side and clamps the frame pipeline: the automatic choice must be within 10 % of
+    the best forced limit."""
+    import json
+    import sys
+    script = tmp_path / "late_host.py"
+    script.write_text(_LATE_HOST)
+    res = {}
+    for cap in ("auto", "1", "2", "3", "4", "8", "16"):
+        out = subprocess.check_output([sys.executable, str(script), cap, ROOT], stderr=subprocess.DEVNULL, timeout=300).decode()
+        res[cap] = json.loads(out.strip().splitlines()[-1])
+    auto = res["auto"]
+    assert auto["hw_queues"] <= 8, auto           # the probe saw the small queue pool ...
+    assert auto["overlap_effective"] <= 5, auto   # ... and clamped the pipeline
+    best = max(v["rate"] for v in res.values())
+    assert auto["rate"] >= 0.9 * best, res
+
+
+def test_pipeline_info_with_queues_set_early(tpt_defaults):
+    """In the test process GPU_MAX_HW_QUEUES=32 was exported before HIP started (api.load_library): all trace streams run
+    side by side, the full pipeline is used, and the per-slot buffers are allocated once per frame shape."""
+    import torch
+    tpt = tpt_defaults
+    info = tpt.pipeline_info()
+    assert info["hw_queues"] == 16 and info["overlap_effective"] == 16, info
+    w, h = 320, 200
+    tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    tpt.UpdateTest(0.0, 0, w, h, FLAG_PROGRESSIVE)
+    tpt.draw_device(0.0, 0, w, h, tile.data_ptr(), FLAG_PROGRESSIVE)
+    r0 = tpt.pipeline_info()["slot_reservations"]
+    for f in range(1, 40):
+        tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+        tpt.draw_device(0.0, f, w, h, tile.data_ptr(), FLAG_PROGRESSIVE)
+    tpt.synchronize()
+    assert tpt.pipeline_info()["slot_reservations"] == r0  # nothing allocated on the steady-state path

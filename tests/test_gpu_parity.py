@@ -206,17 +206,19 @@ def test_config2_1280x720_4spp_full_parity(tpt_defaults, oracle):
     assert per == pero and bb.tobytes() == bo.tobytes()
 
 
-def test_config2_row_serial_golden(tpt_defaults):
-    """1280x720x4spp, 3 accumulated frames, reference seed mode: the BASELINE.md golden 16cce49a."""
+@pytest.mark.parametrize("frames", [2, 3, 10])
+def test_config2_row_serial_golden(tpt_defaults, frames):
+    """1280x720x4spp in the reference's own seed mode: BASELINE.md's goldens 609aacda (F=2), 16cce49a (F=3), 46afd557 (F=10)."""
     tpt = tpt_defaults
     tpt.set_seed_mode(SEED_ROW_SERIAL)
-    case = [c for c in goldens() if (c["width"], c["frames"]) == (1280, 3)][0]
-    rays, bb, _ = gpu_frames(tpt, 1280, 720, 3)
+    case = [c for c in goldens() if (c["width"], c["frames"]) == (1280, frames)][0]
+    rays, bb, _ = gpu_frames(tpt, 1280, 720, frames)
     assert rays == case["rays"] and "%08x" % fnv1a(bb) == case["fnv"]
+    assert case["fnv"] == {2: "609aacda", 3: "16cce49a", 10: "46afd557"}[frames]
 
 
-def test_config3_3840x2160_16spp_properties(tpt_defaults, oracle):
-    """configs[2] at full size through size-independent properties + an oracle check on a band of rows."""
+def test_config3_3840x2160_16spp_full_parity(tpt_defaults, oracle):
+    """configs[2] at full size: every pixel and the ray count against the oracle, plus determinism and variant agreement."""
     tpt = tpt_defaults
     w, h, spp = 3840, 2160, 16
     tpt.set_samples_per_pixel(spp)
@@ -225,11 +227,10 @@ def test_config3_3840x2160_16spp_properties(tpt_defaults, oracle):
     assert r1 == r2 and b1.tobytes() == b2.tobytes()          # deterministic
     assert np.isfinite(b1[..., :3]).all() and float(b1[..., 3].max()) == 0.0
     assert 4.3 * w * h * spp < r1 < 4.8 * w * h * spp          # rays/sample = 4.56 on this scene
-    # rows [1000,1016) against the oracle (seeds are partition independent)
+    # the WHOLE frame against the oracle (605 M rays: seconds on the GPU box's host cores)
     s, m = oracle.default_scene()
-    band = np.zeros((h, w, 4), np.float32)
-    oracle.render(s, m, oracle.default_camera(w, h), w, h, spp, 0, seed_mode=SEED_PER_PIXEL, backbuffer=band, y0=1000, y1=1016)
-    assert b1[1000:1016].tobytes() == band[1000:1016].tobytes()
+    ro, bo = oracle.render(s, m, oracle.default_camera(w, h), w, h, spp, 0, seed_mode=SEED_PER_PIXEL)
+    assert r1 == ro and b1.tobytes() == bo.tobytes()
     # static thread-per-pixel variant gives the same frame
     tpt.set_kernel_variant(0, 0, -1)
     r3, b3, _ = gpu_frames(tpt, w, h, 1)
@@ -341,7 +342,9 @@ def test_sharded_frame_exchange_on_device(tpt_defaults, oracle, world, stripe):
             image, total = img.cpu().numpy(), tot
     tpt.set_row_shard(0, 1, 0)
     ro, bo, _ = oracle_frames(oracle, w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
-    assert total == ro and image.tobytes() == bo.tobytes()
+    assert total == ro
+    bad = np.argwhere((image.view(np.uint32) != bo.view(np.uint32)).any(axis=2))
+    assert len(bad) == 0, "%d pixels differ, first rows %s" % (len(bad), sorted(set(bad[:, 0].tolist()))[:12])
 
 
 def test_tile_mirror_snapshot(tpt_defaults, oracle):
@@ -482,9 +485,9 @@ def test_cost_ordered_chunks_table_is_a_permutation_and_image_unchanged(tpt_defa
     assert rays == ro and tile.cpu().numpy().tobytes() == bo.tobytes()
 
 
-def test_config5_stress_scene_full_size_properties(tpt_defaults, oracle):
-    """configs[4]: 4096 spheres, 1920x1080, 8 spp at full size: determinism, finiteness, kernel-variant agreement, and
-    a band of rows against the oracle (seeds are partition independent, so a band is a valid sample)."""
+def test_config5_stress_scene_full_parity(tpt_defaults, oracle):
+    """configs[4]: 4096 spheres, 1920x1080, 8 spp at full size: every pixel and the ray count against the oracle, plus
+    determinism, finiteness and kernel-variant agreement."""
     from toypathtracer_amd.scenes import STRESS_CAMERA, stress_scene
     tpt = tpt_defaults
     s, m = stress_scene(4096, 64)
@@ -499,9 +502,9 @@ def test_config5_stress_scene_full_size_properties(tpt_defaults, oracle):
     assert r1 > 2 * w * h * spp
     cam = oracle.camera(STRESS_CAMERA["look_from"], STRESS_CAMERA["look_at"], (0, 1, 0), STRESS_CAMERA["vfov"], w / h,
                         STRESS_CAMERA["aperture"], STRESS_CAMERA["focus_dist"])
-    band = np.zeros((h, w, 4), np.float32)
-    oracle.render(s, m, cam, w, h, spp, 0, seed_mode=SEED_PER_PIXEL, backbuffer=band, y0=300, y1=303)
-    assert b1[300:303].tobytes() == band[300:303].tobytes()
+    # the WHOLE frame against the oracle's brute force over 4096 spheres (the grouped traversal must change nothing)
+    ro, bo = oracle.render(s, m, cam, w, h, spp, 0, seed_mode=SEED_PER_PIXEL)
+    assert r1 == ro and b1.tobytes() == bo.tobytes()
     tpt.set_kernel_variant(0, 1, -1)  # lane-refill kernel on the same frame
     r3, b3, _ = gpu_frames(tpt, w, h, 1)
     assert r3 == r1 and b3.tobytes() == b1.tobytes()

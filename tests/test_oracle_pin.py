@@ -37,7 +37,9 @@ def test_baseline_md_goldens_are_in_the_fixture():
     assert by[(640, 360, 4, 1, 2)]["rays"] == 4204569 and by[(640, 360, 4, 1, 2)]["fnv"] == "a299de4a"
     assert by[(640, 360, 1, 1, 2)]["rays"] == 1050173 and by[(640, 360, 1, 1, 2)]["fnv"] == "641c3e8f"
     assert by[(1280, 720, 4, 1, 2)]["rays"] == 16809105
+    assert by[(1280, 720, 4, 2, 2)]["rays"] == 33632052 and by[(1280, 720, 4, 2, 2)]["fnv"] == "609aacda"
     assert by[(1280, 720, 4, 3, 2)]["rays"] == 50450142 and by[(1280, 720, 4, 3, 2)]["fnv"] == "16cce49a"
+    assert by[(1280, 720, 4, 10, 2)]["rays"] == 168141976 and by[(1280, 720, 4, 10, 2)]["fnv"] == "46afd557"
 
 
 def test_default_scene_matches_reference_scene_desc(oracle):

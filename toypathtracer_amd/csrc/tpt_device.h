@@ -50,8 +50,10 @@ int tptTraceSortedOccupancy(int fold, bool ldsScene, size_t lds);
 size_t tptQueueLdsBytes(const tpt::KernelArgs& a, bool ldsScene);
 hipError_t tptLaunchTraceQueue(const tpt::KernelArgs& a, bool ldsScene, int blocks, size_t lds, hipStream_t stream);
 int tptQueuePathsPerBlock();
+int tptQueueMatrixFilter();
 int tptQueueThreadsPerBlock();
 hipError_t tptLaunchDisplay(const float* tile, unsigned char* rgba, int width, int height, hipStream_t stream);
+hipError_t tptLaunchQueueProbe(unsigned long long ticks, hipStream_t stream);
 hipError_t tptLaunchChunkOrder(const unsigned* cost, unsigned* snap, unsigned* order, int numChunks, hipStream_t stream);
 hipError_t tptLaunchResolve(float* tile, const tpt::f4* frameColour, int nPixels, float lerpFac, float* mirror,
                             const unsigned long long* rayCounter, unsigned long long* counterOut, hipStream_t stream);

@@ -13,6 +13,7 @@
 #include "tpt_device.h"
 #include "tpt_scene.h"
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <map>
 #include <stdio.h>
 #include <stdlib.h>
@@ -23,8 +24,9 @@ using namespace tpt;
 namespace {
 
 struct Context {
-    static const int kMaxOverlap = 32;              // frames in flight (trace streams, colour buffers, ...)
-    static const int kOrderTables = kMaxOverlap + 2; // rotating chunk-order tables: more than frames in flight
+    static const int kMaxOverlap = 16;              // frames in flight (trace streams, colour buffers, ...): one hardware queue each
+    static const int kMaxSlots = kMaxOverlap;       // frame slots (colour / stack / path buffers, events)
+    static const int kOrderTables = kMaxSlots + 2;  // rotating chunk-order tables: more than frames in flight
     bool inited = false;
     int device = 0, numCUs = 0;
     std::string deviceName, err;
@@ -43,10 +45,10 @@ struct Context {
     // device scene: a ring of scene sets, so that an animated scene (kFlagAnimate re-packs every frame,
     // Test.cpp:304-308,321-339) is uploaded asynchronously while earlier frames still read the older sets.
     // One device blob + one pinned host staging blob per set, laid out pairs | sph4 | invR | mats | lights.
-    // A frame uploads at most one set, a set is reused after kSceneSets uploads, at most kMaxOverlap frames
+    // A frame uploads at most one set, a set is reused after kSceneSets uploads, at most kMaxSlots frames
     // are in flight and the upload is stream-ordered behind the resolve of frame f - overlap: no kernel still reads the
     // set that is being overwritten.
-    static const int kSceneSets = 2 * kMaxOverlap;
+    static const int kSceneSets = 2 * kMaxSlots;
     struct SceneSet {
         char* dev = nullptr;
         char* stage = nullptr; // pinned
@@ -86,7 +88,7 @@ struct Context {
     unsigned long long* dRaysOwn = nullptr;
     long long lastTotal = 0;
 
-    f4* dStack[kMaxOverlap] = {};       // recursive fold: global bounce stacks / spill levels (one per in-flight frame)
+    f4* dStack[kMaxSlots] = {};         // recursive fold: global bounce stacks / spill levels (one per in-flight frame)
     size_t stackCap = 0, colourCap = 0, pathCap = 0; // bytes per slot; all reserved slots have the same capacities
     int slotsReserved = 0;              // slots [0, slotsReserved) hold buffers of those capacities
     int slotReservations = 0;           // how often the slot buffers were (re-)allocated (tptGetPipelineInfo)
@@ -101,7 +103,7 @@ struct Context {
     bool orderDone = true;
     unsigned long long orderSeq = 0;
     int lastOrderTable = 0;
-    f4* dPath[kMaxOverlap] = {};        // path-queue kernel: cold path state (one per in-flight frame)
+    f4* dPath[kMaxSlots] = {};          // path-queue kernel: cold path state (one per in-flight frame)
     float* dFrame = nullptr; // device tile behind the host-pointer DrawTest
     const float* uploadSrc = nullptr; // tptDraw: host backbuffer whose rows tptDrawDevice uploads once the trace is launched
     size_t frameCap = 0;
@@ -110,9 +112,10 @@ struct Context {
     // their own per-frame colour buffer; the (ordered) resolve kernels run on g.stream
     int overlap = 16;
     hipStream_t traceStream[kMaxOverlap] = {};
-    hipEvent_t evTrace[kMaxOverlap] = {}, evResolve[kMaxOverlap] = {};
-    bool resolveRecorded[kMaxOverlap] = {};
-    f4* dColour[kMaxOverlap] = {};
+    hipEvent_t evTrace[kMaxSlots] = {}, evResolve[kMaxSlots] = {};
+    bool resolveRecorded[kMaxSlots] = {};
+    f4* dColour[kMaxSlots] = {};
+    int hwQueues = 0, overlapCap = kMaxOverlap; // measured at tptInitialize (probeHardwareQueues)
     unsigned long long frameSeq = 0;
 
     // per-launch timing of the trace kernel: hipEvent pairs on the stream each launch goes to
@@ -297,7 +300,7 @@ int enqueueSceneUpload(hipStream_t ts)
 
 // Number of earlier frames whose trace kernel has not finished yet (their events complete in order: amortised one
 // hipEventQuery per frame).
-int framesInFlight(int nOverlap)
+int framesInFlight(int nOverlap) // nOverlap: frame slots in use
 {
     if (nOverlap <= 1) return 0;
     if (g.oldestPending + (unsigned long long)nOverlap < g.frameSeq) g.oldestPending = g.frameSeq - (unsigned long long)nOverlap;
@@ -337,6 +340,36 @@ int requireInit()
     return 0;
 }
 
+// How many of the trace streams does the runtime really run side by side?  ROCm maps streams onto GPU_MAX_HW_QUEUES
+// hardware queues (default 4) and reads that variable when the runtime starts -- a host that touched HIP before loading
+// this library keeps its 4, whatever tptInitialize puts into the environment, and streams that share a queue serialise
+// (3 frames in flight on 4 queues were SLOWER than 2).  So measure instead of assuming: one wave spinning 2 ms on each
+// trace stream; 16 concurrent ones take ~2 ms, 4 queues take 4 rounds.  The frame pipeline is then clamped to what the
+// queues can carry (tptGetPipelineInfo reports both numbers).
+int probeHardwareQueues()
+{
+    // Long enough that enqueueing the 16 probes (~20 us each) does not matter: 2 ms of the 100 MHz wall clock.
+    const double spinUs = 2000.0;
+    const unsigned long long ticks = (unsigned long long)(spinUs * 100.0);
+    for (int rep = 0; rep < 2; ++rep) { // first round: warm-up (code object load, queue creation)
+        const auto t0 = std::chrono::steady_clock::now();
+        for (int k = 0; k < Context::kMaxOverlap; ++k) HIPCHK(tptLaunchQueueProbe(rep ? ticks : 100ull, g.traceStream[k]));
+        for (int k = 0; k < Context::kMaxOverlap; ++k) HIPCHK(hipStreamSynchronize(g.traceStream[k]));
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        if (rep) {
+            const double rounds = us / spinUs; // 1.0x with a queue per stream, 4 with the default 4 queues
+            int q = (int)((double)Context::kMaxOverlap / (rounds > 1.0 ? rounds : 1.0) + 0.5);
+            if (rounds < 1.5) q = Context::kMaxOverlap; // all side by side
+            g.hwQueues = q < 1 ? 1 : q;
+        }
+    }
+    // the ordered resolve chain, the scene uploads and the caller's own streams need queues too: with fewer than
+    // ~3 queues per 2 trace streams to spare, two frames in flight is the best there is
+    g.overlapCap = g.hwQueues >= Context::kMaxOverlap ? Context::kMaxOverlap : (g.hwQueues >= 8 ? g.hwQueues - 3 : 2);
+    if (const char* e = getenv("TPT_OVERLAP_CAP")) g.overlapCap = atoi(e) < 1 ? 1 : (atoi(e) > Context::kMaxOverlap ? Context::kMaxOverlap : atoi(e));
+    return 0;
+}
+
 } // namespace
 
 extern "C" {
@@ -373,16 +406,17 @@ int tptInitialize(void)
     g.orderDone = true;
     HIPCHK(hipEventCreate(&g.ev0));
     HIPCHK(hipEventCreate(&g.ev1));
-    HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dWork), 64 * Context::kMaxOverlap));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dWork), 64 * Context::kMaxSlots));
     // (memsets go to the stream that orders them against the first kernels: every stream of this context is
     //  non-blocking, the legacy null stream would order nothing)
-    HIPCHK(hipMemsetAsync(g.dWork, 0, 64 * Context::kMaxOverlap, g.stream));
-    for (int k = 0; k < Context::kMaxOverlap; ++k) {
-        HIPCHK(hipStreamCreateWithFlags(&g.traceStream[k], hipStreamNonBlocking));
+    HIPCHK(hipMemsetAsync(g.dWork, 0, 64 * Context::kMaxSlots, g.stream));
+    for (int k = 0; k < Context::kMaxOverlap; ++k) HIPCHK(hipStreamCreateWithFlags(&g.traceStream[k], hipStreamNonBlocking));
+    for (int k = 0; k < Context::kMaxSlots; ++k) {
         HIPCHK(hipEventCreateWithFlags(&g.evTrace[k], kOrderingEvent));
         HIPCHK(hipEventCreateWithFlags(&g.evResolve[k], kOrderingEvent));
         g.resolveRecorded[k] = false;
     }
+
     g.frameSeq = 0;
     g.oldestPending = 0;
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dRaysOwn), 64));
@@ -402,6 +436,10 @@ int tptInitialize(void)
         if (g.ldsStackLevels > TPT_MAX_DEPTH) g.ldsStackLevels = TPT_MAX_DEPTH;
     }
     g.sceneDirty = true;
+    {
+        int rc = probeHardwareQueues();
+        if (rc) return rc;
+    }
     g.inited = true;
     return 0;
 }
@@ -429,12 +467,15 @@ int tptShutdown(void)
     g.ktStart.clear(); g.ktStop.clear(); g.ktUsed = 0; g.kernelTiming = false;
     for (int k = 0; k < Context::kMaxOverlap; ++k) {
         if (g.traceStream[k]) { (void)hipStreamSynchronize(g.traceStream[k]); (void)hipStreamDestroy(g.traceStream[k]); }
+        g.traceStream[k] = nullptr;
+    }
+    for (int k = 0; k < Context::kMaxSlots; ++k) {
         if (g.evTrace[k]) (void)hipEventDestroy(g.evTrace[k]);
         if (g.evResolve[k]) (void)hipEventDestroy(g.evResolve[k]);
         (void)hipFree(g.dColour[k]);
         (void)hipFree(g.dStack[k]); g.dStack[k] = nullptr;
         (void)hipFree(g.dPath[k]); g.dPath[k] = nullptr;
-        g.traceStream[k] = nullptr; g.evTrace[k] = nullptr; g.evResolve[k] = nullptr; g.dColour[k] = nullptr;
+        g.evTrace[k] = nullptr; g.evResolve[k] = nullptr; g.dColour[k] = nullptr;
     }
     g.stackCap = g.colourCap = g.pathCap = 0; g.slotsReserved = 0; g.slotReservations = 0;
     (void)hipEventDestroy(g.ev0); (void)hipEventDestroy(g.ev1);
@@ -512,17 +553,16 @@ int tptKernelTimingEnd(float* outSumMs, int* outLaunches)
 
 int tptSetFrameOverlap(int frames)
 {
-    if (frames < 1 || frames > Context::kMaxOverlap) return fail("tptSetFrameOverlap: 1..32");
+    if (frames < 1 || frames > Context::kMaxOverlap) return fail("tptSetFrameOverlap: 1..16");
     if (g.inited) {
         HIPCHK(hipStreamSynchronize(g.stream));
         for (int k = 0; k < Context::kMaxOverlap; ++k)
             if (g.traceStream[k]) HIPCHK(hipStreamSynchronize(g.traceStream[k]));
     }
     g.overlap = frames;
-    g.frameSeq = 0;
-    g.oldestPending = 0;
+    g.oldestPending = g.frameSeq; // everything enqueued so far has completed (synchronised above)
     g.streamDepth = 1; g.prevInFlight = -1;
-    for (int k = 0; k < Context::kMaxOverlap; ++k) g.resolveRecorded[k] = false;
+    for (int k = 0; k < Context::kMaxSlots; ++k) g.resolveRecorded[k] = false;
     return 0;
 }
 
@@ -615,7 +655,8 @@ struct FramePlan {
     bool rowSerial = false, sorted = false, queued = false, ldsScene = false, useOrder = false;
     size_t lds = 0;
     int occ = 0, threadsPerBlock = 0, blocks = 0;
-    int nOverlap = 1, slot = 0; // frames in flight allowed / this frame's slot (trace stream, colour buffer, ...)
+    int nOverlap = 1;           // launches that may run side by side (trace streams in use)
+    int nSlots = 1, slot = 0;   // frames that may be enqueued ahead / this frame's slot (colour, stack, path buffers, events)
 };
 
 // Per-slot device buffers (frame colour, bounce stacks, path colour sums) are allocated for ALL slots of the pipeline at
@@ -733,7 +774,7 @@ void sizeGrid(FramePlan& P)
         // of 33 Gray/s.  So the deepest pipeline this caller has built is remembered (streamDepth) and only forgotten
         // when two consecutive frames find the pipeline empty: that is a caller who synchronises every frame
         // (the reference's DrawTest contract) and gets the whole machine.
-        const int inFlight = framesInFlight(P.nOverlap);
+        const int inFlight = framesInFlight(P.nSlots);
         if (inFlight == 0 && g.prevInFlight == 0) g.streamDepth = 1;
         if (inFlight + 1 > g.streamDepth) g.streamDepth = inFlight + 1;
         g.prevInFlight = inFlight;
@@ -774,7 +815,7 @@ int ensureFrameBuffers(FramePlan& P, int w)
     const size_t maxColumns = (size_t)maxBlocks * (size_t)(P.queued ? tptQueuePathsPerBlock() : P.threadsPerBlock);
     const size_t stackBytes = needStack ? maxColumns * (size_t)(TPT_MAX_DEPTH - a.ldsStackLevels) * sizeof(f4) : 0;
     const size_t pathBytes = P.queued ? maxColumns * sizeof(f4) : 0; // one colour sum per path
-    int rc = reserveSlotBuffers(P.nOverlap, (size_t)a.nLocalRows * w * sizeof(f4), stackBytes, pathBytes);
+    int rc = reserveSlotBuffers(P.nSlots, (size_t)a.nLocalRows * w * sizeof(f4), stackBytes, pathBytes);
     if (rc) return rc;
     a.frameColour = g.dColour[slot];
     a.work = g.dWork + 16 * slot;
@@ -791,8 +832,8 @@ int ensureFrameBuffers(FramePlan& P, int w)
 
 int syncAllStreams()
 {
-    HIPCHK(hipStreamSynchronize(g.stream));
     for (int k = 0; k < Context::kMaxOverlap; ++k) HIPCHK(hipStreamSynchronize(g.traceStream[k]));
+    HIPCHK(hipStreamSynchronize(g.stream));
     return 0;
 }
 
@@ -850,8 +891,8 @@ int enqueueChunkOrder(FramePlan& P, hipStream_t ts)
     if (!P.useOrder) return 0;
     if (g.orderSeq > 0) {
         const int fresh = (int)(g.orderSeq % Context::kOrderTables);
-        if (g.orderSeq <= (unsigned long long)(2 * P.nOverlap + 2) || (g.orderSeq & 31ull) == 0ull) {
-            HIPCHK(tptLaunchChunkOrder(g.dChunkCost, g.dChunkSnap[P.slot], g.dChunkOrder[fresh], P.a.numChunks, ts));
+        if (g.orderSeq <= (unsigned long long)(2 * P.nSlots + 2) || (g.orderSeq & 31ull) == 0ull) {
+            HIPCHK(tptLaunchChunkOrder(g.dChunkCost, g.dChunkSnap[P.slot % P.nOverlap], g.dChunkOrder[fresh], P.a.numChunks, ts));
             HIPCHK(hipEventRecord(g.evOrder, ts));
             g.orderStream = ts;
             g.orderDone = false;
@@ -903,7 +944,9 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
     const int tilesY = (a.nLocalRows + 7) / 8;
     a.numItems = g.seedMode == SEED_ROW_SERIAL ? a.nLocalRows : a.tilesX * tilesY * 64;
     P.nOverlap = g.overlap < 1 ? 1 : (g.overlap > Context::kMaxOverlap ? Context::kMaxOverlap : g.overlap);
-    P.slot = (int)(g.frameSeq % (unsigned long long)P.nOverlap);
+    if (P.nOverlap > g.overlapCap) P.nOverlap = g.overlapCap; // what the hardware queues granted to this process can carry
+    P.nSlots = P.nOverlap;
+    P.slot = (int)(g.frameSeq % (unsigned long long)P.nSlots);
     g.frameSeq++;
 
     int rc = chooseKernel(P);
@@ -918,8 +961,10 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
     // trace(f) on its own stream (no dependency on the previous frame), then the ordered blend on g.stream
     const int slot = P.slot;
     const bool pipelined = P.nOverlap > 1;
-    hipStream_t ts = pipelined ? g.traceStream[slot] : g.stream;
-    if (pipelined && g.resolveRecorded[slot]) HIPCHK(hipStreamWaitEvent(ts, g.evResolve[slot], 0)); // colour buffer free again
+    hipStream_t ts = pipelined ? g.traceStream[slot % P.nOverlap] : g.stream;
+    if (pipelined && g.resolveRecorded[slot]) {
+        HIPCHK(hipStreamWaitEvent(ts, g.evResolve[slot], 0)); // colour buffer free again
+    }
     if ((rc = enqueueSceneUpload(ts))) return rc; // behind the wait above: nobody reads the set being replaced any more
     if ((rc = enqueueChunkOrder(P, ts))) return rc;
     const bool timeIt = g.kernelTiming && g.ktUsed < g.ktStart.size();
@@ -1076,6 +1121,15 @@ int tptGetSceneDesc(void* outObjects, void* outMaterials, void* outCam, void* ou
     if (outEmissives && !g.packed.emissive.empty())
         memcpy(outEmissives, g.packed.emissive.data(), g.packed.emissive.size() * sizeof(int));
     if (outEmissiveCount) *outEmissiveCount = (int)g.packed.emissive.size();
+    return 0;
+}
+
+int tptGetPipelineInfo(int* outHwQueues, int* outOverlapEffective, int* outStreamDepth, int* outSlotReservations)
+{
+    if (outHwQueues) *outHwQueues = g.hwQueues;
+    if (outOverlapEffective) *outOverlapEffective = g.overlap < g.overlapCap ? g.overlap : g.overlapCap;
+    if (outStreamDepth) *outStreamDepth = g.streamDepth;
+    if (outSlotReservations) *outSlotReservations = g.slotReservations;
     return 0;
 }
 

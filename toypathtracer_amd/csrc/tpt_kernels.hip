@@ -65,6 +65,10 @@ __device__ __forceinline__ void storeColour(const KernelArgs& a, const Lane& L)
 // 48 B per pixel (read tile + colour, write tile).
 __global__ void __launch_bounds__(256) tptResolveKernel(float* __restrict__ tile, const f4* __restrict__ colour, int nPixels, float lerpFac)
 {
+    // These few waves land on CUs saturated with persistent trace waves, and VALU issue is arbitrated by priority, then
+    // AGE: the newcomer gets the leftover slots (a 6-us kernel took 40-1000 us; the ordered resolve chain is what bounds
+    // small frames).  Raise the wave's priority for its short life.
+    __builtin_amdgcn_s_setprio(3);
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= nPixels) return;
     f4 t = reinterpret_cast<const f4*>(tile)[i];
@@ -80,6 +84,7 @@ __global__ void __launch_bounds__(256) tptResolveMirrorKernel(float* __restrict_
                                                               f4* __restrict__ mirror, const unsigned long long* rayCounter,
                                                               unsigned long long* counterOut)
 {
+    __builtin_amdgcn_s_setprio(3); // see tptResolveKernel
     int i = blockIdx.x * 256 + threadIdx.x;
     if (i == 0 && counterOut) *counterOut = __hip_atomic_load(rayCounter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (i >= nPixels) return;
@@ -89,6 +94,16 @@ __global__ void __launch_bounds__(256) tptResolveMirrorKernel(float* __restrict_
     t.x = r.x; t.y = r.y; t.z = r.z;
     reinterpret_cast<f4*>(tile)[i] = t;
     mirror[i] = t;
+}
+
+// One wave that spins for `ticks` of the 100 MHz wall clock: tptInitialize launches one per trace stream to measure how
+// many of them the runtime really runs side by side (hardware queues granted to this process).
+__global__ void tptQueueProbeKernel(unsigned long long ticks, unsigned* sink)
+{
+    const unsigned long long t0 = wall_clock64();
+    unsigned n = 0;
+    while (wall_clock64() - t0 < ticks) ++n;
+    if (sink && n == 0xffffffffu) *sink = n;
 }
 
 #ifndef TPT_MIN_WAVES_PER_SIMD
@@ -562,6 +577,9 @@ __global__ void __launch_bounds__(TPT_SORT_T) tptTraceSortedKernel(const KernelA
 #define TPT_Q_FUSE_MIN 48 // a batch intersects its own rays when at least this many lanes still hold one
 #endif
 #define TPT_Q_NF4 3
+#ifndef TPT_MATRIX_FILTER
+#define TPT_MATRIX_FILTER 0 // 1: phase 1 on v_mfma_f32_32x32x2_f32 for scenes of <= 64 spheres (measured slower)
+#endif
 enum { Q_FREE = 0, Q_INT = 1, Q_END = 2, Q_DIEL = 3, Q_METAL = 4, Q_LAMBERT = 5, Q_COUNT = 6 };
 struct QueueCtl {
     unsigned head[8];
@@ -696,9 +714,11 @@ tptTraceQueueKernel(const KernelArgs a)
     off += Q_COUNT * TPT_Q_P * 2;
     QueueCtl* ctl = reinterpret_cast<QueueCtl*>(smem + off);
     off += (int)sizeof(QueueCtl) + 64 - (int)sizeof(QueueCtl) % 64;
+#if TPT_MATRIX_FILTER
     // phase 1 on the matrix cores (scenes of <= 64 spheres): the A-operand table, 3 KB
     const bool useMatrix = LDS_SCENE && a.scene.mxR1 >= 0;
     float* ldsA = reinterpret_cast<float*>(smem + off);
+#endif
 
     const int tid = threadIdx.x, lane = tid & 63;
     SceneView sv = a.scene;
@@ -714,9 +734,11 @@ tptTraceQueueKernel(const KernelArgs a)
     }
     for (int i = tid; i < a.scene.nLights * 2; i += TPT_Q_T) ldsLights[i] = a.scene.lights[i];
     sv.lights = ldsLights;
+#if TPT_MATRIX_FILTER
     if (useMatrix)
         for (int i = tid; i < 2 * 6 * 64; i += TPT_Q_T) ldsA[i] = a.scene.amat[i];
     const int mxR1 = a.scene.mxR1;
+#endif
     // every path starts in the FREE queue; all other queues empty (sentinel everywhere)
     for (int i = tid; i < Q_COUNT * TPT_Q_P; i += TPT_Q_T) q[i] = (unsigned short)(i < TPT_Q_P ? i : 0xFFFF);
     if (tid < 8) {
@@ -735,6 +757,11 @@ tptTraceQueueKernel(const KernelArgs a)
     int chunkNext = 0, chunkEnd = 0; // this wave's private pixel pool
     bool noMoreChunks = false;
     unsigned myRays = 0;
+#if defined(TPT_STATS)
+    const unsigned long long qT0 = wall_clock64();
+    unsigned qSteps = 0, qBatches = 0, qIdle = 0;
+    unsigned long long qSec[5] = {0, 0, 0, 0, 0}; // s_memtime ticks: pick+pop, class code, intersect, push, idle
+#endif
 
 #if defined(TPT_STATS)
 #define TPT_TSTAMP(v)                      \
@@ -742,7 +769,11 @@ tptTraceQueueKernel(const KernelArgs a)
     __builtin_amdgcn_s_waitcnt(0);         \
     const unsigned long long v = __builtin_amdgcn_s_memtime(); \
     __builtin_amdgcn_sched_barrier(0)
+#if TPT_STATS < 2
 #define TPT_TADD(slot, a, b) do { if (lane == 0) atomicAdd(&g_tptStats[slot], (b) - (a)); } while (0)
+#else // level 2: per-wave sums by KIND of section (slot & 3; idle = 4), flushed when the wave ends
+#define TPT_TADD(slot, a, b) do { qSec[(slot) == 64 + 24 ? 4 : ((slot) & 3)] += (b) - (a); } while (0)
+#endif
 #else
 #define TPT_TSTAMP(v) do { } while (0)
 #define TPT_TADD(slot, a, b) do { } while (0)
@@ -785,6 +816,9 @@ tptTraceQueueKernel(const KernelArgs a)
             if (avail[Q_FREE] == (unsigned)TPT_Q_P && pool == 0u && exhausted != 0u && !canStart) break;
             if (exhausted != 0u && pool == 0u) noMoreChunks = true;
             TPT_STAT(ST_REFILL); // idle polls
+#if defined(TPT_STATS)
+            qIdle++;
+#endif
             __builtin_amdgcn_s_sleep(4);
             TPT_TSTAMP(tsIdle);
             TPT_TADD(64 + 24, tsTop, tsIdle);
@@ -793,6 +827,9 @@ tptTraceQueueKernel(const KernelArgs a)
         int p = 0;
         const int n = qPop(q + pick * TPT_Q_P, &ctl->head[pick], &ctl->tail[pick], lane, p);
         if (n == 0) continue;
+#if defined(TPT_STATS)
+        qBatches++;
+#endif
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         TPT_TSTAMP(tsPop);
         TPT_TADD(64 + pick * 4 + 0, tsTop, tsPop);
@@ -918,16 +955,25 @@ tptTraceQueueKernel(const KernelArgs a)
             float hitT = 0.0f;
             bool pending = ray;
             while (__ballot(pending) != 0ull) {
-                // phase 1 of HitSpheres for the whole wave on the matrix cores (every lane takes part; lanes without a ray
-                // feed whatever finite values they hold and ignore their mask)
+#if defined(TPT_STATS)
+                qSteps++;
+#endif
+                // (TPT_MATRIX_FILTER builds: phase 1 of HitSpheres for the whole wave on the matrix cores; every lane takes part,
+                //  lanes without a ray feed whatever finite values they hold and ignore their mask)
+#if TPT_MATRIX_FILTER
                 uint64_t cand = 0ull;
                 if (LDS_SCENE && useMatrix) cand = phase1Matrix(ldsA, mxR1, L.orig, L.dir);
+#endif
                 if (pending) {
                     TPT_STAT(ST_STEP);
                     float t;
+#if TPT_MATRIX_FILTER
                     const int id = (LDS_SCENE && useMatrix)
                                        ? hitSpheresCandidates(sv, cand, L.orig, L.dir, TPT_MIN_T, TPT_MAX_T, t)
                                        : hitSpheres<LDS_SCENE ? HS_TWO_PHASE : HS_TWO_PHASE_GROUPS>(sv, L.orig, L.dir, TPT_MIN_T, TPT_MAX_T, t);
+#else
+                    const int id = hitSpheres<LDS_SCENE ? HS_TWO_PHASE : HS_TWO_PHASE_GROUPS>(sv, L.orig, L.dir, TPT_MIN_T, TPT_MAX_T, t);
+#endif
                     myRays++;
                     if (L.kind == KIND_SHADOW) {
                         (void)lanePost<FOLD_RECURSIVE>(L, id, t, sv, fc, stack); // Test.cpp:123-132, then next light or bounce
@@ -971,6 +1017,20 @@ tptTraceQueueKernel(const KernelArgs a)
             a.work[1] = 0u;
         }
     }
+#if defined(TPT_STATS)
+    if (lane == 0) {
+        const unsigned long long qT1 = wall_clock64();
+        TPT_COUNT(106, qSteps);       // intersection iterations of this wave
+        TPT_COUNT(107, waveRays);     // rays in them
+        TPT_COUNT(108, qT1 - qT0);    // wave lifetime, 10 ns ticks
+        TPT_COUNT(109, 1);            // waves
+        TPT_COUNT(110, qBatches);     // batches popped
+        TPT_COUNT(105, qIdle);        // idle polls
+#if TPT_STATS >= 2
+        for (int k = 0; k < 5; ++k) TPT_COUNT(112 + k, qSec[k]);
+#endif
+    }
+#endif
 }
 
 // ---------------------------------------------------------------- unit-test kernels (GPU parity of the math layer)
@@ -1160,7 +1220,9 @@ size_t tptQueueLdsBytes(const KernelArgs& a, bool ldsScene)
     if (ldsScene) bytes += (size_t)nPad * 16 + (((size_t)nPad * 4 + 15) & ~(size_t)15) + (size_t)a.scene.nSpheres * 48;
     bytes += (size_t)a.scene.nLights * 32;
     bytes += (size_t)TPT_Q_NF4 * TPT_Q_P * 16 + (size_t)Q_COUNT * TPT_Q_P * 2 + sizeof(QueueCtl) + 64;
+#if TPT_MATRIX_FILTER
     if (ldsScene && a.scene.mxR1 >= 0) bytes += 2 * 6 * 64 * sizeof(float) + 64;
+#endif
     return bytes;
 }
 hipError_t tptLaunchTraceQueue(const KernelArgs& a, bool ldsScene, int blocks, size_t lds, hipStream_t stream)
@@ -1179,6 +1241,7 @@ hipError_t tptLaunchTraceQueue(const KernelArgs& a, bool ldsScene, int blocks, s
     return hipGetLastError();
 }
 int tptQueuePathsPerBlock() { return TPT_Q_P; }
+int tptQueueMatrixFilter() { return TPT_MATRIX_FILTER; }
 int tptQueueThreadsPerBlock() { return TPT_Q_T; }
 
 hipError_t tptLaunchDisplay(const float* tile, unsigned char* rgba, int width, int height, hipStream_t stream)
@@ -1188,6 +1251,11 @@ hipError_t tptLaunchDisplay(const float* tile, unsigned char* rgba, int width, i
     return hipGetLastError();
 }
 
+hipError_t tptLaunchQueueProbe(unsigned long long ticks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(tptQueueProbeKernel, dim3(1), dim3(64), 0, stream, ticks, static_cast<unsigned*>(nullptr));
+    return hipGetLastError();
+}
 hipError_t tptLaunchChunkOrder(const unsigned* cost, unsigned* snap, unsigned* order, int numChunks, hipStream_t stream)
 {
     hipLaunchKernelGGL(tptChunkOrderKernel, dim3(1), dim3(1024), 0, stream, cost, snap, order, numChunks);

@@ -99,7 +99,7 @@ TPT_HD f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 #if defined(__HIPCC__) && defined(TPT_STATS)
 __device__ unsigned long long g_tptStats[128];
 #endif
-#if defined(__HIP_DEVICE_COMPILE__) && defined(TPT_STATS)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(TPT_STATS) && TPT_STATS < 2
 #define TPT_STAT(i)                                                                  \
     do {                                                                             \
         unsigned long long m_ = __ballot(1);                                         \
@@ -112,6 +112,12 @@ __device__ unsigned long long g_tptStats[128];
 #define TPT_STAT(i) \
     do {            \
     } while (0)
+#endif
+// -DTPT_STATS=2: only a handful of cheap event counters (slots 100..), so that the build still runs at full speed
+#if defined(__HIP_DEVICE_COMPILE__) && defined(TPT_STATS)
+#define TPT_COUNT(slot, n) atomicAdd(&g_tptStats[slot], (unsigned long long)(n))
+#else
+#define TPT_COUNT(slot, n) do { } while (0)
 #endif
 enum { ST_STEP = 0, ST_PHASE2 = 1, ST_CAMERA = 2, ST_SHADOW = 3, ST_SKY = 4, ST_HIT = 5, ST_LAMBERT = 6, ST_METAL = 7,
        ST_DIELECTRIC = 8, ST_LIGHTGEN = 9, ST_BOUNCE = 10, ST_FINISH = 11, ST_REFILL = 12, ST_CHUNK = 13, ST_PIXELDONE = 14,

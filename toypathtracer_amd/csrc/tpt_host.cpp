@@ -714,13 +714,23 @@ int chooseKernel(FramePlan& P)
     P.sorted = g.persist == 2 && !P.rowSerial && g.hs == HS_TWO_PHASE; // lane-sorting kernel (PER_PIXEL seeds only)
     // path-queue kernel: PER_PIXEL seeds, recursive fold, two-phase HitSpheres
     // (it packs a pixel as x | y << 16 and a path id as 16 bits: larger frames take the lane-refill kernel)
+    // (so does its 64-B path record: 11 bits of sample index, 16 of sphere id)
     P.queued = g.persist == 3 && !P.rowSerial && g.hs == HS_TWO_PHASE && g.foldMode == FOLD_RECURSIVE && a.fc.width <= 65535 &&
-               a.fc.height <= 65535;
+               a.fc.height <= 65535 && g.spp <= 2047 && a.scene.nSpheres <= 65534;
     P.lds = P.queued ? tptQueueLdsBytes(a, P.ldsScene) : P.sorted ? tptSortedLdsBytes(a, g.foldMode, P.ldsScene) : ldsV1;
     if ((size_t)a.scene.nLights * 32 > 96 * 1024)
         return fail("tptDrawDevice: too many emissive spheres for the LDS light table (3072 at most)");
     if (P.lds > 160 * 1024) return fail("tptDrawDevice: scene too large for LDS staging; use tptSetKernelVariant(.., .., 0)");
-    if (P.sorted || P.queued) a.ldsStackLevels = 0;
+    if (P.sorted) a.ldsStackLevels = 0;
+    if (P.queued) {
+        a.ldsStackLevels = 1; // level 0 of the bounce stack sits in the path record (LDS), levels 1-9 in global memory
+        // two workgroups per CU are worth more than the scene in LDS: a scene that costs the second workgroup its place
+        // is read from global memory (L2) instead
+        if (g.ldsScene < 0 && P.ldsScene && 160 * 1024 / (P.lds + 256) < 2 && 160 * 1024 / (tptQueueLdsBytes(a, false) + 256) >= 2) {
+            P.ldsScene = false;
+            P.lds = tptQueueLdsBytes(a, false);
+        }
+    }
     const int key = (P.queued ? (1 << 30) : 0) | (P.sorted ? 16 : 0) | (g.hs ? 8 : 0) | (g.foldMode ? 4 : 0) | (g.persist ? 2 : 0) |
                     (P.ldsScene ? 1 : 0) | ((int)(P.lds / 256) << 5);
     auto it = g.occCache.find(key);
@@ -814,7 +824,7 @@ int ensureFrameBuffers(FramePlan& P, int w)
     const bool needStack = g.persist && g.foldMode == FOLD_RECURSIVE && a.ldsStackLevels < TPT_MAX_DEPTH;
     const size_t maxColumns = (size_t)maxBlocks * (size_t)(P.queued ? tptQueuePathsPerBlock() : P.threadsPerBlock);
     const size_t stackBytes = needStack ? maxColumns * (size_t)(TPT_MAX_DEPTH - a.ldsStackLevels) * sizeof(f4) : 0;
-    const size_t pathBytes = P.queued ? maxColumns * sizeof(f4) : 0; // one colour sum per path
+    const size_t pathBytes = 0; // (the path-queue kernel's per-path colour sums moved into LDS)
     int rc = reserveSlotBuffers(P.nSlots, (size_t)a.nLocalRows * w * sizeof(f4), stackBytes, pathBytes);
     if (rc) return rc;
     a.frameColour = g.dColour[slot];
@@ -826,7 +836,7 @@ int ensureFrameBuffers(FramePlan& P, int w)
         a.stackBuf = g.dStack[slot];
         a.stackStride = P.queued ? P.blocks * tptQueuePathsPerBlock() : P.blocks * P.threadsPerBlock;
     }
-    a.pathBuf = P.queued ? g.dPath[slot] : nullptr;
+    a.pathBuf = nullptr;
     return 0;
 }
 

@@ -51,6 +51,12 @@ __device__ __forceinline__ int localRowToGlobal(const KernelArgs& a, int ly)
     return (ly / a.stripeRows) * a.stripeStride + a.stripeOffset + (ly % a.stripeRows);
 }
 
+__device__ __forceinline__ int globalRowToLocal(const KernelArgs& a, int gy) // inverse of localRowToGlobal, for rows of this rank
+{
+    const int q = gy / a.stripeStride;
+    return q * a.stripeRows + (gy - q * a.stripeStride - a.stripeOffset);
+}
+
 __device__ __forceinline__ void storeColour(const KernelArgs& a, const Lane& L)
 {
     f3 c = lanePixelColour(L, a.fc);
@@ -576,7 +582,7 @@ __global__ void __launch_bounds__(TPT_SORT_T) tptTraceSortedKernel(const KernelA
 #ifndef TPT_Q_FUSE_MIN
 #define TPT_Q_FUSE_MIN 48 // a batch intersects its own rays when at least this many lanes still hold one
 #endif
-#define TPT_Q_NF4 3
+#define TPT_Q_NF4 4
 #ifndef TPT_MATRIX_FILTER
 #define TPT_MATRIX_FILTER 0 // 1: phase 1 on v_mfma_f32_32x32x2_f32 for scenes of <= 64 spheres (measured slower)
 #endif
@@ -647,42 +653,36 @@ __device__ __forceinline__ int qPop(volatile unsigned short* q, unsigned* head, 
     return (int)n;
 }
 
-__device__ __forceinline__ uint32_t qFlags(const Lane& L)
+// The path record, 64 B in LDS, four f4 planes [plane][path]:
+//   [0] ray origin -- for a path waiting in a class queue: the HIT POSITION orig + dir * t (Maths.cpp:195) -- .xyz, rng
+//   [1] ray direction .xyz, {sample : 11, depth : 4, doMatE : 1, hit id : 16}
+//   [2] colour sum of the pixel's finished samples .xyz (Test.cpp:289), pixel x | y << 16
+//   [3] bounce-stack level 0 {matE + lightE, attenuation id}: 56 % of all pushes; deeper levels live in global memory
+// Everything else of a Lane is constant while a path sits in a queue (a main-chain ray, alive, no camera ray pending;
+// sp == depth with the recursive fold) or is recomputed by the class code.
+__device__ __forceinline__ void qStoreHot(const Lane& L, int id, f4* st, int p)
 {
-    return ((uint32_t)L.sample & 0xffffu) | (((uint32_t)L.depth & 15u) << 16) | ((uint32_t)(L.kind & 1) << 20) |
-           (((uint32_t)L.hitType & 3u) << 21) | ((uint32_t)L.active << 23) | ((uint32_t)L.needCamera << 24) |
-           ((uint32_t)L.doMatE << 25) | (((uint32_t)L.sp & 15u) << 26);
-}
-__device__ __forceinline__ void qUnflags(Lane& L, uint32_t flags)
-{
-    L.sample = (int)(flags & 0xffffu);
-    L.depth = (int)((flags >> 16) & 15u);
-    L.kind = (int)((flags >> 20) & 1u);
-    L.hitType = (int)((flags >> 21) & 3u);
-    L.active = ((flags >> 23) & 1u) != 0;
-    L.needCamera = ((flags >> 24) & 1u) != 0;
-    L.doMatE = ((flags >> 25) & 1u) != 0;
-    L.sp = (int)((flags >> 26) & 15u);
-}
-// hot state (LDS): [0] orig.xyz rng  [1] dir.xyz t  [2] flags, hit id, pix, -
-__device__ __forceinline__ void qStoreHot(const Lane& L, int id, float t, f4* st, int p)
-{
+    const uint32_t w = ((uint32_t)L.sample & 0x7ffu) | (((uint32_t)L.depth & 15u) << 11) | ((uint32_t)L.doMatE << 15) | (((uint32_t)id & 0xffffu) << 16);
     st[0 * TPT_Q_P + p] = mk4(L.orig.x, L.orig.y, L.orig.z, u2f(L.rng));
-    st[1 * TPT_Q_P + p] = mk4(L.dir.x, L.dir.y, L.dir.z, t);
-    st[2 * TPT_Q_P + p] = mk4(u2f(qFlags(L)), u2f((uint32_t)id), u2f((uint32_t)L.pix), 0.0f);
+    st[1 * TPT_Q_P + p] = mk4(L.dir.x, L.dir.y, L.dir.z, u2f(w));
 }
-__device__ __forceinline__ void qLoadHot(Lane& L, int& id, float& t, const f4* st, int p)
+__device__ __forceinline__ void qLoadHot(Lane& L, int& id, const f4* st, int p)
 {
     f4 v = st[0 * TPT_Q_P + p];
     L.orig = mk3(v.x, v.y, v.z); L.rng = f2u(v.w);
     v = st[1 * TPT_Q_P + p];
-    L.dir = mk3(v.x, v.y, v.z); t = v.w;
-    v = st[2 * TPT_Q_P + p];
-    qUnflags(L, f2u(v.x));
-    id = (int)f2u(v.y);
-    L.pix = (int)f2u(v.z);
+    L.dir = mk3(v.x, v.y, v.z);
+    const uint32_t w = f2u(v.w);
+    L.sample = (int)(w & 0x7ffu);
+    L.depth = (int)((w >> 11) & 15u);
+    L.sp = L.depth; // recursive fold: one stack entry per bounce
+    L.doMatE = ((w >> 15) & 1u) != 0;
+    id = (w >> 16) == 0xffffu ? -1 : (int)(w >> 16);
+    L.kind = KIND_MAIN;
+    L.active = true;
+    L.needCamera = false;
+    L.hitType = 0;
 }
-// cold state (global, per path): colour sum of the pixel's finished samples .xyz, x | y << 16
 
 #ifndef TPT_Q_MIN_WAVES_PER_SIMD
 #define TPT_Q_MIN_WAVES_PER_SIMD 4
@@ -753,7 +753,7 @@ tptTraceQueueKernel(const KernelArgs a)
 
     const FrameConsts& fc = a.fc;
     const unsigned long long laneBelow = (1ull << lane) - 1ull;
-    f4* cold = a.pathBuf + (size_t)blockIdx.x * TPT_Q_P; // this workgroup's [P] colour sums
+    f4* colSum = st + 2 * TPT_Q_P;                        // plane 2: per-path colour sums + pixel coordinates
     int chunkNext = 0, chunkEnd = 0; // this wave's private pixel pool
     bool noMoreChunks = false;
     unsigned myRays = 0;
@@ -846,9 +846,9 @@ tptTraceQueueKernel(const KernelArgs a)
         bool ray = false;    // this lane holds a ray that still has to be intersected
         bool toFree = false; // this lane's path goes back to the FREE queue
         BounceStack stack;
-        stack.base = nullptr;
+        stack.base = st + 3 * TPT_Q_P + p; // level 0 in the path record
         stack.stride = 0;
-        stack.fastLevels = 0;
+        stack.fastLevels = 1;
         stack.spill = a.stackBuf + ((size_t)blockIdx.x * TPT_Q_P + p);
         stack.spillStride = a.stackStride;
 
@@ -896,7 +896,7 @@ tptTraceQueueKernel(const KernelArgs a)
             if (mine && L.active) {
                 L.hitType = 0;
                 laneCamera<FOLD_RECURSIVE>(L, fc);
-                cold[p] = mk4(0.0f, 0.0f, 0.0f, u2f((uint32_t)L.x | ((uint32_t)L.y << 16))); // colour sum = 0
+                colSum[p] = mk4(0.0f, 0.0f, 0.0f, u2f((uint32_t)L.x | ((uint32_t)L.y << 16))); // colour sum = 0
                 ray = true;
             } else if (mine) {
                 toFree = true; // no pixel left for this path
@@ -905,15 +905,13 @@ tptTraceQueueKernel(const KernelArgs a)
             // ---- overflow: rays of sparse batches, re-batched
             if (mine) {
                 int id;
-                float t;
-                qLoadHot(L, id, t, st, p);
+                qLoadHot(L, id, st, p);
                 ray = true;
             }
         } else if (mine) {
             // ---- Scatter / sky / fold of one class, at full lane utilisation
             int id;
-            float t;
-            qLoadHot(L, id, t, st, p);
+            qLoadHot(L, id, st, p);
             L.sdir = L.nl = L.lightE = L.albedo = L.matE = mk3(0, 0, 0);
             L.cosAMax = 0.0f;
             L.hitId = 0;
@@ -921,21 +919,19 @@ tptTraceQueueKernel(const KernelArgs a)
             L.col = mk3(0, 0, 0); // colour of the sample that ends in this step, if one does (0 + c == c)
             L.x = 0; L.y = 0;
             const int sampleBefore = L.sample;
-            // END batches always finish a sample: ask for the pixel's running sum now, use it after the fold
-            f4 c3 = mk4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (pick == Q_END) c3 = cold[p];
-            const bool pixelDone = lanePost<FOLD_RECURSIVE>(L, id, t, sv, fc, stack);
+            const bool pixelDone = lanePost<FOLD_RECURSIVE, true>(L, id, 0.0f, sv, fc, stack);
             if (L.sample != sampleBefore) {
                 // a sample ended: add it to the pixel's running sum (same order of additions as Test.cpp:289)
-                if (pick != Q_END) c3 = cold[p];
+                const f4 c3 = colSum[p];
                 L.col = mk3(c3.x, c3.y, c3.z) + L.col;
                 L.x = (int)(f2u(c3.w) & 0xffffu);
                 L.y = (int)(f2u(c3.w) >> 16);
                 if (pixelDone) {
+                    L.pix = globalRowToLocal(a, L.y) * fc.width + L.x;
                     storeColour(a, L);
                     toFree = true;
                 } else {
-                    cold[p] = mk4(L.col.x, L.col.y, L.col.z, c3.w);
+                    colSum[p] = mk4(L.col.x, L.col.y, L.col.z, c3.w);
                     laneCamera<FOLD_RECURSIVE>(L, fc); // needCamera is set: next sample of the same pixel
                     ray = true;
                 }
@@ -991,10 +987,11 @@ tptTraceQueueKernel(const KernelArgs a)
                     const int type = (int)f2u(sv.mats[hitId * 3].w);
                     cls = type == MAT_LAMBERT ? Q_LAMBERT : type == MAT_METAL ? Q_METAL : type == MAT_DIELECTRIC ? Q_DIEL : Q_END;
                 }
-                qStoreHot(L, hitId, hitT, st, p);
+                if (hitId >= 0) L.orig = L.orig + L.dir * hitT; // the hit position (Maths.cpp:195), all the class code needs of {orig, t}
+                qStoreHot(L, hitId, st, p);
             }
         } else if (ray) {
-            qStoreHot(L, 0, 0.0f, st, p);
+            qStoreHot(L, 0, st, p);
             cls = Q_INT;
         }
         if (toFree) cls = Q_FREE;

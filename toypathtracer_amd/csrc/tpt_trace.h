@@ -659,7 +659,9 @@ TPT_HD int laneClassify(const Lane& L, int id, const SceneView& sv)
 
 // Everything after HitWorld for one ray of this lane: Scatter / light sampling / bounce / fold.
 // Returns true when the lane's pixel is complete (L.col then holds the sum over spp samples).
-template <int FOLD>
+// POS_GIVEN: L.orig already holds the hit position orig + dir * t (the path-queue kernel computes it right after the
+// intersection and keeps it instead of {orig, t} in the path record)
+template <int FOLD, bool POS_GIVEN = false>
 TPT_HD bool lanePost(Lane& L, const int id, const float t, const SceneView& sv, const FrameConsts& fc, const BounceStack& stack)
 {
     bool lightLoop = false, finish = false, bounce = false;
@@ -687,7 +689,7 @@ TPT_HD bool lanePost(Lane& L, const int id, const float t, const SceneView& sv, 
         // ---- hit: finish HitSpheres (Maths.cpp:195-197), then Scatter (Test.cpp:83-193)
         TPT_STAT(ST_HIT);
         f4 s = sv.sph4[id];
-        f3 pos = L.orig + L.dir * t;
+        f3 pos = POS_GIVEN ? L.orig : L.orig + L.dir * t;
         f3 normal = (pos - mk3(s.x, s.y, s.z)) * sv.invR[id];
         f4 m0 = sv.mats[id * 3], m1 = sv.mats[id * 3 + 1];
         int type = (int)f2u(m0.w);
@@ -814,18 +816,19 @@ TPT_HD bool lanePost(Lane& L, const int id, const float t, const SceneView& sv, 
             c = term;
             // matE + lightE + attenuation * Trace(...), Test.cpp:216, innermost level first.
             const int sp = L.sp;
-            if (stack.fastLevels == 0) {
-                // Stack entirely in global memory (path-queue kernel).  The records of ALL levels are requested before
-                // the first one is used: a loop that loads one level per trip pays one memory latency per level, and a
-                // wave runs as many trips as its deepest lane -- that loop alone was a third of all wave time.  Two groups
-                // of five keep the register cost at 20.
+            if (stack.fastLevels <= 1) {
+                // Stack (almost) entirely in global memory (path-queue kernel: level 0 in LDS, the rest global; lane-sorting
+                // kernel: all global).  The records of ALL levels are requested before the first one is used: a loop that
+                // loads one level per trip pays one memory latency per level, and a wave runs as many trips as its deepest
+                // lane -- that loop alone was a third of all wave time.  Two groups of five keep the register cost at 20.
 #pragma unroll
                 for (int g5 = 1; g5 >= 0; --g5) {
                     f4 ent[5];
 #pragma unroll
                     for (int k = 0; k < 5; ++k) {
                         ent[k].x = ent[k].y = ent[k].z = ent[k].w = 0.0f;
-                        if (g5 * 5 + k < sp) ent[k] = stack.spill[(g5 * 5 + k) * stack.spillStride];
+                        const int lvl = g5 * 5 + k;
+                        if (lvl < sp) ent[k] = lvl < stack.fastLevels ? stack.base[lvl * stack.stride] : stack.spill[(lvl - stack.fastLevels) * stack.spillStride];
                     }
 #pragma unroll
                     for (int k = 4; k >= 0; --k) {

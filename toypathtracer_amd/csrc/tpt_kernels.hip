@@ -594,8 +594,25 @@ struct QueueCtl {
     unsigned globalExhausted; // some wave saw the global chunk counter run out
 };
 
-// Push every lane's path id to the queue of its class `cls` (Q_FREE..Q_LAMBERT, or -1 for none) with ONE LDS atomic
-// instruction: lane c reserves the slots of class c, the bases come back through readlane.
+// Push every lane's path id to the queue of its class `cls` (Q_FREE..Q_LAMBERT, or -1 for none): one returning LDS atomic
+// per lane reserves the slot (the LDS unit serialises the lanes that hit the same tail word -- its time, not the VALU's:
+// the ballot / popcount / readlane version of this cost ~35 VALU instructions per batch).
+#ifndef TPT_Q_PUSH_BALLOT
+__device__ __forceinline__ void qPushByClass(volatile unsigned short* q, QueueCtl* ctl, int cls, int pathId, int lane)
+{
+    (void)lane;
+    if (cls >= 0) {
+        const unsigned pos = atomicAdd(&ctl->tail[cls], 1u);
+        volatile unsigned short* slot = q + cls * TPT_Q_P + (pos & (TPT_Q_P - 1));
+        // A consumer advances the head BEFORE it reads its slots, and ids can cycle through a ring any number of times
+        // while one consumer stalls between those two steps (FREE: pop, no pixel left, push again): the tail may lap a
+        // reserved-but-unread slot.  Publish only into a slot whose previous entry has been taken (sentinel restored).
+        while (*slot != 0xFFFFu) {
+        }
+        *slot = (unsigned short)pathId;
+    }
+}
+#else
 __device__ __forceinline__ void qPushByClass(volatile unsigned short* q, QueueCtl* ctl, int cls, int pathId, int lane)
 {
     unsigned long long mine = 0ull;
@@ -616,14 +633,12 @@ __device__ __forceinline__ void qPushByClass(volatile unsigned short* q, QueueCt
     }
     if (cls >= 0) {
         volatile unsigned short* slot = q + cls * TPT_Q_P + ((base + (unsigned)__popcll(mine & ((1ull << lane) - 1ull))) & (TPT_Q_P - 1));
-        // A consumer advances the head BEFORE it reads its slots, and ids can cycle through a ring any number of times
-        // while one consumer stalls between those two steps (FREE: pop, no pixel left, push again): the tail may lap a
-        // reserved-but-unread slot.  Publish only into a slot whose previous entry has been taken (sentinel restored).
         while (*slot != 0xFFFFu) {
         }
         *slot = (unsigned short)pathId;
     }
 }
+#endif
 // Pops up to 64 ids (uniform count returned); lanes < count receive a path id.
 __device__ __forceinline__ int qPop(volatile unsigned short* q, unsigned* head, unsigned* tail, int lane, int& pathId)
 {

@@ -47,6 +47,22 @@ int tptUpdate(float time, int frameCount, int screenWidth, int screenHeight, uns
  * With row sharding active (tptSetRowShard) only this rank's rows are touched. */
 int tptDraw(float time, int frameCount, int screenWidth, int screenHeight, float* backbuffer, int* outRayCount,
             unsigned testFlags);
+/* The host-pointer path above keeps the reference's contract (synchronous, the caller's buffer read-modify-written in
+ * place); three things make it fast, none changes a byte of the result:
+ *  - the upload of the previous image, the blend and the download are done in four row bands on two streams, so that one
+ *    band's download crosses PCIe while the next band's upload does (full duplex).  The caller's memory is NOT page-locked:
+ *    it is the caller's to free between calls, and the download is as fast from pageable memory (measured: 270 us);
+ *  - tptSetHostBufferMode(1): the caller promises that nobody but DrawTest writes the backbuffer between calls (true of
+ *    every reference host: TestWin.cpp:73-74,315-316; Renderer.mm:225; Emscripten/main.cpp:59-60) -- the device-resident
+ *    accumulation tile is then the source of truth and the buffer is uploaded once per buffer / size / frameCount == 0
+ *    instead of every frame.  Default 0: upload every frame, exactly as the reference's semantics demand;
+ *  - tptSetHostLookahead(n), default 2: after DrawTest(f) the library traces frames f+1 .. f+n AHEAD, guessing that the
+ *    host goes on with the same size / flags / scene (what every reference host does); the next DrawTest then only
+ *    blends and downloads.  A frame alone on the GPU is bound by its longest paths (1.0 ms at 1280x720x4); with three in
+ *    flight the pipeline delivers one every 0.55 ms.  A wrong guess (other frame number, size, flags, scene, spp, ...) only
+ *    costs GPU time: the frames traced ahead are dropped and the frame is traced again.  Never used with kFlagAnimate. */
+int tptSetHostBufferMode(int hostBufferOnlyWrittenByDrawTest);
+int tptSetHostLookahead(int frames);
 /* GetObjectCount / GetSceneDesc, Test.h:16-17 / Test.cpp:369-384: sizes are 20 / 36 / 88 bytes and
  * the copies are byte-compatible with the reference's Sphere / Material / Camera structs. */
 int tptGetObjectCount(int* outCount, int* outObjectSize, int* outMaterialSize, int* outCamSize);

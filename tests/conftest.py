@@ -72,4 +72,6 @@ def tpt_defaults(tpt):
     tpt.set_kernel_variant(0, 3, -1)
     tpt.set_row_shard(0, 1, 0)
     tpt.set_frame_overlap(16)
+    tpt.set_host_buffer_mode(False)
+    tpt.set_host_lookahead(2)
     return tpt

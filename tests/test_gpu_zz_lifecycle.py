@@ -19,6 +19,7 @@ def test_shutdown_and_reinitialise(tpt_defaults, oracle):
         for f in range(2):
             tpt.UpdateTest(0.0, f, w, h, 2)
             rays += tpt.DrawTest(0.0, f, w, h, bb, 2)
-        assert rays == ro and bb.tobytes() == bo.tobytes()
+        assert rays == ro, cycle
+        assert bb.tobytes() == bo.tobytes(), cycle
         tpt.ShutdownTest()
         tpt.InitializeTest()

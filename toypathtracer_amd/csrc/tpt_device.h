@@ -56,7 +56,7 @@ hipError_t tptLaunchDisplay(const float* tile, unsigned char* rgba, int width, i
 hipError_t tptLaunchQueueProbe(unsigned long long ticks, hipStream_t stream);
 hipError_t tptLaunchChunkOrder(const unsigned* cost, unsigned* snap, unsigned* order, int numChunks, hipStream_t stream);
 hipError_t tptLaunchResolve(float* tile, const tpt::f4* frameColour, int nPixels, float lerpFac, float* mirror,
-                            const unsigned long long* rayCounter, unsigned long long* counterOut, hipStream_t stream);
+                            unsigned long long* rayCounter, unsigned long long* counterOut, const unsigned long long* frameRays, hipStream_t stream);
 hipError_t tptLaunchMathTest(int op, const float* a, const float* b, float* out, int n, hipStream_t stream);
 hipError_t tptLaunchMatrixFilterTest(const tpt::KernelArgs& a, const float* rays, unsigned long long* outMask, int n, hipStream_t stream);
 hipError_t tptLaunchHitTest(const tpt::KernelArgs& a, int hs, const float* rays, int* outId, float* outT, int n, hipStream_t stream);

@@ -69,13 +69,16 @@ __device__ __forceinline__ void storeColour(const KernelArgs& a, const Lane& L)
 // Separate from the trace kernel so that consecutive frames' trace kernels carry no dependency on each
 // other and can overlap on the device (the tail of frame f runs beside the head of frame f+1).  HBM-bound:
 // 48 B per pixel (read tile + colour, write tile).
-__global__ void __launch_bounds__(256) tptResolveKernel(float* __restrict__ tile, const f4* __restrict__ colour, int nPixels, float lerpFac)
+// frameRays (host-pointer path): the frame's own ray count, which this kernel folds into the context's running total.
+__global__ void __launch_bounds__(256) tptResolveKernel(float* __restrict__ tile, const f4* __restrict__ colour, int nPixels, float lerpFac,
+                                                        const unsigned long long* frameRays, unsigned long long* totalRays)
 {
     // These few waves land on CUs saturated with persistent trace waves, and VALU issue is arbitrated by priority, then
     // AGE: the newcomer gets the leftover slots (a 6-us kernel took 40-1000 us; the ordered resolve chain is what bounds
     // small frames).  Raise the wave's priority for its short life.
     __builtin_amdgcn_s_setprio(3);
     int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && frameRays) atomicAdd(totalRays, *frameRays);
     if (i >= nPixels) return;
     f4 t = reinterpret_cast<const f4*>(tile)[i];
     f4 c = colour[i];
@@ -1275,14 +1278,14 @@ hipError_t tptLaunchChunkOrder(const unsigned* cost, unsigned* snap, unsigned* o
 }
 
 hipError_t tptLaunchResolve(float* tile, const f4* frameColour, int nPixels, float lerpFac, float* mirror,
-                            const unsigned long long* rayCounter, unsigned long long* counterOut, hipStream_t stream)
+                            unsigned long long* rayCounter, unsigned long long* counterOut, const unsigned long long* frameRays, hipStream_t stream)
 {
     if (nPixels <= 0) return hipSuccess;
     if (mirror)
         hipLaunchKernelGGL(tptResolveMirrorKernel, dim3((nPixels + 255) / 256), dim3(256), 0, stream, tile, frameColour, nPixels, lerpFac,
                            reinterpret_cast<f4*>(mirror), rayCounter, counterOut);
     else
-        hipLaunchKernelGGL(tptResolveKernel, dim3((nPixels + 255) / 256), dim3(256), 0, stream, tile, frameColour, nPixels, lerpFac);
+        hipLaunchKernelGGL(tptResolveKernel, dim3((nPixels + 255) / 256), dim3(256), 0, stream, tile, frameColour, nPixels, lerpFac, frameRays, rayCounter);
     return hipGetLastError();
 }
 

@@ -134,6 +134,28 @@ int tptSetRayCounter(void* deviceU64);
  * pointers are read at enqueue time; call again to rotate buffers. */
 int tptSetTileMirror(float* deviceMirror, void* deviceCounterOut);
 int tptSynchronize(void);
+
+/* ---- multi-GPU inside the library: one process per GPU, RCCL over xGMI (replaces the row fan-out / join of
+ * DrawTest, Test.cpp:357-361, across GPUs).  A C++ host needs nothing but these five calls and a way to hand 128 bytes from
+ * rank 0 to the other processes (pipe, file, MPI, ...): examples/multi_gpu_host.cpp.
+ *   rank 0: tptCommGetUniqueId(id);  every rank: tptInitialize (TPT_DEVICE / LOCAL_RANK picks the GPU), tptCommInit(id, n, rank, 8);
+ *   per frame, every rank: tptUpdate(...); tptDrawSharded(time, f, w, h, imageOnRank0, flags);   (asynchronous)
+ *   tptShardedFinish(&rays);  ...  tptCommDestroy() / tptShutdown().
+ * The image's rows are dealt out in stripes of `stripeRows` rows round-robin over the ranks (cost is not uniform in y); each
+ * rank keeps its compact accumulation tile resident; per frame exactly ONE collective -- ncclGather (rccl.h:745) of the
+ * blended tile plus one row whose first 8 bytes carry the rank's 64-bit ray counter -- on a communication stream, from a
+ * ring of 4 snapshots written by the blend kernel itself, so it overlaps the tracing of the next frames; rank 0
+ * de-interleaves the gathered tiles into `deviceImageOnRoot` (w*h*4 floats, device memory; ignored on other ranks).  RNG seeds
+ * depend on the global (x, y) only: the assembled image is bit-identical to a 1-GPU render.  librccl is dlopen()ed by
+ * tptCommInit / tptCommGetUniqueId; a single-GPU host never loads it. */
+#define TPT_COMM_ID_BYTES 128
+int tptCommGetUniqueId(void* outId128);
+int tptCommInit(const void* id128, int nRanks, int rank, int stripeRows);
+int tptCommDestroy(void);
+int tptDrawSharded(float time, int frameCount, int screenWidth, int screenHeight, float* deviceImageOnRoot, unsigned testFlags);
+/* waits for every exchange enqueued so far; rank 0: total rays of all ranks as of the last frame, other ranks: their own */
+int tptShardedFinish(int64_t* outTotalRays);
+
 /* hipEvent bracket on the context's stream, for kernel-only timing (as the reference times its
  * Dispatch with timestamp queries, TestWin.cpp:299-302). */
 int tptTimerBegin(void);

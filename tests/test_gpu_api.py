@@ -231,3 +231,83 @@ def test_drawtest_trusted_buffer_mode(tpt_defaults, oracle):
     _draw_seq(tpt, [2], w, h, bb)
     assert float(bb[:10, :, :3].min()) > 3.0  # 5 * 2/3 + col / 3
     tpt.set_host_buffer_mode(False)
+
+
+# ---- multi-GPU through the C ABI (RCCL inside the library)
+def _build_multi_gpu_host(tmp_path):
+    exe = str(tmp_path / "multi_gpu_host")
+    libdir = os.path.join(ROOT, "toypathtracer_amd", "lib")
+    subprocess.check_call(["g++", "-O2", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "multi_gpu_host.cpp"),
+                           "-L", libdir, "-ltoypathtracer_hip", "-L", "/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + libdir,
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    return exe
+
+
+def _run_multi_gpu_host(exe, ranks, w, h, frames, stripe):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.check_output([exe, str(ranks), str(w), str(h), str(frames), str(stripe)], stderr=subprocess.STDOUT, env=env,
+                                  timeout=300).decode()
+    m = re.search(r"(\d+) rays, .* fnv ([0-9a-f]{8})", out)
+    assert m, out
+    return int(m.group(1)), m.group(2)
+
+
+def test_cxx_host_shards_through_the_c_abi_one_rank(oracle, tmp_path):
+    """examples/multi_gpu_host.cpp with a communicator of ONE rank: librccl is loaded, ncclCommInitRank / ncclGather /
+    the assemble kernel / the snapshot ring all run (a gather to oneself), image and ray count equal the oracle's."""
+    exe = _build_multi_gpu_host(tmp_path)
+    w, h, frames = 320, 184, 6
+    rays, fnv = _run_multi_gpu_host(exe, 1, w, h, frames, 8)
+    ro, bo = oracle.render_frames(w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
+    assert rays == ro and fnv == "%08x" % fnv1a(bo)
+    rays5, fnv5 = _run_multi_gpu_host(exe, 1, 203, 117, 3, 5)   # ragged: 117 rows in stripes of 5
+    ro5, bo5 = oracle.render_frames(203, 117, 4, 3, seed_mode=SEED_PER_PIXEL)
+    assert rays5 == ro5 and fnv5 == "%08x" % fnv1a(bo5)
+
+
+def test_cxx_host_shards_over_two_gpus(oracle, tmp_path):
+    """The same host with two processes on two GPUs: RCCL over xGMI, one ncclGather per frame.  Skipped on a 1-GPU box."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    exe = _build_multi_gpu_host(tmp_path)
+    w, h, frames = 320, 184, 6
+    rays, fnv = _run_multi_gpu_host(exe, 2, w, h, frames, 8)
+    ro, bo = oracle.render_frames(w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
+    assert rays == ro and fnv == "%08x" % fnv1a(bo)
+
+
+def test_bench_runs_on_two_ranks_over_rccl(tmp_path):
+    """bench.py --gpus 2 through torch.distributed.run (backend nccl == RCCL): the path the driver's scaling run takes.
+    Skipped on a 1-GPU box."""
+    import json
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                                   "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8",
+                                   "--warmup", "4", "--no-cpu-baseline"], stderr=subprocess.DEVNULL, env=env, timeout=600).decode()
+    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 1000
+
+
+def test_draw_sharded_in_process_single_rank(tpt_defaults, oracle):
+    """tptCommInit / tptDrawSharded / tptShardedFinish from this process, communicator of one rank, size change in between."""
+    import torch
+    from common import oracle_frames
+    tpt = tpt_defaults
+    tpt.comm_init(tpt.comm_get_unique_id(), 1, 0, 8)
+    try:
+        for (w, h, frames) in [(256, 144, 5), (160, 90, 3)]:
+            img = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+            r0 = tpt.sharded_finish()
+            for f in range(frames):
+                tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+                tpt.draw_sharded(0.0, f, w, h, img.data_ptr(), FLAG_PROGRESSIVE)
+            rays = tpt.sharded_finish() - r0
+            ro, bo, _ = oracle_frames(oracle, w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
+            assert rays == ro and img.cpu().numpy().tobytes() == bo.tobytes(), (w, h)
+    finally:
+        tpt.comm_destroy()

@@ -37,7 +37,7 @@ C_ABI_SYMBOLS = [
     "tptSetSamplesPerPixel", "tptSetSeedMode", "tptSetFoldMode", "tptSetScene", "tptSetCamera", "tptSetStream",
     "tptSetRowShard", "tptLocalRowCount", "tptLocalRowToGlobal", "tptDrawDevice", "tptRayCounterRead", "tptSetRayCounter", "tptSetFrameOverlap", "tptDisplayRGBA8", "tptKernelTimingBegin", "tptKernelTimingEnd",
     "tptSynchronize", "tptTimerBegin", "tptTimerEnd", "tptSetKernelVariant", "tptTestMath", "tptTestHitSpheres",
-    "tptGetLaunchInfo", "tptGetPipelineInfo", "tptSetHostBufferMode", "tptSetHostLookahead", "tptTestMatrixFilter", "tptSetTileMirror", "tptGetLastError", "tptGetDeviceName", "tptDebugStats", "tptDebugChunkOrder",
+    "tptCommGetUniqueId", "tptCommInit", "tptCommDestroy", "tptDrawSharded", "tptShardedFinish", "tptGetLaunchInfo", "tptGetPipelineInfo", "tptSetHostBufferMode", "tptSetHostLookahead", "tptTestMatrixFilter", "tptSetTileMirror", "tptGetLastError", "tptGetDeviceName", "tptDebugStats", "tptDebugChunkOrder",
 ]
 # the reference's own C++ symbols (nm of the compiled Test.cpp), exported for link-level drop-in
 CXX_ABI_SYMBOLS = [
@@ -79,7 +79,7 @@ def load_library():
         "tptSetRayCounter": [p], "tptSetTileMirror": [p, p], "tptSetFrameOverlap": [i], "tptDisplayRGBA8": [p, i, i, p], "tptKernelTimingBegin": [i],
         "tptKernelTimingEnd": [C.POINTER(f), C.POINTER(i)],
         "tptSynchronize": [], "tptTimerBegin": [], "tptTimerEnd": [C.POINTER(f)], "tptSetKernelVariant": [i, i, i],
-        "tptDebugStats": [p, i], "tptDebugChunkOrder": [p, p, i], "tptTestMath": [i, p, p, p, i], "tptTestHitSpheres": [i, p, p, p, i], "tptTestMatrixFilter": [p, p, i], "tptGetLaunchInfo": [C.POINTER(i)] * 4, "tptGetPipelineInfo": [C.POINTER(i)] * 4, "tptSetHostBufferMode": [i], "tptSetHostLookahead": [i],
+        "tptDebugStats": [p, i], "tptDebugChunkOrder": [p, p, i], "tptTestMath": [i, p, p, p, i], "tptTestHitSpheres": [i, p, p, p, i], "tptTestMatrixFilter": [p, p, i], "tptGetLaunchInfo": [C.POINTER(i)] * 4, "tptGetPipelineInfo": [C.POINTER(i)] * 4, "tptCommGetUniqueId": [p], "tptCommInit": [p, i, i, i], "tptCommDestroy": [], "tptDrawSharded": [f, i, i, i, p, u], "tptShardedFinish": [C.POINTER(C.c_int64)], "tptSetHostBufferMode": [i], "tptSetHostLookahead": [i],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -264,6 +264,30 @@ def launch_info():
     v = [C.c_int() for _ in range(4)]
     load_library().tptGetLaunchInfo(*[C.byref(x) for x in v])
     return dict(blocks_per_cu=v[0].value, lds_bytes=v[1].value, grid_blocks=v[2].value, num_cus=v[3].value)
+
+
+def comm_get_unique_id():
+    buf = (C.c_char * 128)()
+    _chk(load_library().tptCommGetUniqueId(buf), "tptCommGetUniqueId")
+    return bytes(buf)
+
+
+def comm_init(unique_id, n_ranks, rank, stripe_rows=8):
+    _chk(load_library().tptCommInit(C.c_char_p(unique_id), n_ranks, rank, stripe_rows), "tptCommInit")
+
+
+def comm_destroy():
+    _chk(load_library().tptCommDestroy(), "tptCommDestroy")
+
+
+def draw_sharded(time, frameCount, screenWidth, screenHeight, device_image_ptr, testFlags):
+    _chk(load_library().tptDrawSharded(time, frameCount, screenWidth, screenHeight, device_image_ptr, testFlags), "tptDrawSharded")
+
+
+def sharded_finish():
+    v = C.c_int64()
+    _chk(load_library().tptShardedFinish(C.byref(v)), "tptShardedFinish")
+    return v.value
 
 
 def set_host_buffer_mode(only_written_by_drawtest):

@@ -53,6 +53,7 @@ int tptQueuePathsPerBlock();
 int tptQueueMatrixFilter();
 int tptQueueThreadsPerBlock();
 hipError_t tptLaunchDisplay(const float* tile, unsigned char* rgba, int width, int height, hipStream_t stream);
+hipError_t tptLaunchAssemble(const float* gathered, float* image, int width, int height, int stripeRows, int nRanks, int padRows, hipStream_t stream);
 hipError_t tptLaunchQueueProbe(unsigned long long ticks, hipStream_t stream);
 hipError_t tptLaunchChunkOrder(const unsigned* cost, unsigned* snap, unsigned* order, int numChunks, hipStream_t stream);
 hipError_t tptLaunchResolve(float* tile, const tpt::f4* frameColour, int nPixels, float lerpFac, float* mirror,

@@ -13,7 +13,9 @@
 #include "tpt_device.h"
 #include "tpt_scene.h"
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h> // types and prototypes only: the library is dlopen()ed when tptCommInit is called
 #include <chrono>
+#include <dlfcn.h>
 #include <map>
 #include <stdio.h>
 #include <stdlib.h>
@@ -131,6 +133,27 @@ struct Context {
     TraceTicket aheadTicket[4];
     unsigned long long* dRaysAhead = nullptr; // [kMaxSlots] per-slot ray counters of the host path
     unsigned long long configEpoch = 1;       // bumped by every call that changes what a frame looks like
+
+    // ---- multi-GPU inside the library (one process per GPU, RCCL): tptCommInit .. tptDrawSharded
+    struct Shard {
+        static const int kRing = 4;     // send snapshots: a gather may trail the renderer by this many frames
+        void* lib = nullptr;            // librccl, loaded on first use (no link-time dependency: a single-GPU host never needs it)
+        ncclComm_t comm = nullptr;
+        int nRanks = 0, rank = 0, stripeRows = 8;
+        int w = 0, h = 0, padRows = 0;
+        hipStream_t commStream = nullptr;
+        float* tile = nullptr;          // this rank's resident accumulation tile [localRows][w] f4
+        float* send[kRing] = {};        // snapshots [padRows + 1][w] f4: blended tile + the row carrying the ray counter
+        float* gathered = nullptr;      // rank 0: [nRanks][padRows + 1][w] f4
+        hipEvent_t evSnap[kRing] = {}, evSent[kRing] = {};
+        bool sentRecorded[kRing] = {};
+        unsigned long long frames = 0;
+        decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+        decltype(&ncclCommInitRank) CommInitRank = nullptr;
+        decltype(&ncclCommDestroy) CommDestroy = nullptr;
+        decltype(&ncclGather) Gather = nullptr;
+        decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    } shard;
     size_t frameCap = 0;
 
     // frame pipelining: trace kernels of consecutive frames run on alternating internal streams and write
@@ -481,6 +504,7 @@ int tptShutdown(void)
 {
     if (!g.inited) return 0;
     (void)discardLookahead();
+    (void)tptCommDestroy();
     (void)hipStreamSynchronize(g.stream);
     (void)hipDeviceSynchronize();
     for (int k = 0; k < Context::kSceneSets; ++k) {
@@ -1338,6 +1362,180 @@ int tptGetSceneDesc(void* outObjects, void* outMaterials, void* outCam, void* ou
     if (outEmissives && !g.packed.emissive.empty())
         memcpy(outEmissives, g.packed.emissive.data(), g.packed.emissive.size() * sizeof(int));
     if (outEmissiveCount) *outEmissiveCount = (int)g.packed.emissive.size();
+    return 0;
+}
+
+// ---------------------------------------------------------------- multi-GPU inside the library
+// One process per GPU.  The image's rows are dealt out in stripes round-robin (tptSetRowShard); every rank renders its
+// stripes into its own resident tile; per frame ONE collective: ncclGather (rccl.h:745) of the blended tile + one extra
+// row whose first 8 bytes are the rank's 64-bit ray counter, to rank 0, on a communication stream, from a ring of
+// snapshots the resolve kernel itself writes (tptSetTileMirror) -- so the gather of frame f overlaps the tracing of the
+// following frames.  Rank 0 de-interleaves the gathered tiles into the caller's image.  Replaces the row fan-out / join of
+// DrawTest (Test.cpp:357-361) across GPUs; no Python, no torch: a C++ host that links this library shards by itself
+// (examples/multi_gpu_host.cpp).
+namespace {
+int loadRccl()
+{
+    Context::Shard& S = g.shard;
+    if (S.lib) return 0;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char* n : names)
+        if ((S.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
+    if (!S.lib) return fail(std::string("tptComm: cannot load librccl: ") + dlerror());
+    S.GetUniqueId = reinterpret_cast<decltype(S.GetUniqueId)>(dlsym(S.lib, "ncclGetUniqueId"));
+    S.CommInitRank = reinterpret_cast<decltype(S.CommInitRank)>(dlsym(S.lib, "ncclCommInitRank"));
+    S.CommDestroy = reinterpret_cast<decltype(S.CommDestroy)>(dlsym(S.lib, "ncclCommDestroy"));
+    S.Gather = reinterpret_cast<decltype(S.Gather)>(dlsym(S.lib, "ncclGather"));
+    S.GetErrorString = reinterpret_cast<decltype(S.GetErrorString)>(dlsym(S.lib, "ncclGetErrorString"));
+    if (!S.GetUniqueId || !S.CommInitRank || !S.CommDestroy || !S.Gather || !S.GetErrorString) return fail("tptComm: librccl lacks a needed symbol");
+    return 0;
+}
+int ncclFail(ncclResult_t r, const char* what)
+{
+    g.err = std::string(what) + ": " + (g.shard.GetErrorString ? g.shard.GetErrorString(r) : "RCCL error");
+    return -3;
+}
+#define NCCLCHK(x)                                        \
+    do {                                                  \
+        ncclResult_t _r = (x);                            \
+        if (_r != ncclSuccess) return ncclFail(_r, #x);   \
+    } while (0)
+
+int releaseShardBuffers()
+{
+    Context::Shard& S = g.shard;
+    if (S.commStream) HIPCHK(hipStreamSynchronize(S.commStream));
+    (void)hipFree(S.tile); S.tile = nullptr;
+    (void)hipFree(S.gathered); S.gathered = nullptr;
+    for (int k = 0; k < Context::Shard::kRing; ++k) { (void)hipFree(S.send[k]); S.send[k] = nullptr; S.sentRecorded[k] = false; }
+    S.w = S.h = S.padRows = 0;
+    return 0;
+}
+} // namespace
+
+int tptCommGetUniqueId(void* out128)
+{
+    if (!out128) return fail("tptCommGetUniqueId: NULL");
+    if (loadRccl()) return -1;
+    ncclUniqueId id;
+    NCCLCHK(g.shard.GetUniqueId(&id));
+    memcpy(out128, &id, sizeof(id));
+    return 0;
+}
+
+int tptCommInit(const void* id128, int nRanks, int rank, int stripeRows)
+{
+    if (requireInit()) return -1;
+    if (!id128 || nRanks < 1 || rank < 0 || rank >= nRanks || stripeRows < 1) return fail("tptCommInit: bad arguments");
+    if (g.shard.comm) return fail("tptCommInit: already initialised (tptCommDestroy first)");
+    if (loadRccl()) return -1;
+    Context::Shard& S = g.shard;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    NCCLCHK(S.CommInitRank(&S.comm, nRanks, id, rank));
+    S.nRanks = nRanks; S.rank = rank; S.stripeRows = stripeRows; S.frames = 0;
+    HIPCHK(hipStreamCreateWithFlags(&S.commStream, hipStreamNonBlocking));
+    for (int k = 0; k < Context::Shard::kRing; ++k) {
+        HIPCHK(hipEventCreateWithFlags(&S.evSnap[k], kOrderingEvent));
+        HIPCHK(hipEventCreateWithFlags(&S.evSent[k], kOrderingEvent));
+        S.sentRecorded[k] = false;
+    }
+    return tptSetRowShard(stripeRows, nRanks, rank);
+}
+
+int tptCommDestroy(void)
+{
+    Context::Shard& S = g.shard;
+    if (!S.comm) return 0;
+    (void)discardLookahead();
+    if (g.stream) (void)hipStreamSynchronize(g.stream);
+    (void)releaseShardBuffers();
+    (void)tptSetTileMirror(nullptr, nullptr);
+    NCCLCHK(S.CommDestroy(S.comm));
+    S.comm = nullptr;
+    for (int k = 0; k < Context::Shard::kRing; ++k) {
+        if (S.evSnap[k]) (void)hipEventDestroy(S.evSnap[k]);
+        if (S.evSent[k]) (void)hipEventDestroy(S.evSent[k]);
+        S.evSnap[k] = S.evSent[k] = nullptr;
+    }
+    if (S.commStream) (void)hipStreamDestroy(S.commStream);
+    S.commStream = nullptr;
+    S.nRanks = 0;
+    return tptSetRowShard(0, 1, 0);
+}
+
+// DrawTest for a frame sharded over the ranks of the communicator: asynchronous; `deviceImageOnRoot` (rank 0: w*h*4 floats in
+// device memory, may be NULL elsewhere) holds frame f once tptShardedFinish (or a later call's gather) has completed.
+int tptDrawSharded(float time, int frameCount, int w, int h, float* deviceImageOnRoot, unsigned testFlags)
+{
+    if (requireInit()) return -1;
+    Context::Shard& S = g.shard;
+    if (!S.comm) return fail("tptDrawSharded: call tptCommInit first");
+    if (w <= 0 || h <= 0) return fail("tptDrawSharded: bad size");
+    if (S.rank == 0 && !deviceImageOnRoot) return fail("tptDrawSharded: rank 0 needs the image buffer");
+    if (w != S.w || h != S.h) { // (re)allocate for this frame size: every rank the same padded tile height
+        int rc = releaseShardBuffers();
+        if (rc) return rc;
+        HIPCHK(hipStreamSynchronize(g.stream));
+        const int stripes = (h + S.stripeRows - 1) / S.stripeRows;
+        S.padRows = ((stripes + S.nRanks - 1) / S.nRanks) * S.stripeRows; // rank 0 owns the most stripes; whole stripes
+        const size_t rowBytes = (size_t)w * 4 * sizeof(float);
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&S.tile), rowBytes * (size_t)S.padRows));
+        HIPCHK(hipMemsetAsync(S.tile, 0, rowBytes * (size_t)S.padRows, g.stream));
+        for (int k = 0; k < Context::Shard::kRing; ++k) {
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&S.send[k]), rowBytes * (size_t)(S.padRows + 1)));
+            HIPCHK(hipMemsetAsync(S.send[k], 0, rowBytes * (size_t)(S.padRows + 1), g.stream));
+        }
+        if (S.rank == 0) HIPCHK(hipMalloc(reinterpret_cast<void**>(&S.gathered), rowBytes * (size_t)(S.padRows + 1) * (size_t)S.nRanks));
+        S.w = w; S.h = h;
+    }
+    const int k = (int)(S.frames % Context::Shard::kRing);
+    S.frames++;
+    // the snapshot this frame's resolve kernel writes must have left the GPU (gather of the frame that used it last)
+    if (S.sentRecorded[k]) HIPCHK(hipStreamWaitEvent(g.stream, S.evSent[k], 0));
+    const size_t tileFloats = (size_t)S.padRows * w * 4;
+    int rc = tptSetTileMirror(S.send[k], S.send[k] + tileFloats); // blended tile -> snapshot, ray counter -> first 8 bytes of the extra row
+    if (rc) return rc;
+    if ((rc = tptDrawDevice(time, frameCount, w, h, S.tile, testFlags))) return rc;
+    HIPCHK(hipEventRecord(S.evSnap[k], g.stream));
+    HIPCHK(hipStreamWaitEvent(S.commStream, S.evSnap[k], 0));
+    const size_t count = (size_t)(S.padRows + 1) * w * 4;
+    NCCLCHK(S.Gather(S.send[k], S.gathered, count, ncclFloat32, 0, S.comm, S.commStream));
+    if (S.rank == 0) HIPCHK(tptLaunchAssemble(S.gathered, deviceImageOnRoot, w, h, S.stripeRows, S.nRanks, S.padRows, S.commStream));
+    HIPCHK(hipEventRecord(S.evSent[k], S.commStream));
+    S.sentRecorded[k] = true;
+    return 0;
+}
+
+// Waits for every exchange enqueued so far; on rank 0 *outTotalRays = sum over the ranks of their ray counters as of the last
+// gathered frame (exact 64-bit integers: they travel bit-cast in the float payload), elsewhere this rank's own.
+int tptShardedFinish(int64_t* outTotalRays)
+{
+    if (requireInit()) return -1;
+    Context::Shard& S = g.shard;
+    if (!S.comm) return fail("tptShardedFinish: call tptCommInit first");
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipStreamSynchronize(S.commStream));
+    long long total = 0;
+    if (S.frames == 0 || !S.w) {
+        if (outTotalRays) *outTotalRays = 0;
+        return 0;
+    }
+    const size_t rowBytes = (size_t)S.w * 4 * sizeof(float);
+    if (S.rank == 0) {
+        for (int r = 0; r < S.nRanks; ++r) {
+            unsigned long long v = 0;
+            const char* src = reinterpret_cast<const char*>(S.gathered) + rowBytes * ((size_t)r * (S.padRows + 1) + S.padRows);
+            HIPCHK(hipMemcpy(&v, src, sizeof(v), hipMemcpyDeviceToHost));
+            total += (long long)v;
+        }
+    } else {
+        const int k = (int)((S.frames - 1) % Context::Shard::kRing);
+        unsigned long long v = 0;
+        HIPCHK(hipMemcpy(&v, reinterpret_cast<const char*>(S.send[k]) + rowBytes * (size_t)S.padRows, sizeof(v), hipMemcpyDeviceToHost));
+        total = (long long)v;
+    }
+    if (outTotalRays) *outTotalRays = total;
     return 0;
 }
 

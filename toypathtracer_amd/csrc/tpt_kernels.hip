@@ -105,6 +105,21 @@ __global__ void __launch_bounds__(256) tptResolveMirrorKernel(float* __restrict_
     mirror[i] = t;
 }
 
+// Rank 0 of a sharded frame: the gathered tiles [rank][padRows + 1][width] f4 (row stripes dealt round-robin, one extra row
+// per rank whose first 8 bytes carry that rank's ray counter) -> the image [height][width] f4.  HBM-bound copy, one f4 per
+// lane, coalesced on both sides; replaces the per-row joins of DrawTest's task set (Test.cpp:357-361).
+__global__ void __launch_bounds__(256) tptAssembleKernel(const f4* __restrict__ gathered, f4* __restrict__ image, int width, int height, int stripeRows,
+                                                         int nRanks, int padRows)
+{
+    __builtin_amdgcn_s_setprio(3);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= width * height) return;
+    const int gy = i / width, x = i - gy * width;
+    const int stripe = gy / stripeRows, rank = stripe % nRanks;
+    const int ly = (stripe / nRanks) * stripeRows + (gy - stripe * stripeRows);
+    image[i] = gathered[((size_t)rank * (padRows + 1) + ly) * width + x];
+}
+
 // One wave that spins for `ticks` of the 100 MHz wall clock: tptInitialize launches one per trace stream to measure how
 // many of them the runtime really runs side by side (hardware queues granted to this process).
 __global__ void tptQueueProbeKernel(unsigned long long ticks, unsigned* sink)
@@ -1266,6 +1281,12 @@ hipError_t tptLaunchDisplay(const float* tile, unsigned char* rgba, int width, i
     return hipGetLastError();
 }
 
+hipError_t tptLaunchAssemble(const float* gathered, float* image, int width, int height, int stripeRows, int nRanks, int padRows, hipStream_t stream)
+{
+    hipLaunchKernelGGL(tptAssembleKernel, dim3((width * height + 255) / 256), dim3(256), 0, stream, reinterpret_cast<const f4*>(gathered),
+                       reinterpret_cast<f4*>(image), width, height, stripeRows, nRanks, padRows);
+    return hipGetLastError();
+}
 hipError_t tptLaunchQueueProbe(unsigned long long ticks, hipStream_t stream)
 {
     hipLaunchKernelGGL(tptQueueProbeKernel, dim3(1), dim3(64), 0, stream, ticks, static_cast<unsigned*>(nullptr));

@@ -326,8 +326,9 @@ def main():
             api.set_row_shard(0, 1, 0)
             ms, mr = drawtest_host_path(api, width, height)
             out["drawtest_host_ms"], out["drawtest_host_Mray_s"] = ms, mr
-            out["drawtest_host_note"] = ("synchronous DrawTest(host float* backbuffer) per frame: backbuffer upload + trace + blend + download "
-                                         "over PCIe, one frame in flight -- the reference's own calling contract; never the headline value")
+            out["drawtest_host_note"] = ("synchronous DrawTest(host float* backbuffer) per frame, the reference's own calling contract: backbuffer "
+                                         "upload + blend + download over PCIe in every call (default host-buffer mode), the next two frames "
+                                         "traced ahead of the caller (tptSetHostLookahead); never the headline value")
             if scene == "default" and width * height <= 1280 * 720:
                 ms, mr = row_serial_rate(api, width, height)
                 out["row_serial_ms"], out["row_serial_Mray_s"] = ms, mr

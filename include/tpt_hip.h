@@ -72,6 +72,11 @@ int tptGetSceneDesc(void* outObjects, void* outMaterials, void* outCam, void* ou
 
 /* DO_SAMPLES_PER_PIXEL, Config.h:22 (default 4). */
 int tptSetSamplesPerPixel(int spp);
+/* DO_LIGHT_SAMPLING (default 1), DO_ANIMATE_SMOOTHING (default 0.9f), DO_MITSUBA_COMPARE (default 0), Config.h:23-25 /
+ * Test.cpp:95,143-145,209-214,226-227,273-274,312-313.  Without light sampling Lambert hits shoot no shadow rays and
+ * emission is never suppressed; "Mitsuba compare" is the reference's only correctness method (readme.md:30): metal
+ * roughness 0, constant sky (0.15, 0.21, 0.3), aperture 0 (takes effect at the next tptUpdate). */
+int tptSetConfig(int lightSampling, float animateSmoothing, int mitsubaCompare);
 /* RNG seeding.  0 = ROW_SERIAL: one XorShift stream per image row carried along x (Test.cpp:280);
  * bit-identical to the reference CPU image, parallel over rows only (debug / verification).
  * 1 = PER_PIXEL (default): one stream per pixel, the reference's own GPU formula

@@ -26,10 +26,18 @@ fi
 mkdir -p "$OUT"
 TMP=$(mktemp -d)
 trap 'rm -rf "$TMP"' EXIT
+# REDEF="MACRO value;MACRO value": further Config.h switches re-defined the same way (they are plain #defines in Config.h,
+# used by Test.cpp only, so -D cannot reach them): variants of the scalar path for pinning the oracle's run-time switches.
 build() {  # name, flags...
     local name=$1; shift
     local common="-std=c++11 -fPIC -DNDEBUG -Wno-attributes -include string.h -I$S"
-    ( cd "$TMP" && sed '/#include <atomic>/a #undef DO_SAMPLES_PER_PIXEL\n#define DO_SAMPLES_PER_PIXEL g_tpt_ref_spp\nextern int g_tpt_ref_spp;' "$S/Test.cpp" \
+    local extra=""
+    if [ -n "$REDEF" ]; then
+        local IFS=';'
+        for kv in $REDEF; do extra="$extra\\n#undef ${kv%% *}\\n#define $kv"; done
+        unset IFS
+    fi
+    ( cd "$TMP" && sed "/#include <atomic>/a #undef DO_SAMPLES_PER_PIXEL\\n#define DO_SAMPLES_PER_PIXEL g_tpt_ref_spp\\nextern int g_tpt_ref_spp;$extra" "$S/Test.cpp" \
         | g++ $common "$@" -x c++ -c - -o "$TMP/$name.Test.o" )
     g++ $common "$@" -c "$S/Maths.cpp" -o "$TMP/$name.Maths.o"
     g++ $common "$@" -c "$S/enkiTS/TaskScheduler.cpp" -o "$TMP/$name.ts.o"
@@ -44,4 +52,8 @@ build libtpt_ref      -O2 -msse4.1 -ffp-contract=off
 # scalar path" BASELINE.json's north_star names as the parity target.
 build libtpt_ref_scalar -O2 -ffp-contract=off -D__EMSCRIPTEN__ -D__EMSCRIPTEN_PTHREADS__
 build libtpt_ref_fast -O3 -msse4.1 -mavx2 -mfma -ffast-math
-echo "built $OUT/libtpt_ref.so $OUT/libtpt_ref_scalar.so $OUT/libtpt_ref_fast.so"
+# the reference's other compile-time switches (Config.h:23-25), scalar path: what the oracle's run-time switches are pinned to
+REDEF="DO_LIGHT_SAMPLING 0" build libtpt_ref_nols -O2 -ffp-contract=off -D__EMSCRIPTEN__ -D__EMSCRIPTEN_PTHREADS__
+REDEF="DO_MITSUBA_COMPARE 1" build libtpt_ref_mitsuba -O2 -ffp-contract=off -D__EMSCRIPTEN__ -D__EMSCRIPTEN_PTHREADS__
+REDEF="DO_ANIMATE_SMOOTHING 0.5f" build libtpt_ref_smooth05 -O2 -ffp-contract=off -D__EMSCRIPTEN__ -D__EMSCRIPTEN_PTHREADS__
+echo "built $OUT/libtpt_ref.so $OUT/libtpt_ref_scalar.so $OUT/libtpt_ref_fast.so + Config.h variants (nols, mitsuba, smooth05)"

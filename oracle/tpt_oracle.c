@@ -112,6 +112,7 @@ typedef struct {
     int emissiveCount;
     const TptoCamera* cam;
     int math_mode, fold_mode;
+    int no_light_sampling, mitsuba_compare; /* Config.h:24-25 as run-time switches */
 } Scene;
 
 static int HitSpheres(const Scene* sc, const Ray* r, float tMin, float tMax, Hit* outHit) /* Maths.cpp:165-202 */
@@ -175,7 +176,7 @@ static int Scatter(const Scene* sc, int matId, const Ray* r_in, const Hit* rec, 
         scattered->dir = normalize(sub(target, rec->pos));
         f3 matAlbedo = ld3(mat->albedo);
         *attenuation = matAlbedo;
-        for (int j = 0; j < sc->emissiveCount; ++j) { /* Test.cpp:96-133 */
+        for (int j = 0; j < (sc->no_light_sampling ? 0 : sc->emissiveCount); ++j) { /* Test.cpp:96-133 (#if DO_LIGHT_SAMPLING) */
             int i = sc->emissive[j];
             if (i == matId) continue; /* skip self */
             const TptoMaterial* smat = &sc->mats[i];
@@ -208,6 +209,7 @@ static int Scatter(const Scene* sc, int matId, const Ray* r_in, const Hit* rec, 
     } else if (mat->type == TPTO_METAL) { /* Test.cpp:137-150 */
         f3 refl = reflect3(r_in->dir, rec->normal);
         float roughness = mat->roughness;
+        if (sc->mitsuba_compare) roughness = 0; /* Test.cpp:143-145 */
         scattered->orig = rec->pos;
         scattered->dir = normalize(add(refl, smul(roughness, RandomInUnitSphere(state))));
         *attenuation = ld3(mat->albedo);
@@ -263,14 +265,16 @@ static f3 Trace(const Scene* sc, const Ray* r, int depth, int64_t* inoutRayCount
         const TptoMaterial* mat = &sc->mats[id];
         f3 matE = ld3(mat->emissive);
         if (depth < kMaxDepth && Scatter(sc, id, r, &rec, &attenuation, &scattered, &lightE, inoutRayCount, state)) {
-            if (!doMaterialE) matE = mk(0, 0, 0);
-            doMaterialE = (mat->type != TPTO_LAMBERT);
+            if (!sc->no_light_sampling) { /* Test.cpp:209-214 */
+                if (!doMaterialE) matE = mk(0, 0, 0);
+                doMaterialE = (mat->type != TPTO_LAMBERT);
+            }
             f3 rest = Trace(sc, &scattered, depth + 1, inoutRayCount, state, doMaterialE);
             return add(add(matE, lightE), mul(attenuation, rest));
         }
         return matE;
     }
-    return Sky(r);
+    return sc->mitsuba_compare ? mk(0.15f, 0.21f, 0.3f) : Sky(r); /* Test.cpp:226-231 */
 }
 
 /* Same paths as Trace, colour folded front-to-back (what a GPU megakernel naturally does). */
@@ -282,14 +286,16 @@ static f3 TraceForward(const Scene* sc, Ray r, int64_t* inoutRayCount, uint32_t*
         Hit rec;
         ++*inoutRayCount;
         int id = HitSpheres(sc, &r, kMinT, kMaxT, &rec);
-        if (id == -1) return add(radiance, mul(throughput, Sky(&r)));
+        if (id == -1) return add(radiance, mul(throughput, sc->mitsuba_compare ? mk(0.15f, 0.21f, 0.3f) : Sky(&r)));
         Ray scattered;
         f3 attenuation, lightE;
         const TptoMaterial* mat = &sc->mats[id];
         f3 matE = ld3(mat->emissive);
         if (depth < kMaxDepth && Scatter(sc, id, &r, &rec, &attenuation, &scattered, &lightE, inoutRayCount, state)) {
-            if (!doMaterialE) matE = mk(0, 0, 0);
-            doMaterialE = (mat->type != TPTO_LAMBERT);
+            if (!sc->no_light_sampling) {
+                if (!doMaterialE) matE = mk(0, 0, 0);
+                doMaterialE = (mat->type != TPTO_LAMBERT);
+            }
             radiance = add(radiance, mul(throughput, add(matE, lightE)));
             throughput = mul(throughput, attenuation);
             r = scattered;
@@ -317,7 +323,7 @@ static int64_t TraceRows(const Scene* sc, const TptoParams* p, int start, int en
     float invWidth = 1.0f / p->width;
     float invHeight = 1.0f / p->height;
     float lerpFac = (float)p->frame / (float)(p->frame + 1);
-    if (p->flags & TPTO_FLAG_ANIMATE) lerpFac *= 0.9f; /* DO_ANIMATE_SMOOTHING, Config.h:23 */
+    if (p->flags & TPTO_FLAG_ANIMATE) lerpFac *= p->has_animate_smoothing ? p->animate_smoothing : 0.9f; /* DO_ANIMATE_SMOOTHING, Config.h:23 */
     if (!(p->flags & TPTO_FLAG_PROGRESSIVE)) lerpFac = 0;
     int64_t rayCount = 0;
     for (uint32_t y = (uint32_t)start; y < (uint32_t)end; ++y) {
@@ -358,6 +364,8 @@ int64_t tpto_render(const TptoSphere* spheres, const TptoMaterial* mats, int cou
     sc->cam = cam;
     sc->math_mode = p->math_mode;
     sc->fold_mode = p->fold_mode;
+    sc->no_light_sampling = p->no_light_sampling;
+    sc->mitsuba_compare = p->mitsuba_compare;
     float* soa = (float*)malloc(sizeof(float) * 5 * (size_t)(count > 0 ? count : 1));
     sc->cx = soa; sc->cy = soa + count; sc->cz = soa + 2 * count; sc->sqR = soa + 3 * count; sc->invR = soa + 4 * count;
     for (int i = 0; i < count; ++i) { /* Test.cpp:321-339 */

@@ -42,6 +42,12 @@ typedef struct {
     unsigned flags;      /* TestFlags */
     int seed_mode, math_mode, fold_mode;
     int threads;         /* <=0: all cores (OpenMP over rows; rows are independent) */
+    /* The reference's remaining compile-time switches (Config.h:23-25), zero = the reference's defaults: */
+    int no_light_sampling;      /* 1: DO_LIGHT_SAMPLING 0 (Test.cpp:95-134 and :209-214 compiled out) */
+    int mitsuba_compare;        /* 1: DO_MITSUBA_COMPARE 1 (metal roughness 0 :143-145, constant sky :226-227; the caller
+                                   passes a camera with aperture 0, :312-313) */
+    int has_animate_smoothing;  /* 1: use animate_smoothing instead of DO_ANIMATE_SMOOTHING 0.9f (Test.cpp:273-274) */
+    float animate_smoothing;
 } TptoParams;
 
 int tpto_default_scene(TptoSphere* spheres, TptoMaterial* mats, int capacity); /* returns 46; Test.cpp:13-31,46-64 */

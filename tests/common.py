@@ -13,6 +13,24 @@ def goldens():
     return json.load(open(os.path.join(HERE, "golden", "goldens.json")))["cases"]
 
 
+def config_goldens():
+    """Golden vectors of the reference's scalar path built with one of Config.h's other switches re-defined."""
+    return json.load(open(os.path.join(HERE, "golden", "goldens.json")))["config_cases"]
+
+
+def config_kwargs(o, case):
+    """What a Config.h variant means for the oracle / the product: keyword arguments for Oracle.render + the camera."""
+    w, h = case["width"], case["height"]
+    v = case["variant"]
+    if v == "nols":
+        return dict(light_sampling=False), o.default_camera(w, h)
+    if v == "mitsuba":  # aperture 0 (Test.cpp:312-313)
+        return dict(mitsuba_compare=True), o.camera((0, 2, 3), (0, 0, 0), (0, 1, 0), 60.0, w / h, 0.0, 3.0)
+    if v == "smooth05":
+        return dict(animate_smoothing=0.5), o.default_camera(w, h)
+    raise KeyError(v)
+
+
 def golden_scene():
     z = np.load(os.path.join(HERE, "golden", "default_scene.npz"))
     return z["spheres"], z["materials"], z["camera_640x360"], z["emissives"]

@@ -67,6 +67,7 @@ def tpt_defaults(tpt):
     tpt.set_scene(None)
     tpt.set_camera(None)
     tpt.set_samples_per_pixel(4)
+    tpt.set_config(True, 0.9, False)
     tpt.set_seed_mode(tpt.SEED_PER_PIXEL)
     tpt.set_fold_mode(tpt.FOLD_RECURSIVE)
     tpt.set_kernel_variant(0, 3, -1)

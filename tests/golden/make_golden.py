@@ -37,6 +37,15 @@ CASES = [
 ]
 
 
+# The reference's other compile-time switches (Config.h:23-25), one scalar-path build each (oracle/build_ref.sh):
+# variant, w, h, spp, frames, flags, time
+CONFIG_CASES = [
+    ("nols", 320, 180, 4, 2, FLAG_PROGRESSIVE, 0.0),                       # DO_LIGHT_SAMPLING 0
+    ("mitsuba", 320, 180, 4, 2, FLAG_PROGRESSIVE, 0.0),                    # DO_MITSUBA_COMPARE 1
+    ("smooth05", 320, 180, 4, 3, FLAG_PROGRESSIVE | FLAG_ANIMATE, 0.75),   # DO_ANIMATE_SMOOTHING 0.5f (moves spheres: last)
+]
+
+
 def main():
     ref = Ref.get("scalar")
     simd = Ref.get("simd")
@@ -55,7 +64,13 @@ def main():
                         mean_rgb=[float(bb[..., c].mean(dtype=np.float64)) for c in range(3)],
                         alpha_max=float(bb[..., 3].max())))
         print(out[-1])
-    json.dump(dict(source="oracle/_ref/libtpt_ref_scalar.so (pristine /root/reference scalar path, g++ -O2 -ffp-contract=off "
+    cfg = []
+    for (variant, w, h, spp, frames, flags, t) in CONFIG_CASES:
+        rays, bb = Ref.get(variant).render_frames(w, h, spp, frames, flags, time=t)
+        cfg.append(dict(variant=variant, width=w, height=h, spp=spp, frames=frames, flags=flags, time=t, rays=int(rays),
+                        fnv="%08x" % fnv1a(bb), mean_rgb=[float(bb[..., c].mean(dtype=np.float64)) for c in range(3)]))
+        print(cfg[-1])
+    json.dump(dict(config_cases=cfg, source="oracle/_ref/libtpt_ref_scalar.so (pristine /root/reference scalar path, g++ -O2 -ffp-contract=off "
                           "-D__EMSCRIPTEN__ -D__EMSCRIPTEN_PTHREADS__); simd_* = oracle/_ref/libtpt_ref.so",
                    cases=out), open(os.path.join(HERE, "goldens.json"), "w"), indent=1)
 

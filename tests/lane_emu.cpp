@@ -11,7 +11,17 @@
 
 using namespace tpt;
 
+static int g_emuConfig = CFG_LIGHT_SAMPLING;
+static float g_emuSmoothing = 0.9f;
+
 extern "C" {
+
+// Config.h:23-25 as run-time switches for the renders that follow (tptSetConfig's twin)
+void emu_set_config(int lightSampling, float animateSmoothing, int mitsubaCompare)
+{
+    g_emuConfig = (lightSampling ? CFG_LIGHT_SAMPLING : 0) | (mitsubaCompare ? CFG_MITSUBA_COMPARE : 0);
+    g_emuSmoothing = animateSmoothing;
+}
 
 // spheres/mats: reference layouts (20 B / 36 B).  cam: 88 B.  Returns ray count.
 int64_t emu_render_ex(const void* spheres, const void* mats, int count, const void* cam, int w, int h, int y0, int y1,
@@ -36,7 +46,7 @@ int64_t emu_render_ex(const void* spheres, const void* mats, int count, const vo
     if (hs == 2) sv.nGroups = 0; // two-phase, brute force even for a large scene
     CameraPOD c;
     memcpy(&c, cam, sizeof(c));
-    FrameConsts fc = makeFrameConsts(c, w, h, spp, frame, flags, seedMode);
+    FrameConsts fc = makeFrameConsts(c, w, h, spp, frame, flags, seedMode, g_emuConfig, g_emuSmoothing);
     f4 stackMem[TPT_MAX_DEPTH];
     BounceStack stack;
     stack.base = stackMem;

@@ -29,7 +29,8 @@ assert SPHERE_DT.itemsize == 20 and MATERIAL_DT.itemsize == 36 and CAMERA_DT.ite
 class Params(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("y0", C.c_int), ("y1", C.c_int), ("spp", C.c_int),
                 ("frame", C.c_int), ("flags", C.c_uint), ("seed_mode", C.c_int), ("math_mode", C.c_int),
-                ("fold_mode", C.c_int), ("threads", C.c_int)]
+                ("fold_mode", C.c_int), ("threads", C.c_int), ("no_light_sampling", C.c_int), ("mitsuba_compare", C.c_int),
+                ("has_animate_smoothing", C.c_int), ("animate_smoothing", C.c_float)]
 
 
 def build_oracle():
@@ -104,11 +105,14 @@ class Oracle:
         return cam
 
     def render(self, spheres, mats, cam, w, h, spp, frame, flags=FLAG_PROGRESSIVE, seed_mode=SEED_ROW_SERIAL,
-               math_mode=MATH_TPT, fold_mode=FOLD_RECURSIVE, backbuffer=None, y0=0, y1=None, threads=0):
+               math_mode=MATH_TPT, fold_mode=FOLD_RECURSIVE, backbuffer=None, y0=0, y1=None, threads=0,
+               light_sampling=True, mitsuba_compare=False, animate_smoothing=None):
         if backbuffer is None:
             backbuffer = np.zeros((h, w, 4), np.float32)
         assert backbuffer.dtype == np.float32 and backbuffer.flags.c_contiguous and backbuffer.size == w * h * 4
-        p = Params(w, h, y0, h if y1 is None else y1, spp, frame, flags, seed_mode, math_mode, fold_mode, threads)
+        p = Params(w, h, y0, h if y1 is None else y1, spp, frame, flags, seed_mode, math_mode, fold_mode, threads,
+                   0 if light_sampling else 1, 1 if mitsuba_compare else 0, 0 if animate_smoothing is None else 1,
+                   0.0 if animate_smoothing is None else float(animate_smoothing))
         rays = self.lib.tpto_render(spheres.ctypes.data, mats.ctypes.data, len(spheres), cam.ctypes.data,
                                     C.byref(p), backbuffer.ctypes.data)
         return int(rays), backbuffer
@@ -130,7 +134,9 @@ class Ref:
     variant: "scalar" (the reference's own scalar path = the parity target), "simd" (as in the repo,
     oracle flags), "fast" (SIMD, -O3 -ffast-math: how the reference ships)."""
     _inst = {}
-    FILES = {"scalar": "libtpt_ref_scalar.so", "simd": "libtpt_ref.so", "fast": "libtpt_ref_fast.so"}
+    FILES = {"scalar": "libtpt_ref_scalar.so", "simd": "libtpt_ref.so", "fast": "libtpt_ref_fast.so",
+             # scalar path with one of Config.h's other switches re-defined (oracle/build_ref.sh)
+             "nols": "libtpt_ref_nols.so", "mitsuba": "libtpt_ref_mitsuba.so", "smooth05": "libtpt_ref_smooth05.so"}
 
     @classmethod
     def available(cls, variant="scalar"):

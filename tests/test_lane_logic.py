@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from common import oracle_frames
+from common import config_goldens, config_kwargs, oracle_frames
 from oracle_lib import CAMERA_DT, FLAG_PROGRESSIVE, MATERIAL_DT, SPHERE_DT, ROOT
 
 HS = {"two_phase": 0, "simple": 1}
@@ -204,3 +204,25 @@ def test_matrix_filter_mask_layout(emu, oracle):
     assert (masks & np.uint64((1 << 18) - 1)).max() == 0  # bits of spheres 46..63 never set
     counts = np.array([bin(int(x)).count("1") for x in masks[:2000]])
     assert counts.mean() < 6  # a filter, not a pass-through
+
+
+@pytest.mark.parametrize("case", config_goldens(), ids=lambda c: c["variant"])
+def test_config_switches_reproduce_reference_variants(emu, oracle, case):
+    """DO_LIGHT_SAMPLING 0 / DO_MITSUBA_COMPARE 1 / DO_ANIMATE_SMOOTHING 0.5f as run-time switches of the lane logic
+    (tptSetConfig): in the reference's own seed mode the lane logic reproduces the golden hash of the reference's scalar
+    path compiled with that macro re-defined."""
+    import ctypes as C
+    from oracle_lib import fnv1a
+    emu.emu_set_config.argtypes = [C.c_int, C.c_float, C.c_int]
+    emu.emu_set_config.restype = None
+    kw, cam = config_kwargs(oracle, case)
+    emu.emu_set_config(1 if kw.get("light_sampling", True) else 0, kw.get("animate_smoothing", 0.9), 1 if kw.get("mitsuba_compare") else 0)
+    try:
+        s, m = oracle.default_scene()
+        if case["flags"] & 1:
+            s = s.copy()
+            oracle.animate(s, case["time"])
+        rays, bb = emu_frames(emu, s, m, cam, case["width"], case["height"], case["spp"], case["frames"], case["flags"], 0, 0, 0)
+        assert rays == case["rays"] and "%08x" % fnv1a(bb) == case["fnv"]
+    finally:
+        emu.emu_set_config(1, 0.9, 0)

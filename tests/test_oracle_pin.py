@@ -4,7 +4,7 @@ present, live bit-for-bit comparison."""
 import numpy as np
 import pytest
 
-from common import goldens, golden_scene, oracle_frames
+from common import config_goldens, config_kwargs, goldens, golden_scene, oracle_frames
 from oracle_lib import (FLAG_PROGRESSIVE, FOLD_FORWARD, FOLD_RECURSIVE, MATH_LIBM, MATH_TPT, SEED_PER_PIXEL,
                         SEED_ROW_SERIAL, fnv1a)
 
@@ -21,6 +21,17 @@ def test_oracle_reproduces_reference_goldens(oracle, case, math_mode):
     assert float(bb[..., 3].max()) == 0.0  # alpha never written (Maths.h:38)
     for c in range(3):
         assert abs(float(bb[..., c].mean(dtype=np.float64)) - case["mean_rgb"][c]) < 1e-12
+
+
+@pytest.mark.parametrize("case", config_goldens(), ids=lambda c: c["variant"])
+def test_oracle_config_switches_match_reference_variants(oracle, case):
+    """DO_LIGHT_SAMPLING 0, DO_MITSUBA_COMPARE 1, DO_ANIMATE_SMOOTHING 0.5f (Config.h:23-25): the oracle's run-time switches
+    against the reference's scalar path compiled with the macro re-defined (oracle/build_ref.sh)."""
+    kw, cam = config_kwargs(oracle, case)
+    rays, bb, _ = oracle_frames(oracle, case["width"], case["height"], case["spp"], case["frames"], case["flags"], case["time"],
+                                cam=cam, seed_mode=SEED_ROW_SERIAL, math_mode=MATH_LIBM, **kw)
+    assert rays == case["rays"]
+    assert "%08x" % fnv1a(bb) == case["fnv"]
 
 
 def test_scalar_and_simd_reference_agree_on_static_scenes():

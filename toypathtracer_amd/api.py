@@ -34,7 +34,7 @@ _lib = None
 # every symbol include/tpt_hip.h declares (checked by tests/test_abi.py)
 C_ABI_SYMBOLS = [
     "tptInitialize", "tptShutdown", "tptUpdate", "tptDraw", "tptGetObjectCount", "tptGetSceneDesc",
-    "tptSetSamplesPerPixel", "tptSetSeedMode", "tptSetFoldMode", "tptSetScene", "tptSetCamera", "tptSetStream",
+    "tptSetSamplesPerPixel", "tptSetConfig", "tptSetSeedMode", "tptSetFoldMode", "tptSetScene", "tptSetCamera", "tptSetStream",
     "tptSetRowShard", "tptLocalRowCount", "tptLocalRowToGlobal", "tptDrawDevice", "tptRayCounterRead", "tptSetRayCounter", "tptSetFrameOverlap", "tptDisplayRGBA8", "tptKernelTimingBegin", "tptKernelTimingEnd",
     "tptSynchronize", "tptTimerBegin", "tptTimerEnd", "tptSetKernelVariant", "tptTestMath", "tptTestHitSpheres",
     "tptCommGetUniqueId", "tptCommInit", "tptCommDestroy", "tptDrawSharded", "tptShardedFinish", "tptGetLaunchInfo", "tptGetPipelineInfo", "tptSetHostBufferMode", "tptSetHostLookahead", "tptTestMatrixFilter", "tptSetTileMirror", "tptGetLastError", "tptGetDeviceName", "tptDebugStats", "tptDebugChunkOrder",
@@ -73,7 +73,7 @@ def load_library():
         "tptInitialize": [], "tptShutdown": [], "tptUpdate": [f, i, i, i, u],
         "tptDraw": [f, i, i, i, p, C.POINTER(i), u],
         "tptGetObjectCount": [C.POINTER(i)] * 4, "tptGetSceneDesc": [p, p, p, p, C.POINTER(i)],
-        "tptSetSamplesPerPixel": [i], "tptSetSeedMode": [i], "tptSetFoldMode": [i], "tptSetScene": [p, p, i],
+        "tptSetSamplesPerPixel": [i], "tptSetConfig": [i, f, i], "tptSetSeedMode": [i], "tptSetFoldMode": [i], "tptSetScene": [p, p, i],
         "tptSetCamera": [p, p, f, f, f], "tptSetStream": [p], "tptSetRowShard": [i, i, i], "tptLocalRowCount": [i],
         "tptLocalRowToGlobal": [i], "tptDrawDevice": [f, i, i, i, p, u], "tptRayCounterRead": [C.POINTER(C.c_int64)],
         "tptSetRayCounter": [p], "tptSetTileMirror": [p, p], "tptSetFrameOverlap": [i], "tptDisplayRGBA8": [p, i, i, p], "tptKernelTimingBegin": [i],
@@ -140,6 +140,10 @@ def GetSceneDesc():
 # ---------------------------------------------------------------- run-time knobs / device path
 def set_samples_per_pixel(spp):
     _chk(load_library().tptSetSamplesPerPixel(spp), "tptSetSamplesPerPixel")
+
+
+def set_config(light_sampling=True, animate_smoothing=0.9, mitsuba_compare=False):
+    _chk(load_library().tptSetConfig(1 if light_sampling else 0, animate_smoothing, 1 if mitsuba_compare else 0), "tptSetConfig")
 
 
 def set_seed_mode(mode):

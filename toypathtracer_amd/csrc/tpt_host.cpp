@@ -78,6 +78,8 @@ struct Context {
 
     // run-time versions of the reference's compile-time switches
     int spp = 4;                     // DO_SAMPLES_PER_PIXEL, Config.h:22
+    int config = CFG_LIGHT_SAMPLING; // DO_LIGHT_SAMPLING 1, DO_MITSUBA_COMPARE 0, Config.h:24-25
+    float animateSmoothing = 0.9f;   // DO_ANIMATE_SMOOTHING, Config.h:23
     int seedMode = SEED_PER_PIXEL;
     int foldMode = FOLD_RECURSIVE;
     int allowGroups = 1; // hitSpheres variant 2 = two-phase, brute force even for large scenes
@@ -89,6 +91,7 @@ struct Context {
     int gridDiv = 0;                            // env TPT_GRID_DIV: launch resident/gridDiv workgroups per frame; 0 = adaptive
     unsigned long long oldestPending = 0;       // adaptive grid: oldest frame whose trace kernel may still be running
     int streamDepth = 1, prevInFlight = -1;     // adaptive grid: deepest pipeline the caller has built / in flight at the previous enqueue
+    int depthOverride = 0;                      // > 0: frames that share the machine, known to the caller of enqueueTrace (tptDraw)
     int ldsStackLevels = 6;                     // recursive fold: bounce-stack levels kept in LDS (env TPT_LDS_STACK_LEVELS)
 
     float* mirror = nullptr;                    // tptSetTileMirror: second destination of the resolve kernel
@@ -571,6 +574,13 @@ int tptSetSamplesPerPixel(int spp)
     g.configEpoch++;
     return 0;
 }
+int tptSetConfig(int lightSampling, float animateSmoothing, int mitsubaCompare)
+{
+    g.config = (lightSampling ? CFG_LIGHT_SAMPLING : 0) | (mitsubaCompare ? CFG_MITSUBA_COMPARE : 0);
+    g.animateSmoothing = animateSmoothing;
+    g.configEpoch++;
+    return 0;
+}
 int tptSetSeedMode(int mode)
 {
     if (mode != SEED_ROW_SERIAL && mode != SEED_PER_PIXEL) return fail("tptSetSeedMode: 0 (ROW_SERIAL) or 1 (PER_PIXEL)");
@@ -712,7 +722,9 @@ int tptUpdate(float time, int frameCount, int screenWidth, int screenHeight, uns
         int rc = stageScene();
         if (rc) return rc;
     }
-    g.cam = makeCamera(g.camSetup, float(screenWidth) / float(screenHeight)); // Test.cpp:341
+    CameraSetup cs = g.camSetup;
+    if (g.config & CFG_MITSUBA_COMPARE) cs.aperture = 0.0f; // Test.cpp:312-313
+    g.cam = makeCamera(cs, float(screenWidth) / float(screenHeight)); // Test.cpp:341
     g.updated = true;
     return 0;
 }
@@ -862,6 +874,7 @@ void sizeGrid(FramePlan& P)
         if (inFlight + 1 > g.streamDepth) g.streamDepth = inFlight + 1;
         g.prevInFlight = inFlight;
         int k = g.streamDepth;
+        if (g.depthOverride > 0) k = g.depthOverride; // the host-pointer path knows exactly how deep its pipeline is
         if (k > P.nOverlap) k = P.nOverlap;
         cap = (int)((long long)resident * fill / (100ll * k));
         if (cap > resident) cap = resident;
@@ -1009,7 +1022,7 @@ int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long
     FramePlan P;
     KernelArgs& a = P.a;
     a.scene = deviceView(); // pointers of the set this frame reads; its upload is enqueued below, on the frame's stream
-    a.fc = makeFrameConsts(g.cam, w, h, g.spp, frameCount, testFlags, g.seedMode);
+    a.fc = makeFrameConsts(g.cam, w, h, g.spp, frameCount, testFlags, g.seedMode, g.config, g.animateSmoothing);
     a.nLocalRows = localRows(h);
     if (g.numParts > 1 && g.stripeRows > 0) {
         a.stripeRows = g.stripeRows;
@@ -1225,6 +1238,10 @@ int tptDraw(float time, int frameCount, int w, int h, float* backbuffer, int* ou
     const bool stable = !g.sceneDirty && g.pendingSet < 0 && !(testFlags & TPT_FLAG_ANIMATE);
 
     // ---- 1. this frame's trace: traced ahead by an earlier call, or now
+    struct DepthScope { // launches made from here share the machine with the frames traced ahead, not with a deep device-path pipeline
+        explicit DepthScope(int d) { g.depthOverride = d; }
+        ~DepthScope() { g.depthOverride = 0; }
+    } depthScope(pipelined && stable ? 1 + (g.lookahead < 3 ? g.lookahead : 3) : 1);
     TraceTicket T;
     int raySlot = -1;
     Context::Ahead& front = g.ahead[0];

@@ -357,7 +357,8 @@ inline SceneView viewOf(const PackedScene& P)
     return sv;
 }
 
-inline FrameConsts makeFrameConsts(const CameraPOD& cam, int w, int h, int spp, int frame, unsigned flags, int seedMode)
+inline FrameConsts makeFrameConsts(const CameraPOD& cam, int w, int h, int spp, int frame, unsigned flags, int seedMode,
+                                   int config = CFG_LIGHT_SAMPLING, float animateSmoothing = 0.9f)
 {
     FrameConsts fc;
     fc.cam = cam;
@@ -368,11 +369,12 @@ inline FrameConsts makeFrameConsts(const CameraPOD& cam, int w, int h, int spp, 
     fc.invWidth = 1.0f / w;   // Test.cpp:270
     fc.invHeight = 1.0f / h;  // Test.cpp:271
     float lerpFac = float(frame) / float(frame + 1); // Test.cpp:272
-    if (flags & 1u) lerpFac *= 0.9f;                 // kFlagAnimate * DO_ANIMATE_SMOOTHING, Test.cpp:273-274
+    if (flags & 1u) lerpFac *= animateSmoothing;     // kFlagAnimate * DO_ANIMATE_SMOOTHING (Config.h:23: 0.9f), Test.cpp:273-274
     if (!(flags & 2u)) lerpFac = 0;                  // !kFlagProgressive, Test.cpp:275-276
     fc.lerpFac = lerpFac;
     fc.invSpp = 1.0f / float(spp); // Test.cpp:291
     fc.seedMode = seedMode;
+    fc.config = config;
     return fc;
 }
 

@@ -91,7 +91,9 @@ struct FrameConsts {
     float lerpFac;  // Test.cpp:272-276, computed on the host
     float invSpp;   // 1.0f / float(spp), Test.cpp:291
     int seedMode;
+    int config;     // CFG_* bits: the reference's compile-time switches Config.h:24-25 at run time
 };
+enum { CFG_LIGHT_SAMPLING = 1, CFG_MITSUBA_COMPARE = 2 }; // DO_LIGHT_SAMPLING (default on), DO_MITSUBA_COMPARE (default off)
 
 TPT_HD f3 ld3(const float* p) { return mk3(p[0], p[1], p[2]); }
 
@@ -683,7 +685,7 @@ TPT_HD bool lanePost(Lane& L, const int id, const float t, const SceneView& sv, 
         lightLoop = true;
     } else if (id < 0) {
         TPT_STAT(ST_SKY);
-        term = sky(L.dir); // Test.cpp:229-231
+        term = (fc.config & CFG_MITSUBA_COMPARE) ? mk3(0.15f, 0.21f, 0.3f) : sky(L.dir); // Test.cpp:226-231
         finish = true;
     } else {
         // ---- hit: finish HitSpheres (Maths.cpp:195-197), then Scatter (Test.cpp:83-193)
@@ -706,13 +708,14 @@ TPT_HD bool lanePost(Lane& L, const int id, const float t, const SceneView& sv, 
             L.lightE = mk3(0, 0, 0);
             L.matE = L.doMatE ? matE : mk3(0, 0, 0); // Test.cpp:210
             L.hitId = id;
-            L.j = 0;
+            L.j = (fc.config & CFG_LIGHT_SAMPLING) ? 0 : sv.nLights; // Test.cpp:95: the light loop is compiled out without it
             L.orig = pos;
             lightLoop = true;
         } else if (type == MAT_METAL) { // Test.cpp:137-150
             TPT_STAT(ST_METAL);
             f3 refl = reflect(L.dir, normal);
-            newDir = normalize(refl + m1.w * randomInUnitSphere(L.rng));
+            const float roughness = (fc.config & CFG_MITSUBA_COMPARE) ? 0.0f : m1.w; // Test.cpp:143-145 (the samples are drawn either way)
+            newDir = normalize(refl + roughness * randomInUnitSphere(L.rng));
             if (dot(newDir, normal) > 0) {
                 bounce = true;
                 atten = albedo;
@@ -793,7 +796,7 @@ TPT_HD bool lanePost(Lane& L, const int id, const float t, const SceneView& sv, 
     if (bounce) {
         TPT_STAT(ST_BOUNCE);
         if (L.hitType == MAT_LAMBERT) bounceE = bounceE + L.lightE; // matE + lightE (lightE == 0 otherwise)
-        L.doMatE = (L.hitType != MAT_LAMBERT);
+        L.doMatE = (L.hitType != MAT_LAMBERT) || !(fc.config & CFG_LIGHT_SAMPLING); // Test.cpp:209-214: only with light sampling
         if (FOLD == FOLD_FORWARD) {
             L.radiance = L.radiance + L.throughput * bounceE;
             L.throughput = L.throughput * atten;

@@ -91,6 +91,7 @@ struct Context {
     int gridDiv = 0;                            // env TPT_GRID_DIV: launch resident/gridDiv workgroups per frame; 0 = adaptive
     unsigned long long oldestPending = 0;       // adaptive grid: oldest frame whose trace kernel may still be running
     int streamDepth = 1, prevInFlight = -1;     // adaptive grid: deepest pipeline the caller has built / in flight at the previous enqueue
+    int framesSinceIdle = 0;                    // adaptive grid: frames enqueued since one found the pipeline empty
     int depthOverride = 0;                      // > 0: frames that share the machine, known to the caller of enqueueTrace (tptDraw)
     int ldsStackLevels = 6;                     // recursive fold: bounce-stack levels kept in LDS (env TPT_LDS_STACK_LEVELS)
 
@@ -831,6 +832,8 @@ int chooseKernel(FramePlan& P)
     return 0;
 }
 
+const int kBurstFrames = 24; // frames after an idle pipeline that are launched with burst-sized grids (sizeGrid)
+
 // Work items, chunk size and the number of workgroups of this launch.
 void sizeGrid(FramePlan& P)
 {
@@ -862,7 +865,12 @@ void sizeGrid(FramePlan& P)
     if (g.gridDiv > 0) {
         cap = resident / g.gridDiv;
     } else {
-        const int fill = g.gridFill > 0 ? g.gridFill : (g.numParts > 1 ? 100 : 200);
+        // fill = how many times the machine the launches in flight ask for together.  200 % is best for a long stream
+        // (64 workgroups per launch at 16 in flight: long steady states, 37.6 vs 34.9 Gray/s); a SHORT burst is dominated
+        // by its end, when the last launches have the machine to themselves -- there 400 % (128 workgroups) wins (31.2 vs
+        // 30.0 Gray/s for 20 frames).  The first frames after the pipeline ran empty are launched as a burst, the rest as
+        // a stream.  100 % when the frame is sharded over ranks (oversubscription buys nothing on small tiles).
+        const int fill = g.gridFill > 0 ? g.gridFill : (g.numParts > 1 ? 100 : (g.framesSinceIdle < kBurstFrames ? 400 : 200));
         // k = how many launches share the machine.  Not just what is in flight right now: a caller that streams frames
         // (enqueue, enqueue, ..., synchronise once) starts every burst with an empty pipeline, and whole-machine grids
         // for the first frames of a burst serialise them (each with its own tail) -- a 20-frame burst ran at 24 instead
@@ -870,6 +878,7 @@ void sizeGrid(FramePlan& P)
         // when two consecutive frames find the pipeline empty: that is a caller who synchronises every frame
         // (the reference's DrawTest contract) and gets the whole machine.
         const int inFlight = framesInFlight(P.nSlots);
+        g.framesSinceIdle = inFlight == 0 ? 0 : g.framesSinceIdle + 1;
         if (inFlight == 0 && g.prevInFlight == 0) g.streamDepth = 1;
         if (inFlight + 1 > g.streamDepth) g.streamDepth = inFlight + 1;
         g.prevInFlight = inFlight;

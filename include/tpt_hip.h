@@ -156,6 +156,10 @@ int tptSynchronize(void);
 #define TPT_COMM_ID_BYTES 128
 int tptCommGetUniqueId(void* outId128);
 int tptCommInit(const void* id128, int nRanks, int rank, int stripeRows);
+/* Measurement aid, no RCCL: this process plays rank 0 of an nRanks-way run alone -- same tile, snapshot ring, events and
+ * assemble kernel, a device copy of its own slice in place of the gather (the other ranks' rows of the image stay zero).
+ * Shows what one GPU sustains as rank 0 of N (bench.py --emulate-ranks N).  Paired with tptCommDestroy like tptCommInit. */
+int tptCommInitLoopback(int nRanks, int stripeRows);
 int tptCommDestroy(void);
 int tptDrawSharded(float time, int frameCount, int screenWidth, int screenHeight, float* deviceImageOnRoot, unsigned testFlags);
 /* waits for every exchange enqueued so far; rank 0: total rays of all ranks as of the last frame, other ranks: their own */

@@ -311,3 +311,31 @@ def test_draw_sharded_in_process_single_rank(tpt_defaults, oracle):
             assert rays == ro and img.cpu().numpy().tobytes() == bo.tobytes(), (w, h)
     finally:
         tpt.comm_destroy()
+
+
+@pytest.mark.parametrize("n", [2, 4])
+def test_loopback_rank0_of_n_matches_its_rows(tpt_defaults, oracle, n):
+    """tptCommInitLoopback: this GPU as rank 0 of n.  Rank 0's stripes of the assembled image (and only those) carry the
+    1-GPU render's bytes; the other ranks' rows stay zero; at n > 2 the pipeline runs 8 deep."""
+    import numpy as np
+    import torch
+    from common import oracle_frames
+    tpt = tpt_defaults
+    w, h, frames, stripe = 200, 120, 20, 8
+    tpt.comm_init_loopback(n, stripe)
+    try:
+        assert tpt.pipeline_info()["overlap_effective"] == (16 if n <= 2 else 8)
+        img = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        for f in range(frames):
+            tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+            tpt.draw_sharded(0.0, f, w, h, img.data_ptr(), FLAG_PROGRESSIVE)
+        tpt.sharded_finish()
+        got = img.cpu().numpy()
+    finally:
+        tpt.comm_destroy()
+    assert tpt.pipeline_info()["overlap_effective"] == 16
+    _, bo, _ = oracle_frames(oracle, w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
+    want = np.frombuffer(bo.tobytes(), np.float32).reshape(h, w, 4)
+    mine = (np.arange(h) // stripe) % n == 0
+    assert got[mine].tobytes() == want[mine].tobytes()
+    assert not got[~mine].any()

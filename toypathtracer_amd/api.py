@@ -37,7 +37,7 @@ C_ABI_SYMBOLS = [
     "tptSetSamplesPerPixel", "tptSetConfig", "tptSetSeedMode", "tptSetFoldMode", "tptSetScene", "tptSetCamera", "tptSetStream",
     "tptSetRowShard", "tptLocalRowCount", "tptLocalRowToGlobal", "tptDrawDevice", "tptRayCounterRead", "tptSetRayCounter", "tptSetFrameOverlap", "tptDisplayRGBA8", "tptKernelTimingBegin", "tptKernelTimingEnd",
     "tptSynchronize", "tptTimerBegin", "tptTimerEnd", "tptSetKernelVariant", "tptTestMath", "tptTestHitSpheres",
-    "tptCommGetUniqueId", "tptCommInit", "tptCommDestroy", "tptDrawSharded", "tptShardedFinish", "tptGetLaunchInfo", "tptGetPipelineInfo", "tptSetHostBufferMode", "tptSetHostLookahead", "tptTestMatrixFilter", "tptSetTileMirror", "tptGetLastError", "tptGetDeviceName", "tptDebugStats", "tptDebugChunkOrder",
+    "tptCommGetUniqueId", "tptCommInit", "tptCommInitLoopback", "tptCommDestroy", "tptDrawSharded", "tptShardedFinish", "tptGetLaunchInfo", "tptGetPipelineInfo", "tptSetHostBufferMode", "tptSetHostLookahead", "tptTestMatrixFilter", "tptSetTileMirror", "tptGetLastError", "tptGetDeviceName", "tptDebugStats", "tptDebugChunkOrder",
 ]
 # the reference's own C++ symbols (nm of the compiled Test.cpp), exported for link-level drop-in
 CXX_ABI_SYMBOLS = [
@@ -79,7 +79,7 @@ def load_library():
         "tptSetRayCounter": [p], "tptSetTileMirror": [p, p], "tptSetFrameOverlap": [i], "tptDisplayRGBA8": [p, i, i, p], "tptKernelTimingBegin": [i],
         "tptKernelTimingEnd": [C.POINTER(f), C.POINTER(i)],
         "tptSynchronize": [], "tptTimerBegin": [], "tptTimerEnd": [C.POINTER(f)], "tptSetKernelVariant": [i, i, i],
-        "tptDebugStats": [p, i], "tptDebugChunkOrder": [p, p, i], "tptTestMath": [i, p, p, p, i], "tptTestHitSpheres": [i, p, p, p, i], "tptTestMatrixFilter": [p, p, i], "tptGetLaunchInfo": [C.POINTER(i)] * 4, "tptGetPipelineInfo": [C.POINTER(i)] * 4, "tptCommGetUniqueId": [p], "tptCommInit": [p, i, i, i], "tptCommDestroy": [], "tptDrawSharded": [f, i, i, i, p, u], "tptShardedFinish": [C.POINTER(C.c_int64)], "tptSetHostBufferMode": [i], "tptSetHostLookahead": [i],
+        "tptDebugStats": [p, i], "tptDebugChunkOrder": [p, p, i], "tptTestMath": [i, p, p, p, i], "tptTestHitSpheres": [i, p, p, p, i], "tptTestMatrixFilter": [p, p, i], "tptGetLaunchInfo": [C.POINTER(i)] * 4, "tptGetPipelineInfo": [C.POINTER(i)] * 4, "tptCommGetUniqueId": [p], "tptCommInit": [p, i, i, i], "tptCommInitLoopback": [i, i], "tptCommDestroy": [], "tptDrawSharded": [f, i, i, i, p, u], "tptShardedFinish": [C.POINTER(C.c_int64)], "tptSetHostBufferMode": [i], "tptSetHostLookahead": [i],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -278,6 +278,11 @@ def comm_get_unique_id():
 
 def comm_init(unique_id, n_ranks, rank, stripe_rows=8):
     _chk(load_library().tptCommInit(C.c_char_p(unique_id), n_ranks, rank, stripe_rows), "tptCommInit")
+
+
+def comm_init_loopback(n_ranks, stripe_rows=8):
+    """Measurement aid: play rank 0 of an n_ranks-way sharded run alone (device copy in place of the gather)."""
+    _chk(load_library().tptCommInitLoopback(n_ranks, stripe_rows), "tptCommInitLoopback")
 
 
 def comm_destroy():

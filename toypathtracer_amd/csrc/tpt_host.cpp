@@ -13,6 +13,7 @@
 #include "tpt_device.h"
 #include "tpt_scene.h"
 #include <hip/hip_runtime.h>
+#include <thread>
 #include <rccl/rccl.h> // types and prototypes only: the library is dlopen()ed when tptCommInit is called
 #include <chrono>
 #include <dlfcn.h>
@@ -143,6 +144,7 @@ struct Context {
         static const int kRing = 4;     // send snapshots: a gather may trail the renderer by this many frames
         void* lib = nullptr;            // librccl, loaded on first use (no link-time dependency: a single-GPU host never needs it)
         ncclComm_t comm = nullptr;
+        bool active = false, loopback = false; // loopback: rank 0 of nRanks with a device copy in place of the gather (tptCommInitLoopback)
         int nRanks = 0, rank = 0, stripeRows = 8;
         int w = 0, h = 0, padRows = 0;
         hipStream_t commStream = nullptr;
@@ -168,6 +170,9 @@ struct Context {
     bool resolveRecorded[kMaxSlots] = {};
     f4* dColour[kMaxSlots] = {};
     int hwQueues = 0, overlapCap = kMaxOverlap; // measured at tptInitialize (probeHardwareQueues)
+    int hostPace = 1;                           // env TPT_HOST_PACE=0: let the host run ahead of the pipeline (enqueueTrace)
+    int shardCapOverride = 0;                   // env TPT_SHARD_CAP: frames in flight for tiles sharded over > 2 parts (default 8)
+    int shardOverlapCap = kMaxOverlap;          // 8 while the frame is sharded over more than two parts (tptSetRowShard)
     unsigned long long frameSeq = 0;
 
     // per-launch timing of the trace kernel: hipEvent pairs on the stream each launch goes to
@@ -487,6 +492,8 @@ int tptInitialize(void)
     if (g.spheres.empty()) defaultScene(g.spheres, g.mats);
     if (const char* e1 = getenv("TPT_MAX_BLOCKS_PER_CU")) g.maxBlocksPerCU = atoi(e1);
     if (const char* e6 = getenv("TPT_GRID_FILL")) g.gridFill = atoi(e6);
+    if (const char* e7 = getenv("TPT_HOST_PACE")) g.hostPace = atoi(e7);
+    if (const char* e8 = getenv("TPT_SHARD_CAP")) g.shardCapOverride = atoi(e8);
     if (const char* e5 = getenv("TPT_GRID_DIV")) g.gridDiv = atoi(e5) > 0 ? atoi(e5) : 0;
     if (const char* e2 = getenv("TPT_CHUNK")) g.chunkOverride = atoi(e2);
     if (const char* e4 = getenv("TPT_COST_ORDER")) g.costOrder = atoi(e4);
@@ -630,19 +637,37 @@ int tptKernelTimingEnd(float* outSumMs, int* outLaunches)
     return 0;
 }
 
-int tptSetFrameOverlap(int frames)
+namespace {
+// Everything enqueued so far completes; the slot bookkeeping starts afresh (the number of slots is about to change).
+int drainPipeline()
 {
-    if (frames < 1 || frames > Context::kMaxOverlap) return fail("tptSetFrameOverlap: 1..16");
     if (g.inited) {
         if (discardLookahead()) return -2;
         HIPCHK(hipStreamSynchronize(g.stream));
         for (int k = 0; k < Context::kMaxOverlap; ++k)
             if (g.traceStream[k]) HIPCHK(hipStreamSynchronize(g.traceStream[k]));
     }
-    g.overlap = frames;
-    g.oldestPending = g.frameSeq; // everything enqueued so far has completed (synchronised above)
+    g.oldestPending = g.frameSeq;
     g.streamDepth = 1; g.prevInFlight = -1;
     for (int k = 0; k < Context::kMaxSlots; ++k) g.resolveRecorded[k] = false;
+    return 0;
+}
+// frames in flight: what the caller asked for, what the hardware queues carry, and what the tile size rewards
+int effectiveOverlap()
+{
+    int n = g.overlap < 1 ? 1 : (g.overlap > Context::kMaxOverlap ? Context::kMaxOverlap : g.overlap);
+    if (n > g.overlapCap) n = g.overlapCap;
+    if (n > g.shardOverlapCap) n = g.shardOverlapCap;
+    return n;
+}
+} // namespace
+
+int tptSetFrameOverlap(int frames)
+{
+    if (frames < 1 || frames > Context::kMaxOverlap) return fail("tptSetFrameOverlap: 1..16");
+    int rc = drainPipeline();
+    if (rc) return rc;
+    g.overlap = frames;
     return 0;
 }
 
@@ -697,11 +722,21 @@ int tptSetCamera(const float* lookFrom, const float* lookAt, float vfov, float a
 int tptSetRowShard(int stripeRows, int numParts, int part)
 {
     g.configEpoch++;
-    if (numParts <= 1 || stripeRows <= 0) {
+    const bool sharded = numParts > 1 && stripeRows > 0;
+    if (sharded && (part < 0 || part >= numParts)) return fail("tptSetRowShard: part out of range");
+    // Tiles of a quarter frame and less are small enough that every further launch in flight costs more queue latency
+    // than its overlap buys (one-GPU emulation of rank 0, C2: 16 in flight 29 / 39 Gray/s aggregate at 4 / 8 ranks, 8 in
+    // flight 92 / 99; profiles/r02/r02_run36.log).
+    const int cap = sharded && numParts > 2 ? (g.shardCapOverride > 0 ? g.shardCapOverride : 8) : Context::kMaxOverlap;
+    if (cap != g.shardOverlapCap) {
+        int rc = drainPipeline();
+        if (rc) return rc;
+        g.shardOverlapCap = cap;
+    }
+    if (!sharded) {
         g.stripeRows = 0; g.numParts = 1; g.part = 0;
         return 0;
     }
-    if (part < 0 || part >= numParts) return fail("tptSetRowShard: part out of range");
     g.stripeRows = stripeRows; g.numParts = numParts; g.part = part;
     return 0;
 }
@@ -1047,8 +1082,7 @@ int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long
     a.tilesX = (w + 7) / 8;
     const int tilesY = (a.nLocalRows + 7) / 8;
     a.numItems = g.seedMode == SEED_ROW_SERIAL ? a.nLocalRows : a.tilesX * tilesY * 64;
-    P.nOverlap = g.overlap < 1 ? 1 : (g.overlap > Context::kMaxOverlap ? Context::kMaxOverlap : g.overlap);
-    if (P.nOverlap > g.overlapCap) P.nOverlap = g.overlapCap; // what the hardware queues granted to this process can carry
+    P.nOverlap = effectiveOverlap();
     P.nSlots = P.nOverlap;
     P.slot = (int)(g.frameSeq % (unsigned long long)P.nSlots);
     g.frameSeq++;
@@ -1068,6 +1102,16 @@ int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long
     const bool pipelined = P.nOverlap > 1;
     hipStream_t ts = pipelined ? g.traceStream[slot % P.nOverlap] : g.stream;
     if (pipelined && g.resolveRecorded[slot]) {
+        // Host pacing: the caller's thread waits here until the slot's previous frame has been blended, so it never runs more
+        // than nSlots frames ahead and the queue's barrier below is already satisfied when the command processor reaches it.
+        // A host that runs far ahead leaves every queue with an unsatisfied barrier at its head, and the command processor
+        // polls them all: small frames retire at half the rate (C1, 400 frames: 6.7 -> 13.6 Gray/s; rank 0 of 8: 99 -> 128
+        // aggregate; C2 unchanged; profiles/r02/r02_run40.log).  Pacing only: the stream wait below is what orders the work
+        // (an event query may report "done" early on a re-recorded event).
+        if (g.hostPace) {
+            while (hipEventQuery(g.evResolve[slot]) == hipErrorNotReady) std::this_thread::yield();
+            (void)hipGetLastError();
+        }
         HIPCHK(hipStreamWaitEvent(ts, g.evResolve[slot], 0)); // colour buffer free again
     }
     if ((rc = enqueueSceneUpload(ts))) return rc; // behind the wait above: nobody reads the set being replaced any more
@@ -1239,7 +1283,7 @@ int tptDraw(float time, int frameCount, int w, int h, float* backbuffer, int* ou
         g.tileSrc = nullptr;
     }
     const bool sharded = g.numParts > 1 && g.stripeRows > 0;
-    const bool pipelined = (g.overlap < g.overlapCap ? g.overlap : g.overlapCap) > 1;
+    const bool pipelined = effectiveOverlap() > 1;
     // What a traced frame depends on besides (frameCount, w, h, flags): scene, camera, spp, seed / fold mode, kernel variant,
     // sharding.  Every call that changes one of them bumps configEpoch; a pending scene change (tptSetScene, kFlagAnimate)
     // shows as sceneDirty / a pending scene set.
@@ -1274,7 +1318,7 @@ int tptDraw(float time, int frameCount, int w, int h, float* backbuffer, int* ou
         int nextFrame = have ? g.ahead[have - 1].frameCount + 1 : frameCount + 1;
         // every frame traced but not yet blended holds a slot (its colour buffer): this one plus the ones ahead must leave
         // one slot spare, whatever the hardware-queue probe clamped the pipeline to
-        const int nSlots = g.overlap < g.overlapCap ? g.overlap : g.overlapCap;
+        const int nSlots = effectiveOverlap();
         const int maxAhead = g.lookahead < nSlots - 2 ? g.lookahead : nSlots - 2;
         while (have < maxAhead) {
             Context::Ahead& A = g.ahead[have];
@@ -1449,16 +1493,10 @@ int tptCommGetUniqueId(void* out128)
     return 0;
 }
 
-int tptCommInit(const void* id128, int nRanks, int rank, int stripeRows)
+namespace {
+int startShard(int nRanks, int rank, int stripeRows)
 {
-    if (requireInit()) return -1;
-    if (!id128 || nRanks < 1 || rank < 0 || rank >= nRanks || stripeRows < 1) return fail("tptCommInit: bad arguments");
-    if (g.shard.comm) return fail("tptCommInit: already initialised (tptCommDestroy first)");
-    if (loadRccl()) return -1;
     Context::Shard& S = g.shard;
-    ncclUniqueId id;
-    memcpy(&id, id128, sizeof(id));
-    NCCLCHK(S.CommInitRank(&S.comm, nRanks, id, rank));
     S.nRanks = nRanks; S.rank = rank; S.stripeRows = stripeRows; S.frames = 0;
     HIPCHK(hipStreamCreateWithFlags(&S.commStream, hipStreamNonBlocking));
     for (int k = 0; k < Context::Shard::kRing; ++k) {
@@ -1466,19 +1504,48 @@ int tptCommInit(const void* id128, int nRanks, int rank, int stripeRows)
         HIPCHK(hipEventCreateWithFlags(&S.evSent[k], kOrderingEvent));
         S.sentRecorded[k] = false;
     }
+    S.active = true;
     return tptSetRowShard(stripeRows, nRanks, rank);
+}
+} // namespace
+
+int tptCommInit(const void* id128, int nRanks, int rank, int stripeRows)
+{
+    if (requireInit()) return -1;
+    if (!id128 || nRanks < 1 || rank < 0 || rank >= nRanks || stripeRows < 1) return fail("tptCommInit: bad arguments");
+    if (g.shard.active) return fail("tptCommInit: already initialised (tptCommDestroy first)");
+    if (loadRccl()) return -1;
+    Context::Shard& S = g.shard;
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    NCCLCHK(S.CommInitRank(&S.comm, nRanks, id, rank));
+    S.loopback = false;
+    return startShard(nRanks, rank, stripeRows);
+}
+
+// Measurement aid: this process plays rank 0 of an nRanks-way sharded run on its own -- same tile, snapshot ring, events and
+// assemble kernel as tptCommInit, a device copy of rank 0's slice standing in for the gather (the other ranks' rows stay
+// zero).  What one GPU sustains as rank 0, RCCL apart; tools/shard_exchange_emu.py, bench.py --emulate-ranks.
+int tptCommInitLoopback(int nRanks, int stripeRows)
+{
+    if (requireInit()) return -1;
+    if (nRanks < 1 || stripeRows < 1) return fail("tptCommInitLoopback: bad arguments");
+    if (g.shard.active) return fail("tptCommInitLoopback: already initialised (tptCommDestroy first)");
+    g.shard.loopback = true;
+    return startShard(nRanks, 0, stripeRows);
 }
 
 int tptCommDestroy(void)
 {
     Context::Shard& S = g.shard;
-    if (!S.comm) return 0;
+    if (!S.active) return 0;
     (void)discardLookahead();
     if (g.stream) (void)hipStreamSynchronize(g.stream);
     (void)releaseShardBuffers();
     (void)tptSetTileMirror(nullptr, nullptr);
-    NCCLCHK(S.CommDestroy(S.comm));
+    if (S.comm) NCCLCHK(S.CommDestroy(S.comm));
     S.comm = nullptr;
+    S.active = S.loopback = false;
     for (int k = 0; k < Context::Shard::kRing; ++k) {
         if (S.evSnap[k]) (void)hipEventDestroy(S.evSnap[k]);
         if (S.evSent[k]) (void)hipEventDestroy(S.evSent[k]);
@@ -1496,7 +1563,7 @@ int tptDrawSharded(float time, int frameCount, int w, int h, float* deviceImageO
 {
     if (requireInit()) return -1;
     Context::Shard& S = g.shard;
-    if (!S.comm) return fail("tptDrawSharded: call tptCommInit first");
+    if (!S.active) return fail("tptDrawSharded: call tptCommInit first");
     if (w <= 0 || h <= 0) return fail("tptDrawSharded: bad size");
     if (S.rank == 0 && !deviceImageOnRoot) return fail("tptDrawSharded: rank 0 needs the image buffer");
     if (w != S.w || h != S.h) { // (re)allocate for this frame size: every rank the same padded tile height
@@ -1512,7 +1579,11 @@ int tptDrawSharded(float time, int frameCount, int w, int h, float* deviceImageO
             HIPCHK(hipMalloc(reinterpret_cast<void**>(&S.send[k]), rowBytes * (size_t)(S.padRows + 1)));
             HIPCHK(hipMemsetAsync(S.send[k], 0, rowBytes * (size_t)(S.padRows + 1), g.stream));
         }
-        if (S.rank == 0) HIPCHK(hipMalloc(reinterpret_cast<void**>(&S.gathered), rowBytes * (size_t)(S.padRows + 1) * (size_t)S.nRanks));
+        if (S.rank == 0) {
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&S.gathered), rowBytes * (size_t)(S.padRows + 1) * (size_t)S.nRanks));
+            HIPCHK(hipMemsetAsync(S.gathered, 0, rowBytes * (size_t)(S.padRows + 1) * (size_t)S.nRanks, g.stream));
+            HIPCHK(hipStreamSynchronize(g.stream)); // the communication stream writes it next
+        }
         S.w = w; S.h = h;
     }
     const int k = (int)(S.frames % Context::Shard::kRing);
@@ -1526,7 +1597,8 @@ int tptDrawSharded(float time, int frameCount, int w, int h, float* deviceImageO
     HIPCHK(hipEventRecord(S.evSnap[k], g.stream));
     HIPCHK(hipStreamWaitEvent(S.commStream, S.evSnap[k], 0));
     const size_t count = (size_t)(S.padRows + 1) * w * 4;
-    NCCLCHK(S.Gather(S.send[k], S.gathered, count, ncclFloat32, 0, S.comm, S.commStream));
+    if (S.loopback) HIPCHK(hipMemcpyAsync(S.gathered, S.send[k], count * sizeof(float), hipMemcpyDeviceToDevice, S.commStream));
+    else NCCLCHK(S.Gather(S.send[k], S.gathered, count, ncclFloat32, 0, S.comm, S.commStream));
     if (S.rank == 0) HIPCHK(tptLaunchAssemble(S.gathered, deviceImageOnRoot, w, h, S.stripeRows, S.nRanks, S.padRows, S.commStream));
     HIPCHK(hipEventRecord(S.evSent[k], S.commStream));
     S.sentRecorded[k] = true;
@@ -1539,7 +1611,7 @@ int tptShardedFinish(int64_t* outTotalRays)
 {
     if (requireInit()) return -1;
     Context::Shard& S = g.shard;
-    if (!S.comm) return fail("tptShardedFinish: call tptCommInit first");
+    if (!S.active) return fail("tptShardedFinish: call tptCommInit first");
     HIPCHK(hipStreamSynchronize(g.stream));
     HIPCHK(hipStreamSynchronize(S.commStream));
     long long total = 0;
@@ -1568,7 +1640,7 @@ int tptShardedFinish(int64_t* outTotalRays)
 int tptGetPipelineInfo(int* outHwQueues, int* outOverlapEffective, int* outStreamDepth, int* outSlotReservations)
 {
     if (outHwQueues) *outHwQueues = g.hwQueues;
-    if (outOverlapEffective) *outOverlapEffective = g.overlap < g.overlapCap ? g.overlap : g.overlapCap;
+    if (outOverlapEffective) *outOverlapEffective = effectiveOverlap();
     if (outStreamDepth) *outStreamDepth = g.streamDepth;
     if (outSlotReservations) *outSlotReservations = g.slotReservations;
     return 0;

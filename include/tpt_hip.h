@@ -162,7 +162,9 @@ int tptCommInit(const void* id128, int nRanks, int rank, int stripeRows);
 int tptCommInitLoopback(int nRanks, int stripeRows);
 int tptCommDestroy(void);
 int tptDrawSharded(float time, int frameCount, int screenWidth, int screenHeight, float* deviceImageOnRoot, unsigned testFlags);
-/* waits for every exchange enqueued so far; rank 0: total rays of all ranks as of the last frame, other ranks: their own */
+/* waits for every exchange enqueued so far; rank 0: sum of all ranks' ray counters as of the last gathered frame, other
+ * ranks: their own.  Counters are running totals since tptInitialize / tptSetRayCounter (before the first sharded frame:
+ * this rank's own running total), so callers take differences. */
 int tptShardedFinish(int64_t* outTotalRays);
 
 /* hipEvent bracket on the context's stream, for kernel-only timing (as the reference times its

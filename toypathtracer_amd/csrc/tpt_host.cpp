@@ -36,7 +36,7 @@ struct TraceTicket {
 
 struct Context {
     static const int kMaxOverlap = 16;              // frames in flight (trace streams, colour buffers, ...): one hardware queue each
-    static const int kMaxSlots = kMaxOverlap;       // frame slots (colour / stack / path buffers, events)
+    static const int kMaxSlots = 2 * kMaxOverlap;   // frame slots (colour buffers, events): a frame holds its slot from trace to blend
     static const int kOrderTables = kMaxSlots + 2;  // rotating chunk-order tables: more than frames in flight
     bool inited = false;
     int device = 0, numCUs = 0;
@@ -170,6 +170,7 @@ struct Context {
     bool resolveRecorded[kMaxSlots] = {};
     f4* dColour[kMaxSlots] = {};
     int hwQueues = 0, overlapCap = kMaxOverlap; // measured at tptInitialize (probeHardwareQueues)
+    int slotFactor = 2;                         // colour slots per trace stream (env TPT_SLOT_FACTOR; enqueueTrace)
     int hostPace = 1;                           // env TPT_HOST_PACE=0: let the host run ahead of the pipeline (enqueueTrace)
     int shardCapOverride = 0;                   // env TPT_SHARD_CAP: frames in flight for tiles sharded over > 2 parts (default 8)
     int shardOverlapCap = kMaxOverlap;          // 8 while the frame is sharded over more than two parts (tptSetRowShard)
@@ -264,14 +265,26 @@ int stageScene()
     // only ever waits when the host has run more than 16 animated frames ahead of the GPU
     if (S.copyEnqueued && !S.copyDone) HIPCHK(hipEventSynchronize(S.evUploaded));
     if (total > S.cap) {
+        // Grow EVERY set of the ring at once (one drain now instead of one per first use of a set: an animated scene would
+        // otherwise synchronise the device on each of its first kSceneSets frames).  The set in use keeps its contents.
         HIPCHK(hipDeviceSynchronize());
-        if (S.dev) HIPCHK(hipFree(S.dev));
-        if (S.stage) HIPCHK(hipHostFree(S.stage));
-        S.dev = nullptr; S.stage = nullptr; S.cap = 0;
         const size_t cap = total < 4096 ? 4096 : total + total / 4;
-        HIPCHK(hipMalloc(reinterpret_cast<void**>(&S.dev), cap));
-        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&S.stage), cap, hipHostMallocDefault));
-        S.cap = cap;
+        const bool growAll = cap <= (8u << 20); // (a huge scene is rarely animated: its sets grow as they are first used)
+        for (int k = 0; k < Context::kSceneSets; ++k) {
+            Context::SceneSet& Q = g.sets[k];
+            if (Q.cap >= cap || (!growAll && &Q != &S)) continue;
+            char *dev = nullptr, *stage = nullptr;
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&dev), cap));
+            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&stage), cap, hipHostMallocDefault));
+            if (k == g.curSet && Q.dev && Q.bytes) { // frames still to be enqueued may read it without a new upload
+                HIPCHK(hipMemcpy(dev, Q.dev, Q.bytes, hipMemcpyDeviceToDevice));
+                memcpy(stage, Q.stage, Q.bytes);
+            }
+            if (Q.dev) HIPCHK(hipFree(Q.dev));
+            if (Q.stage) HIPCHK(hipHostFree(Q.stage));
+            Q.dev = dev; Q.stage = stage; Q.cap = cap;
+            Q.copyEnqueued = false; Q.copyDone = true; // (everything has completed: synchronised above)
+        }
     }
     memcpy(S.stage, P.pairs.data(), bPairs);
     memcpy(S.stage + offSph4, P.sph4.data(), bSph4);
@@ -493,6 +506,7 @@ int tptInitialize(void)
     if (const char* e1 = getenv("TPT_MAX_BLOCKS_PER_CU")) g.maxBlocksPerCU = atoi(e1);
     if (const char* e6 = getenv("TPT_GRID_FILL")) g.gridFill = atoi(e6);
     if (const char* e7 = getenv("TPT_HOST_PACE")) g.hostPace = atoi(e7);
+    if (const char* e9 = getenv("TPT_SLOT_FACTOR")) g.slotFactor = atoi(e9) >= 2 ? 2 : 1;
     if (const char* e8 = getenv("TPT_SHARD_CAP")) g.shardCapOverride = atoi(e8);
     if (const char* e5 = getenv("TPT_GRID_DIV")) g.gridDiv = atoi(e5) > 0 ? atoi(e5) : 0;
     if (const char* e2 = getenv("TPT_CHUNK")) g.chunkOverride = atoi(e2);
@@ -788,7 +802,7 @@ struct FramePlan {
 // earlier frame did; it synchronises everything once.
 int syncAllStreams();
 int reserveSlotBuffers(int nSlots, size_t colourBytes, size_t stackBytes, size_t pathBytes)
-{
+{ // (stack / path buffers are used while the kernel runs only: indexed by stream, allocated for the first kMaxOverlap slots)
     if (nSlots <= g.slotsReserved && colourBytes <= g.colourCap && stackBytes <= g.stackCap && pathBytes <= g.pathCap) return 0;
     int rc = syncAllStreams();
     if (rc) return rc;
@@ -805,12 +819,12 @@ int reserveSlotBuffers(int nSlots, size_t colourBytes, size_t stackBytes, size_t
         if (fresh || sb > g.stackCap) {
             if (g.dStack[k]) HIPCHK(hipFree(g.dStack[k]));
             g.dStack[k] = nullptr;
-            if (sb) HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dStack[k]), sb));
+            if (sb && k < Context::kMaxOverlap) HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dStack[k]), sb));
         }
         if (fresh || pb > g.pathCap) {
             if (g.dPath[k]) HIPCHK(hipFree(g.dPath[k]));
             g.dPath[k] = nullptr;
-            if (pb) HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dPath[k]), pb));
+            if (pb && k < Context::kMaxOverlap) HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dPath[k]), pb));
         }
     }
     g.colourCap = cb; g.stackCap = sb; g.pathCap = pb; g.slotsReserved = n;
@@ -963,7 +977,7 @@ int ensureFrameBuffers(FramePlan& P, int w)
     a.stackBuf = nullptr;
     a.stackStride = 0;
     if (needStack) {
-        a.stackBuf = g.dStack[slot];
+        a.stackBuf = g.dStack[slot % P.nOverlap];
         a.stackStride = P.queued ? P.blocks * tptQueuePathsPerBlock() : P.blocks * P.threadsPerBlock;
     }
     a.pathBuf = nullptr;
@@ -1083,7 +1097,14 @@ int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long
     const int tilesY = (a.nLocalRows + 7) / 8;
     a.numItems = g.seedMode == SEED_ROW_SERIAL ? a.nLocalRows : a.tilesX * tilesY * 64;
     P.nOverlap = effectiveOverlap();
+    // Twice as many colour slots as trace streams: the blends are ordered (frame f after f - 1) but the trace kernels finish
+    // out of order (4.0-8.3 ms at C2), so with one slot per stream a stream whose kernel finished early sits idle until
+    // every earlier frame has been blended -- a third of each stream's time.  With a spare slot the stream's next kernel
+    // starts at once and the blend of the finished frame happens whenever its turn comes.  (Unless the colour buffers of
+    // a huge frame would take more than 32 GB.)
     P.nSlots = P.nOverlap;
+    if (P.nOverlap > 1 && g.slotFactor > 1 && (size_t)a.nLocalRows * (size_t)w * sizeof(f4) * (size_t)(2 * P.nOverlap) <= (32ull << 30))
+        P.nSlots = 2 * P.nOverlap;
     P.slot = (int)(g.frameSeq % (unsigned long long)P.nSlots);
     g.frameSeq++;
 
@@ -1615,8 +1636,11 @@ int tptShardedFinish(int64_t* outTotalRays)
     HIPCHK(hipStreamSynchronize(g.stream));
     HIPCHK(hipStreamSynchronize(S.commStream));
     long long total = 0;
-    if (S.frames == 0 || !S.w) {
-        if (outTotalRays) *outTotalRays = 0;
+    if (S.frames == 0 || !S.w) { // nothing gathered yet: this rank's own running total (the other ranks' are not known here)
+        int64_t own = 0;
+        int rc = tptRayCounterRead(&own);
+        if (rc) return rc;
+        if (outTotalRays) *outTotalRays = own;
         return 0;
     }
     const size_t rowBytes = (size_t)S.w * 4 * sizeof(float);

@@ -1097,14 +1097,14 @@ int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long
     const int tilesY = (a.nLocalRows + 7) / 8;
     a.numItems = g.seedMode == SEED_ROW_SERIAL ? a.nLocalRows : a.tilesX * tilesY * 64;
     P.nOverlap = effectiveOverlap();
-    // Twice as many colour slots as trace streams: the blends are ordered (frame f after f - 1) but the trace kernels finish
-    // out of order (4.0-8.3 ms at C2), so with one slot per stream a stream whose kernel finished early sits idle until
-    // every earlier frame has been blended -- a third of each stream's time.  With a spare slot the stream's next kernel
-    // starts at once and the blend of the finished frame happens whenever its turn comes.  (Unless the colour buffers of
-    // a huge frame would take more than 32 GB.)
+    // Twice as many colour slots as trace streams for frames up to 32 MB of colour (2 M pixels): the blends are ordered
+    // (frame f after f - 1) but the trace kernels finish out of order, so with one slot per stream a stream whose kernel
+    // finished early sits idle until every earlier frame has been blended.  With a spare slot its next kernel starts at
+    // once.  Worth +3-8 % on tiles of a sharded C2 frame (rank 0 of 2 / 4 / 8), nothing at C2 on one GPU (the machine is
+    // full either way), and -4 % at C3, where 16 launches of 190 ms running at once only crowd the caches: large frames
+    // keep one slot per stream (profiles/r02/r02_run42.log, r02_evidence2.log).
     P.nSlots = P.nOverlap;
-    if (P.nOverlap > 1 && g.slotFactor > 1 && (size_t)a.nLocalRows * (size_t)w * sizeof(f4) * (size_t)(2 * P.nOverlap) <= (32ull << 30))
-        P.nSlots = 2 * P.nOverlap;
+    if (P.nOverlap > 1 && g.slotFactor > 1 && (size_t)a.nLocalRows * (size_t)w * sizeof(f4) <= (32ull << 20)) P.nSlots = 2 * P.nOverlap;
     P.slot = (int)(g.frameSeq % (unsigned long long)P.nSlots);
     g.frameSeq++;
 

@@ -136,7 +136,10 @@ int tptSetRayCounter(void* deviceU64);
  * `deviceMirror` (same size and layout as the tile) and the current ray-counter value to the 8 bytes at
  * `deviceCounterOut` (may be NULL) -- the snapshot handed to the collective while later frames keep accumulating into
  * the tile -- in the SAME kernel, so the frame's dependency chain stays one kernel long.  NULL turns it off.  The
- * pointers are read at enqueue time; call again to rotate buffers. */
+ * pointers are read at enqueue time; call again to rotate buffers.  The counter written is the context's RUNNING TOTAL at
+ * the moment of the blend, not a per-frame count: with later frames already tracing it includes their rays so far, and
+ * is exact for "all frames up to f" only once nothing later is in flight (the last frame's snapshot after a synchronise,
+ * which is what tptShardedFinish and sharding.finish() read). */
 int tptSetTileMirror(float* deviceMirror, void* deviceCounterOut);
 int tptSynchronize(void);
 

@@ -129,6 +129,25 @@ def drawtest_host_path(api, width, height, frames=24):
     return dt / frames * 1e3, rays / dt / 1e6
 
 
+def batched_rate(api, torch, width, height, per_launch=8, launches=25):
+    """tptDrawDeviceBatch: `per_launch` frames of the static scene per launch (same bits as one launch per frame)."""
+    tile = torch.zeros((height, width, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    api.UpdateTest(0.0, 0, width, height, FLAG_PROGRESSIVE)
+    f = 0
+    for _ in range(16):
+        api.draw_device_batch(0.0, f, per_launch, width, height, tile.data_ptr(), FLAG_PROGRESSIVE)
+        f += per_launch
+    r0 = api.ray_counter_read()  # synchronises
+    t0 = time.perf_counter()
+    for _ in range(launches):
+        api.draw_device_batch(0.0, f, per_launch, width, height, tile.data_ptr(), FLAG_PROGRESSIVE)
+        f += per_launch
+    rays = api.ray_counter_read() - r0
+    dt = time.perf_counter() - t0
+    return dt / (launches * per_launch) * 1e3, rays / dt / 1e6
+
+
 def row_serial_rate(api, width, height, frames=3):
     """ROW_SERIAL seeds: the reference's exact image (one RNG stream per row: one lane per row)."""
     api.set_seed_mode(0)
@@ -157,6 +176,9 @@ def main():
     ap.add_argument("--persistent", type=int, default=3, help="3 path queues (default) 1 persistent waves with lane refill 0 thread-per-pixel 2 lane-sorting")
     ap.add_argument("--fold", type=int, default=0, help="0 recursive (reference order, default) 1 forward")
     ap.add_argument("--lds-scene", type=int, default=-1)
+    ap.add_argument("--batch", type=int, default=1,
+                    help="frames per launch (tptDrawDeviceBatch; sharded: also per exchange).  1 = one launch and one exchange per frame, the "
+                         "reference's own contract and the default; prime / warmup / steps must be multiples of it")
     ap.add_argument("--animate", action="store_true",
                     help="kFlagAnimate: spheres 1 and 8 move every frame (time = frame/60 s), the scene is re-uploaded per frame")
     ap.add_argument("--overlap", type=int, default=0,
@@ -222,7 +244,10 @@ def main():
             sf.begin_frame()
             api.set_tile_mirror(*mirror)
         api.UpdateTest(t, frame, width, height, flags)
-        api.draw_device(t, frame, width, height, tile_ptr, flags)
+        if args.batch > 1:
+            api.draw_device_batch(t, frame, args.batch, width, height, tile_ptr, flags)
+        else:
+            api.draw_device(t, frame, width, height, tile_ptr, flags)
         sf.exchange(snapshot_done=bool(mirror))
 
     def fence():
@@ -235,23 +260,30 @@ def main():
 
     if args.prime < 0:
         args.prime = args.overlap
-    for f in range(args.prime):  # untimed, not part of --warmup either (stated in the JSON line)
+    B = args.batch
+    if B > 1:
+        if args.animate:
+            sys.exit("--batch needs a static scene")
+        args.prime, args.warmup = -(-args.prime // B) * B, -(-args.warmup // B) * B
+        if args.steps % B:
+            sys.exit("--steps must be a multiple of --batch")
+    for f in range(0, args.prime, B):  # untimed, not part of --warmup either (stated in the JSON line)
         step(f)
     fence()
-    for f in range(args.prime, args.prime + args.warmup):
+    for f in range(args.prime, args.prime + args.warmup, B):
         step(f)
     fence()
     rays0 = int(sf.ray_counter.item())
-    api.kernel_timing_begin(args.steps)   # a HIP event pair around every trace launch, on the stream it is launched on
+    api.kernel_timing_begin(args.steps // B)  # a HIP event pair around every trace launch, on the stream it is launched on
     api.timer_begin()                     # + one pair around the whole timed region on the context's stream
     t0 = time.perf_counter()
-    for f in range(args.prime + args.warmup, args.prime + args.warmup + args.steps):
+    for f in range(args.prime + args.warmup, args.prime + args.warmup + args.steps, B):
         step(f)
     pipeline_ms = api.timer_end()         # records + synchronises the end event on the render stream
     fence()
     dt = time.perf_counter() - t0
     launch_ms_sum, launches = api.kernel_timing_end()
-    kernel_ms = launch_ms_sum / max(launches, 1) * args.steps  # = steps x average duration of one trace launch
+    kernel_ms = launch_ms_sum / max(launches, 1) * args.steps  # = steps x average duration of one trace launch (a launch of --batch frames counts once per frame: trace_launch_ms_avg is per LAUNCH)
     rays_local = int(sf.ray_counter.item()) - rays0
     image, _total = sf.finish()
 
@@ -272,8 +304,9 @@ def main():
         #                                                    frame overlap two launches share the GPU, so k_ms ~ 2 x the
         #                                                    pipeline time per frame (p_ms)
         p_ms = pipeline_ms / args.steps
-        px = width * height / world                        # pixels one launch of one rank covers
-        rays_per_launch = rays_total / args.steps / world
+        pl_ms = p_ms * args.batch                          # pipeline time per LAUNCH (= per frame unless --batch)
+        px = width * height / world * args.batch            # pixels one launch of one rank covers (all frames of a batched launch)
+        rays_per_launch = rays_total / args.steps / world * args.batch
         hbm_write_gbs = px * 16 / (k_ms * 1e-3) / 1e9      # 16 B written per pixel
         valu_tflops = rays_per_launch * FLOP_PER_SPHERE_TEST * n_spheres / (k_ms * 1e-3) / 1e12
         traffic = None
@@ -286,7 +319,7 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": label, "width": width, "height": height, "spp": spp, "spheres": n_spheres,
                        "seed_mode": "per_pixel", "fold": "forward" if args.fold else "recursive",
-                       "hit_spheres": ["two_phase" + ("+groups" if n_spheres >= 256 else ""), "simple", "two_phase_brute_force", "two_phase"][args.hit_spheres], "kernel": ["thread_per_pixel", "persistent_waves", "lane_sorting", "path_queues"][args.persistent], "frame_overlap": args.overlap,
+                       "hit_spheres": ["two_phase" + ("+groups" if n_spheres >= 256 else ""), "simple", "two_phase_brute_force", "two_phase"][args.hit_spheres], "kernel": ["thread_per_pixel", "persistent_waves", "lane_sorting", "path_queues"][args.persistent], "frame_overlap": args.overlap, "frames_per_launch": args.batch,
                        "untimed_priming_frames": args.prime,
                        "flags": "progressive|animate" if args.animate else "progressive",
                        "sharding": "none" if world == 1 else "row stripes of %d, round-robin over %d ranks, pipelined gather to rank 0" % (args.stripe_rows, world),
@@ -295,22 +328,22 @@ def main():
             "rays_per_step": rays_total / args.steps,
             "trace_launch_ms_avg": k_ms,
             "pipeline_ms_per_step": p_ms,
-            "pipeline_Mray_s": rays_per_launch * world / (p_ms * 1e-3) / 1e6,
+            "pipeline_Mray_s": rays_per_launch / args.batch * world / (p_ms * 1e-3) / 1e6,
             # roofline.frac is the chip-level figure: the frame's algorithmic bytes over the time a frame occupies the
             # pipeline (ms_per_step measured by HIP events on the render stream) -- up to `frame_overlap` launches share
             # the GPU, so bytes / one launch's own duration (frac_per_launch) understates the chip by that factor
-            "roofline": {"bound": "hbm", "achieved": hbm_write_gbs * k_ms / p_ms, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": hbm_write_gbs * k_ms / p_ms / PEAK_HBM_GBS, "traffic": (traffic or {}).get("bytes_per_launch") if isinstance(traffic, dict) else traffic,
+            "roofline": {"bound": "hbm", "achieved": hbm_write_gbs * k_ms / pl_ms, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": hbm_write_gbs * k_ms / pl_ms / PEAK_HBM_GBS, "traffic": (traffic or {}).get("bytes_per_launch") if isinstance(traffic, dict) else traffic,
                          "traffic_static": True,
                          "traffic_note": ("NOT measured in this run: bytes per trace launch on the L2's fabric side (WRITE_SIZE + 2 x FETCH_SIZE, "
                                           "separate rocprofv3 --pmc passes of this same command, profiles/pmc_traffic.json names the run)"),
                          "achieved_per_launch": hbm_write_gbs, "frac_per_launch": hbm_write_gbs / PEAK_HBM_GBS,
-                         "achieved_read_plus_write": 2 * hbm_write_gbs * k_ms / p_ms, "launch_ms_avg": k_ms, "launches": launches,
+                         "achieved_read_plus_write": 2 * hbm_write_gbs * k_ms / pl_ms, "launch_ms_avg": k_ms, "launches": launches,
                          "note": "north_star's HBM-write roofline (W*H*16 B per frame).  The kernel is FP32-VALU bound (arithmetic "
                                  "intensity ~440 flop/B against a machine balance of ~20): see roofline_valu, the binding one",
                          "kernel": ["tptTraceKernel", "tptTraceKernel", "tptTraceSortedKernel", "tptTraceQueueKernel"][args.persistent]},
-            "roofline_valu": {"bound": "valu_fp32", "achieved": valu_tflops * k_ms / p_ms, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                              "frac": valu_tflops * k_ms / p_ms / PEAK_FP32_TFLOPS,
+            "roofline_valu": {"bound": "valu_fp32", "achieved": valu_tflops * k_ms / pl_ms, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                              "frac": valu_tflops * k_ms / pl_ms / PEAK_FP32_TFLOPS,
                               "achieved_per_launch": valu_tflops, "frac_per_launch": valu_tflops / PEAK_FP32_TFLOPS,
                               "note": "algorithmic flops = rays x 17 flop x spheres (SURVEY 8d: the reference's own per-test count) over the "
                                       "pipeline time per frame; peak counts FMA as 2 flop.  The exact arithmetic (phase 2 of HitSpheres, Scatter) "
@@ -329,6 +362,12 @@ def main():
             out["drawtest_host_note"] = ("synchronous DrawTest(host float* backbuffer) per frame, the reference's own calling contract: backbuffer "
                                          "upload + blend + download over PCIe in every call (default host-buffer mode), the next two frames "
                                          "traced ahead of the caller (tptSetHostLookahead); never the headline value")
+            if args.persistent == 3 and args.hit_spheres != 1 and not args.animate and width * height <= 1280 * 720:
+                for k in (4, 8):
+                    ms, mr = batched_rate(api, torch, width, height, per_launch=k, launches=max(4, 200 // k))
+                    out["batched_%d_ms_per_frame" % k], out["batched_%d_Mray_s" % k] = ms, mr
+                out["batched_note"] = ("tptDrawDeviceBatch: k frames of the static scene per launch, blended in order by one more -- the same bits as "
+                                       "k tptDrawDevice calls; a secondary figure, the headline value is one launch per frame")
             if scene == "default" and width * height <= 1280 * 720:
                 ms, mr = row_serial_rate(api, width, height)
                 out["row_serial_ms"], out["row_serial_Mray_s"] = ms, mr

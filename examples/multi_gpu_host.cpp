@@ -5,7 +5,7 @@
 //
 //   g++ -O2 -I include examples/multi_gpu_host.cpp -L toypathtracer_amd/lib -ltoypathtracer_hip \
 //       -Wl,-rpath,$PWD/toypathtracer_amd/lib -o examples/multi_gpu_host
-//   examples/multi_gpu_host [ranks=1] [width=1280] [height=720] [frames=20] [stripeRows=8]
+//   examples/multi_gpu_host [ranks=1] [width=1280] [height=720] [frames=20] [stripeRows=8] [framesPerLaunch=1]
 //
 // Prints rays, Mray/s and the FNV-1a hash of the final image (rank 0); with the same arguments the hash is the same for
 // every number of ranks (seeds depend on the global pixel position only).
@@ -29,7 +29,7 @@ static void die(const char* what)
     exit(1);
 }
 
-static int runRank(int rank, int ranks, const char* id, int w, int h, int frames, int stripeRows)
+static int runRank(int rank, int ranks, const char* id, int w, int h, int frames, int stripeRows, int batch)
 {
     char dev[16];
     snprintf(dev, sizeof(dev), "%d", rank);
@@ -48,8 +48,10 @@ static int runRank(int rank, int ranks, const char* id, int w, int h, int frames
     int64_t rays0 = 0, rays1 = 0;
     if (tptShardedFinish(&rays0)) die("tptShardedFinish");
     auto t0 = std::chrono::steady_clock::now();
-    for (int f = 0; f < frames; ++f)
-        if (tptUpdate(0.0f, f, w, h, flags) || tptDrawSharded(0.0f, f, w, h, image, flags)) die("tptDrawSharded");
+    for (int f = 0; f < frames; f += batch) { // batch > 1: that many frames per launch and per exchange (same image)
+        const int n = frames - f < batch ? frames - f : batch;
+        if (tptUpdate(0.0f, f, w, h, flags) || tptDrawShardedBatch(0.0f, f, n, w, h, image, flags)) die("tptDrawSharded");
+    }
     if (tptShardedFinish(&rays1)) die("tptShardedFinish");
     const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (rank == 0) {
@@ -68,8 +70,8 @@ static int runRank(int rank, int ranks, const char* id, int w, int h, int frames
 int main(int argc, char** argv)
 {
     const int ranks = argc > 1 ? atoi(argv[1]) : 1, w = argc > 2 ? atoi(argv[2]) : 1280, h = argc > 3 ? atoi(argv[3]) : 720,
-              frames = argc > 4 ? atoi(argv[4]) : 20, stripeRows = argc > 5 ? atoi(argv[5]) : 8;
-    if (ranks < 1 || ranks > 64) return 2;
+              frames = argc > 4 ? atoi(argv[4]) : 20, stripeRows = argc > 5 ? atoi(argv[5]) : 8, batch = argc > 6 ? atoi(argv[6]) : 1;
+    if (ranks < 1 || ranks > 64 || batch < 1 || batch > 32) return 2;
     // children first (they must not inherit an initialised HIP runtime), each with a pipe it reads the id from
     std::vector<int> wr(ranks, -1);
     std::vector<pid_t> pids(ranks, 0);
@@ -86,7 +88,7 @@ int main(int argc, char** argv)
                 if (n <= 0) return 4;
                 got += (size_t)n;
             }
-            return runRank(r, ranks, id, w, h, frames, stripeRows);
+            return runRank(r, ranks, id, w, h, frames, stripeRows, batch);
         }
         close(fd[0]);
         wr[r] = fd[1];
@@ -98,7 +100,7 @@ int main(int argc, char** argv)
         if (write(wr[r], id, sizeof(id)) != (ssize_t)sizeof(id)) return 5;
         close(wr[r]);
     }
-    int rc = runRank(0, ranks, id, w, h, frames, stripeRows);
+    int rc = runRank(0, ranks, id, w, h, frames, stripeRows, batch);
     for (int r = 1; r < ranks; ++r) {
         int st = 0;
         waitpid(pids[r], &st, 0);

@@ -110,6 +110,13 @@ int tptLocalRowToGlobal(int localRow);
  * accumulation buffer stays resident in HBM across frames.  Enqueued on the context's stream;
  * returns immediately.  Ray counts accumulate in a device counter (tptRayCounterRead). */
 int tptDrawDevice(float time, int frameCount, int screenWidth, int screenHeight, float* deviceTile, unsigned testFlags);
+/* Several frames per launch: frames firstFrame .. firstFrame + nFrames - 1 of the scene and camera as of the last tptUpdate
+ * (what the reference's main loop renders while nothing moves: TestWin.cpp:313-316 with kFlagAnimate off), traced by ONE
+ * kernel launch and blended into the tile in frame order by one more.  Bit-identical to nFrames tptDrawDevice calls; a
+ * launch's fixed costs (pool ramp-up and drain, no launch shorter than its longest pixel, queue latencies) are paid once
+ * per batch instead of once per frame -- what bounds small frames and tiles of a sharded frame.  Path-queue kernel only
+ * (the default); frames up to 8192 x 8192; kFlagAnimate is refused (the scene changes every frame). */
+int tptDrawDeviceBatch(float time, int firstFrame, int nFrames, int screenWidth, int screenHeight, float* deviceTile, unsigned testFlags);
 /* Frame pipelining of the asynchronous path: the trace kernels of up to `frames` consecutive tptDrawDevice
  * calls may be in flight at once (each on its own internal stream, writing its own per-frame colour
  * buffer); the progressive blend into the tile (Test.cpp:293-295) is a separate, ordered kernel on the
@@ -165,6 +172,9 @@ int tptCommInit(const void* id128, int nRanks, int rank, int stripeRows);
 int tptCommInitLoopback(int nRanks, int stripeRows);
 int tptCommDestroy(void);
 int tptDrawSharded(float time, int frameCount, int screenWidth, int screenHeight, float* deviceImageOnRoot, unsigned testFlags);
+/* nFrames (1..32) consecutive frames per call, traced by one launch per rank (tptDrawDeviceBatch) and followed by ONE exchange:
+ * rank 0's image is that of the batch's last frame.  Same bits as nFrames tptDrawSharded calls. */
+int tptDrawShardedBatch(float time, int firstFrame, int nFrames, int screenWidth, int screenHeight, float* deviceImageOnRoot, unsigned testFlags);
 /* waits for every exchange enqueued so far; rank 0: sum of all ranks' ray counters as of the last gathered frame, other
  * ranks: their own.  Counters are running totals since tptInitialize / tptSetRayCounter (before the first sharded frame:
  * this rank's own running total), so callers take differences. */

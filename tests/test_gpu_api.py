@@ -243,9 +243,9 @@ def _build_multi_gpu_host(tmp_path):
     return exe
 
 
-def _run_multi_gpu_host(exe, ranks, w, h, frames, stripe):
+def _run_multi_gpu_host(exe, ranks, w, h, frames, stripe, batch=1):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.check_output([exe, str(ranks), str(w), str(h), str(frames), str(stripe)], stderr=subprocess.STDOUT, env=env,
+    out = subprocess.check_output([exe, str(ranks), str(w), str(h), str(frames), str(stripe), str(batch)], stderr=subprocess.STDOUT, env=env,
                                   timeout=300).decode()
     m = re.search(r"(\d+) rays, .* fnv ([0-9a-f]{8})", out)
     assert m, out
@@ -263,6 +263,8 @@ def test_cxx_host_shards_through_the_c_abi_one_rank(oracle, tmp_path):
     rays5, fnv5 = _run_multi_gpu_host(exe, 1, 203, 117, 3, 5)   # ragged: 117 rows in stripes of 5
     ro5, bo5 = oracle.render_frames(203, 117, 4, 3, seed_mode=SEED_PER_PIXEL)
     assert rays5 == ro5 and fnv5 == "%08x" % fnv1a(bo5)
+    raysb, fnvb = _run_multi_gpu_host(exe, 1, w, h, frames, 8, batch=4)   # 4 + 2 frames per launch and exchange: same image
+    assert raysb == ro and fnvb == fnv
 
 
 def test_cxx_host_shards_over_two_gpus(oracle, tmp_path):
@@ -275,6 +277,7 @@ def test_cxx_host_shards_over_two_gpus(oracle, tmp_path):
     rays, fnv = _run_multi_gpu_host(exe, 2, w, h, frames, 8)
     ro, bo = oracle.render_frames(w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
     assert rays == ro and fnv == "%08x" % fnv1a(bo)
+    assert _run_multi_gpu_host(exe, 2, w, h, frames, 8, batch=3) == (rays, fnv)
 
 
 def test_bench_runs_on_two_ranks_over_rccl(tmp_path):
@@ -335,6 +338,33 @@ def test_loopback_rank0_of_n_matches_its_rows(tpt_defaults, oracle, n):
         tpt.comm_destroy()
     assert tpt.pipeline_info()["overlap_effective"] == 16
     _, bo, _ = oracle_frames(oracle, w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
+    want = np.frombuffer(bo.tobytes(), np.float32).reshape(h, w, 4)
+    mine = (np.arange(h) // stripe) % n == 0
+    assert got[mine].tobytes() == want[mine].tobytes()
+    assert not got[~mine].any()
+
+
+def test_sharded_batches_match_per_frame_exchange(tpt_defaults, oracle):
+    """tptDrawShardedBatch on a loopback communicator of 4: rank 0's stripes after batches of 3 + 1 + 4 frames equal the
+    1-GPU render of 8 frames."""
+    import numpy as np
+    import torch
+    from common import oracle_frames
+    tpt = tpt_defaults
+    w, h, stripe, n = 200, 120, 8, 4
+    tpt.comm_init_loopback(n, stripe)
+    try:
+        img = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        f = 0
+        for k in [3, 1, 4]:
+            tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+            tpt.draw_sharded_batch(0.0, f, k, w, h, img.data_ptr(), FLAG_PROGRESSIVE)
+            f += k
+        tpt.sharded_finish()
+        got = img.cpu().numpy()
+    finally:
+        tpt.comm_destroy()
+    _, bo, _ = oracle_frames(oracle, w, h, 4, f, seed_mode=SEED_PER_PIXEL)
     want = np.frombuffer(bo.tobytes(), np.float32).reshape(h, w, 4)
     mine = (np.arange(h) // stripe) % n == 0
     assert got[mine].tobytes() == want[mine].tobytes()

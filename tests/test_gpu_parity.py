@@ -619,3 +619,81 @@ def test_config_switches_on_the_gpu(tpt_defaults, oracle, case):
     finally:
         tpt.set_config(True, 0.9, False)
         tpt.set_scene(None)
+
+
+# ---- several frames per launch (tptDrawDeviceBatch): the same bits as one tptDrawDevice per frame
+def _batched(tpt, w, h, sizes, flags=FLAG_PROGRESSIVE, spp=4):
+    import torch
+    tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    tpt.set_samples_per_pixel(spp)
+    r0 = tpt.ray_counter_read()
+    tpt.UpdateTest(0.0, 0, w, h, flags)
+    f = 0
+    for n in sizes:
+        tpt.draw_device_batch(0.0, f, n, w, h, tile.data_ptr(), flags)
+        f += n
+    rays = tpt.ray_counter_read() - r0
+    return rays, tile.cpu().numpy()
+
+
+@pytest.mark.parametrize("w,h,spp,sizes", [(200, 120, 4, [3, 1, 4, 2]), (67, 41, 3, [5, 5]), (320, 180, 1, [32, 1, 7]), (64, 64, 16, [2, 2])],
+                         ids=["200x120", "ragged", "max-batch", "spp16"])
+def test_batched_launch_is_bit_identical(tpt_defaults, oracle, w, h, spp, sizes):
+    rays, got = _batched(tpt_defaults, w, h, sizes, spp=spp)
+    ro, bo, _ = oracle_frames(oracle, w, h, spp, sum(sizes), seed_mode=SEED_PER_PIXEL)
+    assert rays == ro
+    assert got.tobytes() == bo.tobytes()
+
+
+def test_batched_launch_without_progressive_flag(tpt_defaults, oracle):
+    """lerpFac = 0 for every frame of the batch: the tile ends up as the last frame alone (Test.cpp:275-276)."""
+    w, h, sizes = 160, 96, [4, 3]
+    rays, got = _batched(tpt_defaults, w, h, sizes, flags=0)
+    ro, bo, _ = oracle_frames(oracle, w, h, 4, sum(sizes), flags=0, seed_mode=SEED_PER_PIXEL)
+    assert rays == ro and got.tobytes() == bo.tobytes()
+
+
+def test_batched_launch_at_config2_and_mixed_with_single_frames(tpt_defaults, oracle):
+    """1280x720x4: frames 0-2 as one batch equal the oracle; then single frames and batches interleaved in a 16-deep pipeline
+    equal the same frames drawn one by one."""
+    import torch
+    tpt = tpt_defaults
+    w, h = 1280, 720
+    rays, got = _batched(tpt, w, h, [3])
+    ro, bo, _ = oracle_frames(oracle, w, h, 4, 3, seed_mode=SEED_PER_PIXEL)
+    assert rays == ro and got.tobytes() == bo.tobytes()
+    a = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    b = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    tpt.UpdateTest(0.0, 0, w, h, FLAG_PROGRESSIVE)
+    r0 = tpt.ray_counter_read()
+    f = 0
+    for n in [1, 4, 1, 1, 8, 2, 1, 6]:
+        if n == 1:
+            tpt.draw_device(0.0, f, w, h, a.data_ptr(), FLAG_PROGRESSIVE)
+        else:
+            tpt.draw_device_batch(0.0, f, n, w, h, a.data_ptr(), FLAG_PROGRESSIVE)
+        f += n
+    r1 = tpt.ray_counter_read()
+    for g in range(f):
+        tpt.draw_device(0.0, g, w, h, b.data_ptr(), FLAG_PROGRESSIVE)
+    r2 = tpt.ray_counter_read()
+    assert r1 - r0 == r2 - r1
+    assert a.cpu().numpy().tobytes() == b.cpu().numpy().tobytes()
+
+
+def test_batched_launch_refuses_what_it_cannot_do(tpt_defaults):
+    import torch
+    tpt = tpt_defaults
+    w, h = 64, 64
+    tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    tpt.UpdateTest(0.0, 0, w, h, FLAG_PROGRESSIVE)
+    with pytest.raises(RuntimeError, match="animated"):
+        tpt.draw_device_batch(0.0, 0, 2, w, h, tile.data_ptr(), FLAG_PROGRESSIVE | FLAG_ANIMATE)
+    tpt.set_kernel_variant(0, 1, -1)  # lane-refill kernel
+    with pytest.raises(RuntimeError, match="path-queue"):
+        tpt.draw_device_batch(0.0, 0, 2, w, h, tile.data_ptr(), FLAG_PROGRESSIVE)
+    tpt.draw_device_batch(0.0, 0, 1, w, h, tile.data_ptr(), FLAG_PROGRESSIVE)  # a batch of one is a plain frame
+    tpt.set_kernel_variant(0, 3, -1)
+    tpt.synchronize()

@@ -10,6 +10,8 @@ from toypathtracer_amd import api
 api.InitializeTest()
 w, h = [int(v) for v in os.environ.get("TPT_EMU_SIZE", "1280x720").split("x")]
 frames, warm = int(os.environ.get("TPT_EMU_FRAMES", "300")), 40
+batch = int(os.environ.get("TPT_EMU_BATCH", "1"))  # frames per launch and per exchange (tptDrawShardedBatch)
+frames -= frames % batch; warm -= warm % batch
 image = torch.zeros(h, w, 4, dtype=torch.float32, device="cuda")
 torch.cuda.synchronize()
 base = None
@@ -17,20 +19,20 @@ for n in [int(v) for v in os.environ.get("TPT_EMU_N", "1,2,4,8").split(",")]:
     api.comm_init_loopback(n, 8)
     if os.environ.get("TPT_EMU_OV"):
         api.set_frame_overlap(int(os.environ["TPT_EMU_OV"]))
-    for f in range(warm):
+    for f in range(0, warm, batch):
         api.UpdateTest(0.0, f, w, h, 2)
-        api.draw_sharded(0.0, f, w, h, image.data_ptr(), 2)
+        api.draw_sharded_batch(0.0, f, batch, w, h, image.data_ptr(), 2)
     r0 = api.sharded_finish()
     t0 = time.perf_counter()
-    for f in range(warm, warm + frames):
+    for f in range(warm, warm + frames, batch):
         api.UpdateTest(0.0, f, w, h, 2)
-        api.draw_sharded(0.0, f, w, h, image.data_ptr(), 2)
+        api.draw_sharded_batch(0.0, f, batch, w, h, image.data_ptr(), 2)
     t_enq = time.perf_counter() - t0
     rays = api.sharded_finish() - r0
     dt = time.perf_counter() - t0
     agg = rays / dt / 1e9 * n
     base = base or agg
-    print("N=%d: %.3f ms/frame  rank 0 %.2f Gray/s  aggregate %.1f Gray/s  efficiency %.0f %%  (in flight %d; host enqueue %.3f ms/frame)" % (
-        n, dt / frames * 1e3, rays / dt / 1e9, agg, 100 * agg / (base * n), api.pipeline_info()["overlap_effective"], t_enq / frames * 1e3), flush=True)
+    print("N=%d: %.3f ms/frame  rank 0 %.2f Gray/s  aggregate %.1f Gray/s  efficiency %.0f %%  (batch %d; in flight %d; host enqueue %.3f ms/frame)" % (
+        n, dt / frames * 1e3, rays / dt / 1e9, agg, 100 * agg / (base * n), batch, api.pipeline_info()["overlap_effective"], t_enq / frames * 1e3), flush=True)
     api.comm_destroy()
 api.ShutdownTest()

@@ -22,6 +22,10 @@ struct KernelArgs {
     int tilesX;     // 8x8 tiles per row of tiles
     int numItems;   // pixels incl. tile padding (PER_PIXEL) or rows (ROW_SERIAL)
     int numChunks, chunkSize;
+    // Batched launch (path-queue kernel, tptDrawDeviceBatch): the launch traces batchFrames consecutive frames of the same
+    // scene and camera -- chunk c belongs to frame fc.frame + c / chunksPerFrame -- and writes their colour planes one
+    // after the other into frameColour (framePlane pixels apart).  1 = a single frame (chunksPerFrame == numChunks).
+    int batchFrames, chunksPerFrame, framePlane;
     unsigned totalWaves;
     // FOLD_RECURSIVE bounce stack: the first ldsStackLevels levels live in LDS (per thread), deeper ones in
     // stackBuf [TPT_MAX_DEPTH - ldsStackLevels][stackStride] (global, one column per thread of the launch).
@@ -56,6 +60,9 @@ hipError_t tptLaunchDisplay(const float* tile, unsigned char* rgba, int width, i
 hipError_t tptLaunchAssemble(const float* gathered, float* image, int width, int height, int stripeRows, int nRanks, int padRows, hipStream_t stream);
 hipError_t tptLaunchQueueProbe(unsigned long long ticks, hipStream_t stream);
 hipError_t tptLaunchChunkOrder(const unsigned* cost, unsigned* snap, unsigned* order, int numChunks, hipStream_t stream);
+struct tptLerpTable { float v[32]; }; // lerp factor of each frame of a batch (Test.cpp:272-276), by value in the kernel arguments
+hipError_t tptLaunchResolveBatch(float* tile, const tpt::f4* frameColour, int nPixels, int planeStride, int nFrames, const tptLerpTable& lerp,
+                                 float* mirror, unsigned long long* rayCounter, unsigned long long* counterOut, hipStream_t stream);
 hipError_t tptLaunchResolve(float* tile, const tpt::f4* frameColour, int nPixels, float lerpFac, float* mirror,
                             unsigned long long* rayCounter, unsigned long long* counterOut, const unsigned long long* frameRays, hipStream_t stream);
 hipError_t tptLaunchMathTest(int op, const float* a, const float* b, float* out, int n, hipStream_t stream);

@@ -27,11 +27,14 @@ using namespace tpt;
 namespace {
 
 // What a trace launch leaves behind for the blend that follows it (now, or -- host path with look-ahead -- later).
+const int kMaxBatch = 32; // frames per batched launch (tptDrawDeviceBatch): 6 bits in the path record, 32 lerp factors by value
 struct TraceTicket {
     int slot = 0, nPixels = 0;
     bool pipelined = false, valid = false;
     float lerpFac = 0;
     const f4* colour = nullptr;
+    int batch = 1;           // frames traced by the launch; their colour planes lie nPixels apart
+    tptLerpTable lerp = {};  // batch > 1: each frame's lerp factor
 };
 
 struct Context {
@@ -792,6 +795,7 @@ struct FramePlan {
     int occ = 0, threadsPerBlock = 0, blocks = 0;
     int nOverlap = 1;           // launches that may run side by side (trace streams in use)
     int nSlots = 1, slot = 0;   // frames that may be enqueued ahead / this frame's slot (colour, stack, path buffers, events)
+    int batch = 1;              // frames traced by this launch (tptDrawDeviceBatch)
 };
 
 // Per-slot device buffers (frame colour, bounce stacks, path colour sums) are allocated for ALL slots of the pipeline at
@@ -905,6 +909,8 @@ void sizeGrid(FramePlan& P)
     if (P.queued) chunk = 64; // the path-queue kernel accounts its pixel pools in 64-pixel chunks
     a.chunkSize = chunk;
     a.numChunks = (a.numItems + chunk - 1) / chunk;
+    a.chunksPerFrame = a.numChunks;
+    a.numChunks *= P.batch; // a batched launch hands out the chunks of all its frames, frame after frame
     int blocks = (a.numChunks + wavesPerBlock - 1) / wavesPerBlock;
     // Frames in flight share the machine: with k trace kernels side by side each one gets fill / k of the resident
     // workgroups -- its pools then stay in steady state longer before they drain, and the launches behind it fill the
@@ -954,7 +960,7 @@ int maxGridBlocks(const FramePlan& P)
     const int wavesPerBlock = P.threadsPerBlock / 64;
     const int resident = g.numCUs * P.occ;
     const int minChunk = P.rowSerial ? 1 : 64;
-    const int byWork = ((a.numItems + minChunk - 1) / minChunk + wavesPerBlock - 1) / wavesPerBlock;
+    const int byWork = (((a.numItems + minChunk - 1) / minChunk) * P.batch + wavesPerBlock - 1) / wavesPerBlock;
     int m = resident < byWork ? resident : byWork;
     return m < 1 ? 1 : m;
 }
@@ -969,7 +975,7 @@ int ensureFrameBuffers(FramePlan& P, int w)
     const size_t maxColumns = (size_t)maxBlocks * (size_t)(P.queued ? tptQueuePathsPerBlock() : P.threadsPerBlock);
     const size_t stackBytes = needStack ? maxColumns * (size_t)(TPT_MAX_DEPTH - a.ldsStackLevels) * sizeof(f4) : 0;
     const size_t pathBytes = 0; // (the path-queue kernel's per-path colour sums moved into LDS)
-    int rc = reserveSlotBuffers(P.nSlots, (size_t)a.nLocalRows * w * sizeof(f4), stackBytes, pathBytes);
+    int rc = reserveSlotBuffers(P.nSlots, (size_t)a.nLocalRows * w * sizeof(f4) * (size_t)P.batch, stackBytes, pathBytes);
     if (rc) return rc;
     a.frameColour = g.dColour[slot];
     a.work = g.dWork + 16 * slot;
@@ -1071,7 +1077,7 @@ namespace {
 
 // First half of a frame: plan, buffers, trace kernel on the slot's stream.  `frameRays`: where the kernel adds its ray
 // count (the context's counter, or a per-slot one for frames that are traced ahead of their DrawTest call).
-int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long long* frameRays, TraceTicket& T)
+int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long long* frameRays, TraceTicket& T, int batch = 1)
 {
     if (g.sceneDirty || (g.curSet < 0 && g.pendingSet < 0)) { // tptSetScene after the last tptUpdate
         int rc = stageScene();
@@ -1096,6 +1102,10 @@ int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long
     a.tilesX = (w + 7) / 8;
     const int tilesY = (a.nLocalRows + 7) / 8;
     a.numItems = g.seedMode == SEED_ROW_SERIAL ? a.nLocalRows : a.tilesX * tilesY * 64;
+    P.batch = batch;
+    a.batchFrames = batch;
+    a.framePlane = a.nLocalRows * w;
+    a.chunksPerFrame = 0; // (sizeGrid)
     P.nOverlap = effectiveOverlap();
     // Twice as many colour slots as trace streams for frames up to 32 MB of colour (2 M pixels): the blends are ordered
     // (frame f after f - 1) but the trace kernels finish out of order, so with one slot per stream a stream whose kernel
@@ -1104,12 +1114,14 @@ int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long
     // full either way), and -4 % at C3, where 16 launches of 190 ms running at once only crowd the caches: large frames
     // keep one slot per stream (profiles/r02/r02_run42.log, r02_evidence2.log).
     P.nSlots = P.nOverlap;
-    if (P.nOverlap > 1 && g.slotFactor > 1 && (size_t)a.nLocalRows * (size_t)w * sizeof(f4) <= (32ull << 20)) P.nSlots = 2 * P.nOverlap;
+    if (P.nOverlap > 1 && g.slotFactor > 1 && (size_t)a.nLocalRows * (size_t)w * sizeof(f4) * (size_t)batch <= (32ull << 20)) P.nSlots = 2 * P.nOverlap;
     P.slot = (int)(g.frameSeq % (unsigned long long)P.nSlots);
     g.frameSeq++;
 
     int rc = chooseKernel(P);
     if (rc) return rc;
+    if (batch > 1 && (!P.queued || w > 8192 || h > 8192))
+        return fail("tptDrawDeviceBatch: needs the path-queue kernel (per-pixel seeds, recursive fold, two-phase HitSpheres) and a frame of at most 8192 x 8192");
     sizeGrid(P);
     if ((rc = ensureFrameBuffers(P, w))) return rc;
     if (frameRays) a.rayCounter = frameRays;
@@ -1156,6 +1168,9 @@ int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long
     T.pipelined = pipelined;
     T.lerpFac = a.fc.lerpFac;
     T.colour = a.frameColour;
+    T.batch = batch;
+    for (int j = 0; j < batch && batch > 1; ++j)
+        T.lerp.v[j] = makeFrameConsts(g.cam, w, h, g.spp, frameCount + j, testFlags, g.seedMode, g.config, g.animateSmoothing).lerpFac;
     T.valid = true;
     return 0;
 }
@@ -1166,7 +1181,10 @@ int enqueueResolve(const TraceTicket& T, float* deviceTile, const unsigned long 
 {
     if (!T.valid) return 0;
     if (T.pipelined) HIPCHK(hipStreamWaitEvent(g.stream, g.evTrace[T.slot], 0));
-    HIPCHK(tptLaunchResolve(deviceTile, T.colour, T.nPixels, T.lerpFac, g.mirror, g.dRays, g.mirrorCounter, frameRays, g.stream));
+    if (T.batch > 1)
+        HIPCHK(tptLaunchResolveBatch(deviceTile, T.colour, T.nPixels, T.nPixels, T.batch, T.lerp, g.mirror, g.dRays, g.mirrorCounter, g.stream));
+    else
+        HIPCHK(tptLaunchResolve(deviceTile, T.colour, T.nPixels, T.lerpFac, g.mirror, g.dRays, g.mirrorCounter, frameRays, g.stream));
     if (T.pipelined) {
         HIPCHK(hipEventRecord(g.evResolve[T.slot], g.stream));
         g.resolveRecorded[T.slot] = true;
@@ -1189,6 +1207,27 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
     TraceTicket T;
     if ((rc = enqueueTrace(frameCount, w, h, testFlags, nullptr, T))) return rc;
     return enqueueResolve(T, deviceTile, nullptr);
+}
+
+// nFrames consecutive frames (frameCount = firstFrame ... firstFrame + nFrames - 1) of the scene and camera as of the last
+// tptUpdate, traced by ONE launch and blended in frame order by one: the same bits as nFrames tptDrawDevice calls.
+int tptDrawDeviceBatch(float time, int firstFrame, int nFrames, int w, int h, float* deviceTile, unsigned testFlags)
+{
+    (void)time;
+    if (requireInit()) return -1;
+    if (!g.updated) return fail("tptDrawDeviceBatch: call tptUpdate (UpdateTest) first");
+    if (!deviceTile || w <= 0 || h <= 0 || nFrames < 1) return fail("tptDrawDeviceBatch: bad arguments");
+    if (nFrames > 1 && (testFlags & TPT_FLAG_ANIMATE))
+        return fail("tptDrawDeviceBatch: an animated scene changes every frame (Test.cpp:304-308): one tptUpdate + tptDrawDevice per frame");
+    int rc = discardLookahead();
+    if (rc) return rc;
+    for (int f = 0; f < nFrames; f += kMaxBatch) {
+        const int n = nFrames - f < kMaxBatch ? nFrames - f : kMaxBatch;
+        TraceTicket T;
+        if ((rc = enqueueTrace(firstFrame + f, w, h, testFlags, nullptr, T, n))) return rc;
+        if ((rc = enqueueResolve(T, deviceTile, nullptr))) return rc;
+    }
+    return 0;
 }
 
 int tptRayCounterRead(int64_t* outTotalRays)
@@ -1582,10 +1621,17 @@ int tptCommDestroy(void)
 // device memory, may be NULL elsewhere) holds frame f once tptShardedFinish (or a later call's gather) has completed.
 int tptDrawSharded(float time, int frameCount, int w, int h, float* deviceImageOnRoot, unsigned testFlags)
 {
+    return tptDrawShardedBatch(time, frameCount, 1, w, h, deviceImageOnRoot, testFlags);
+}
+
+// nFrames consecutive frames per rank in one launch (tptDrawDeviceBatch), then ONE exchange: the image on rank 0 is that of
+// the batch's last frame.  Same bits as nFrames tptDrawSharded calls; 1 / nFrames of the launches and gathers.
+int tptDrawShardedBatch(float time, int frameCount, int nFrames, int w, int h, float* deviceImageOnRoot, unsigned testFlags)
+{
     if (requireInit()) return -1;
     Context::Shard& S = g.shard;
     if (!S.active) return fail("tptDrawSharded: call tptCommInit first");
-    if (w <= 0 || h <= 0) return fail("tptDrawSharded: bad size");
+    if (w <= 0 || h <= 0 || nFrames < 1 || nFrames > kMaxBatch) return fail("tptDrawSharded: bad size / batch (1..32 frames)");
     if (S.rank == 0 && !deviceImageOnRoot) return fail("tptDrawSharded: rank 0 needs the image buffer");
     if (w != S.w || h != S.h) { // (re)allocate for this frame size: every rank the same padded tile height
         int rc = releaseShardBuffers();
@@ -1614,7 +1660,7 @@ int tptDrawSharded(float time, int frameCount, int w, int h, float* deviceImageO
     const size_t tileFloats = (size_t)S.padRows * w * 4;
     int rc = tptSetTileMirror(S.send[k], S.send[k] + tileFloats); // blended tile -> snapshot, ray counter -> first 8 bytes of the extra row
     if (rc) return rc;
-    if ((rc = tptDrawDevice(time, frameCount, w, h, S.tile, testFlags))) return rc;
+    if ((rc = nFrames > 1 ? tptDrawDeviceBatch(time, frameCount, nFrames, w, h, S.tile, testFlags) : tptDrawDevice(time, frameCount, w, h, S.tile, testFlags))) return rc;
     HIPCHK(hipEventRecord(S.evSnap[k], g.stream));
     HIPCHK(hipStreamWaitEvent(S.commStream, S.evSnap[k], 0));
     const size_t count = (size_t)(S.padRows + 1) * w * 4;

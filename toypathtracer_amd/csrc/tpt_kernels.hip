@@ -105,6 +105,27 @@ __global__ void __launch_bounds__(256) tptResolveMirrorKernel(float* __restrict_
     mirror[i] = t;
 }
 
+// The blends of a batch of frames (tptDrawDeviceBatch), applied in frame order to each pixel by one launch: exactly the
+// arithmetic of nFrames tptResolveKernel launches (same blendPixel, same order), 1 / nFrames of the launches.
+__global__ void __launch_bounds__(256) tptResolveBatchKernel(float* __restrict__ tile, const f4* __restrict__ colour, int nPixels, int planeStride,
+                                                             int nFrames, tptLerpTable lerp, f4* __restrict__ mirror,
+                                                             const unsigned long long* rayCounter, unsigned long long* counterOut)
+{
+    __builtin_amdgcn_s_setprio(3); // see tptResolveKernel
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0 && counterOut) *counterOut = __hip_atomic_load(rayCounter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (i >= nPixels) return;
+    f4 t = reinterpret_cast<const f4*>(tile)[i];
+    f3 r = mk3(t.x, t.y, t.z);
+    for (int j = 0; j < nFrames; ++j) {
+        const f4 c = colour[(size_t)j * planeStride + i];
+        r = blendPixel(r, mk3(c.x, c.y, c.z), lerp.v[j]);
+    }
+    t.x = r.x; t.y = r.y; t.z = r.z;
+    reinterpret_cast<f4*>(tile)[i] = t;
+    if (mirror) mirror[i] = t;
+}
+
 // Rank 0 of a sharded frame: the gathered tiles [rank][padRows + 1][width] f4 (row stripes dealt round-robin, one extra row
 // per rank whose first 8 bytes carry that rank's ray counter) -> the image [height][width] f4.  HBM-bound copy, one f4 per
 // lane, coalesced on both sides; replaces the per-row joins of DrawTest's task set (Test.cpp:357-361).
@@ -727,7 +748,9 @@ __device__ __forceinline__ void qLoadHot(Lane& L, int& id, const f4* st, int p)
 #ifndef TPT_Q_MAX_VGPR
 #define TPT_Q_MAX_VGPR 60
 #endif
-template <bool LDS_SCENE>
+// BATCH: the launch traces a.batchFrames consecutive frames (tptDrawDeviceBatch).  A compile-time switch: the frame index
+// a path carries costs the single-frame kernel two more spilled registers if it is a run-time one.
+template <bool LDS_SCENE, bool BATCH = false>
 __global__ void __launch_bounds__(TPT_Q_T, TPT_Q_MIN_WAVES_PER_SIMD) __attribute__((amdgpu_num_vgpr(TPT_Q_MAX_VGPR)))
 tptTraceQueueKernel(const KernelArgs a)
 {
@@ -788,6 +811,7 @@ tptTraceQueueKernel(const KernelArgs a)
     const unsigned long long laneBelow = (1ull << lane) - 1ull;
     f4* colSum = st + 2 * TPT_Q_P;                        // plane 2: per-path colour sums + pixel coordinates
     int chunkNext = 0, chunkEnd = 0; // this wave's private pixel pool
+    int chunkFrame = 0;              // batched launch: the frame of the batch that pool belongs to
     bool noMoreChunks = false;
     unsigned myRays = 0;
 #if defined(TPT_STATS)
@@ -878,6 +902,7 @@ tptTraceQueueKernel(const KernelArgs a)
         L.orig = L.dir = mk3(0, 0, 0);
         bool ray = false;    // this lane holds a ray that still has to be intersected
         bool toFree = false; // this lane's path goes back to the FREE queue
+        int laneFrame = 0;   // batched launch: the frame of the batch this lane's new pixel belongs to
         BounceStack stack;
         stack.base = st + 3 * TPT_Q_P + p; // level 0 in the path record
         stack.stride = 0;
@@ -907,6 +932,11 @@ tptTraceQueueKernel(const KernelArgs a)
                         noMoreChunks = true;
                         break;
                     }
+                    chunkFrame = 0;
+                    if (BATCH) { // batched launch: chunk c belongs to frame c / chunksPerFrame of the batch
+                        chunkFrame = c / a.chunksPerFrame;
+                        c -= chunkFrame * a.chunksPerFrame;
+                    }
                     chunkNext = c * a.chunkSize;
                     chunkEnd = chunkNext + a.chunkSize;
                     if (chunkEnd > a.numItems) chunkEnd = a.numItems;
@@ -920,6 +950,8 @@ tptTraceQueueKernel(const KernelArgs a)
                     int x, ly;
                     if (mapItem(a, chunkNext + rank, x, ly)) {
                         laneBeginPixel(L, fc, x, localRowToGlobal(a, ly), ly * fc.width + x, true);
+                        if (BATCH) L.rng = pixelSeed(fc.seedMode, L.x, L.y, fc.frame + chunkFrame);
+                        laneFrame = chunkFrame;
                         need = false;
                     }
                 }
@@ -929,7 +961,10 @@ tptTraceQueueKernel(const KernelArgs a)
             if (mine && L.active) {
                 L.hitType = 0;
                 laneCamera<FOLD_RECURSIVE>(L, fc);
-                colSum[p] = mk4(0.0f, 0.0f, 0.0f, u2f((uint32_t)L.x | ((uint32_t)L.y << 16))); // colour sum = 0
+                // colour sum = 0; the pixel: x | y << 16, or in a batched launch x | y << 13 | frame << 26
+                const uint32_t where = BATCH ? ((uint32_t)L.x | ((uint32_t)L.y << 13) | ((uint32_t)laneFrame << 26))
+                                                         : ((uint32_t)L.x | ((uint32_t)L.y << 16));
+                colSum[p] = mk4(0.0f, 0.0f, 0.0f, u2f(where));
                 ray = true;
             } else if (mine) {
                 toFree = true; // no pixel left for this path
@@ -957,10 +992,17 @@ tptTraceQueueKernel(const KernelArgs a)
                 // a sample ended: add it to the pixel's running sum (same order of additions as Test.cpp:289)
                 const f4 c3 = colSum[p];
                 L.col = mk3(c3.x, c3.y, c3.z) + L.col;
-                L.x = (int)(f2u(c3.w) & 0xffffu);
-                L.y = (int)(f2u(c3.w) >> 16);
+                int plane = 0;
+                if (BATCH) {
+                    L.x = (int)(f2u(c3.w) & 0x1fffu);
+                    L.y = (int)((f2u(c3.w) >> 13) & 0x1fffu);
+                    plane = (int)(f2u(c3.w) >> 26) * a.framePlane;
+                } else {
+                    L.x = (int)(f2u(c3.w) & 0xffffu);
+                    L.y = (int)(f2u(c3.w) >> 16);
+                }
                 if (pixelDone) {
-                    L.pix = globalRowToLocal(a, L.y) * fc.width + L.x;
+                    L.pix = plane + globalRowToLocal(a, L.y) * fc.width + L.x;
                     storeColour(a, L);
                     toFree = true;
                 } else {
@@ -1255,19 +1297,21 @@ size_t tptQueueLdsBytes(const KernelArgs& a, bool ldsScene)
 #endif
     return bytes;
 }
+template <bool LDS_SCENE, bool BATCH>
+static hipError_t launchTraceQueue(const KernelArgs& a, int blocks, size_t lds, hipStream_t stream)
+{
+    auto k = tptTraceQueueKernel<LDS_SCENE, BATCH>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(blocks), dim3(TPT_Q_T), lds, stream, a);
+    return hipSuccess;
+}
 hipError_t tptLaunchTraceQueue(const KernelArgs& a, bool ldsScene, int blocks, size_t lds, hipStream_t stream)
 {
-    if (ldsScene) {
-        auto k = tptTraceQueueKernel<true>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3(blocks), dim3(TPT_Q_T), lds, stream, a);
-    } else {
-        auto k = tptTraceQueueKernel<false>;
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3(blocks), dim3(TPT_Q_T), lds, stream, a);
-    }
+    const bool batch = a.batchFrames > 1;
+    hipError_t e = ldsScene ? (batch ? launchTraceQueue<true, true>(a, blocks, lds, stream) : launchTraceQueue<true, false>(a, blocks, lds, stream))
+                            : (batch ? launchTraceQueue<false, true>(a, blocks, lds, stream) : launchTraceQueue<false, false>(a, blocks, lds, stream));
+    if (e != hipSuccess) return e;
     return hipGetLastError();
 }
 int tptQueuePathsPerBlock() { return TPT_Q_P; }
@@ -1307,6 +1351,15 @@ hipError_t tptLaunchResolve(float* tile, const f4* frameColour, int nPixels, flo
                            reinterpret_cast<f4*>(mirror), rayCounter, counterOut);
     else
         hipLaunchKernelGGL(tptResolveKernel, dim3((nPixels + 255) / 256), dim3(256), 0, stream, tile, frameColour, nPixels, lerpFac, frameRays, rayCounter);
+    return hipGetLastError();
+}
+
+hipError_t tptLaunchResolveBatch(float* tile, const f4* frameColour, int nPixels, int planeStride, int nFrames, const tptLerpTable& lerp,
+                                 float* mirror, unsigned long long* rayCounter, unsigned long long* counterOut, hipStream_t stream)
+{
+    if (nPixels <= 0) return hipSuccess;
+    hipLaunchKernelGGL(tptResolveBatchKernel, dim3((nPixels + 255) / 256), dim3(256), 0, stream, tile, frameColour, nPixels, planeStride, nFrames, lerp,
+                       reinterpret_cast<f4*>(mirror), rayCounter, counterOut);
     return hipGetLastError();
 }
 

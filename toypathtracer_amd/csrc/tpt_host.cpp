@@ -1120,8 +1120,8 @@ int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long
 
     int rc = chooseKernel(P);
     if (rc) return rc;
-    if (batch > 1 && (!P.queued || w > 8192 || h > 8192))
-        return fail("tptDrawDeviceBatch: needs the path-queue kernel (per-pixel seeds, recursive fold, two-phase HitSpheres) and a frame of at most 8192 x 8192");
+    if (batch > 1 && (!P.queued || w > 8192 || h > 8192 || (long long)a.nLocalRows * w * batch > (1ll << 30)))
+        return fail("tptDrawDeviceBatch: needs the path-queue kernel (per-pixel seeds, recursive fold, two-phase HitSpheres) and a frame of at most 8192 x 8192 (2^30 pixels per batch)");
     sizeGrid(P);
     if ((rc = ensureFrameBuffers(P, w))) return rc;
     if (frameRays) a.rayCounter = frameRays;
@@ -1142,7 +1142,13 @@ int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long
         // aggregate; C2 unchanged; profiles/r02/r02_run40.log).  Pacing only: the stream wait below is what orders the work
         // (an event query may report "done" early on a re-recorded event).
         if (g.hostPace) {
-            while (hipEventQuery(g.evResolve[slot]) == hipErrorNotReady) std::this_thread::yield();
+            // (bounded: a caller whose stream is blocked behind something it will only enqueue later must not hang here)
+            const auto t0 = std::chrono::steady_clock::now();
+            unsigned spins = 0;
+            while (hipEventQuery(g.evResolve[slot]) == hipErrorNotReady) {
+                std::this_thread::yield();
+                if ((++spins & 255u) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+            }
             (void)hipGetLastError();
         }
         HIPCHK(hipStreamWaitEvent(ts, g.evResolve[slot], 0)); // colour buffer free again

@@ -148,6 +148,26 @@ def batched_rate(api, torch, width, height, per_launch=8, launches=25):
     return dt / (launches * per_launch) * 1e3, rays / dt / 1e6
 
 
+def sync_caller_rate(api, torch, width, height, frames=60):
+    """tptDrawDevice on a device tile with a synchronise after every frame: the reference's synchronous DrawTest contract
+    without the PCIe copies (the library traces the next frames ahead of such a caller)."""
+    tile = torch.zeros((height, width, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for f in range(8):
+        api.UpdateTest(0.0, f, width, height, FLAG_PROGRESSIVE)
+        api.draw_device(0.0, f, width, height, tile.data_ptr(), FLAG_PROGRESSIVE)
+        api.synchronize()
+    r0 = api.ray_counter_read()
+    t0 = time.perf_counter()
+    for f in range(8, 8 + frames):
+        api.UpdateTest(0.0, f, width, height, FLAG_PROGRESSIVE)
+        api.draw_device(0.0, f, width, height, tile.data_ptr(), FLAG_PROGRESSIVE)
+        api.synchronize()
+    dt = time.perf_counter() - t0
+    rays = api.ray_counter_read() - r0
+    return dt / frames * 1e3, rays / dt / 1e6
+
+
 def row_serial_rate(api, width, height, frames=3):
     """ROW_SERIAL seeds: the reference's exact image (one RNG stream per row: one lane per row)."""
     api.set_seed_mode(0)
@@ -362,6 +382,11 @@ def main():
             out["drawtest_host_note"] = ("synchronous DrawTest(host float* backbuffer) per frame, the reference's own calling contract: backbuffer "
                                          "upload + blend + download over PCIe in every call (default host-buffer mode), the next two frames "
                                          "traced ahead of the caller (tptSetHostLookahead); never the headline value")
+            if not args.animate and width * height <= 1280 * 720:
+                ms, mr = sync_caller_rate(api, torch, width, height)
+                out["sync_device_caller_ms"], out["sync_device_caller_Mray_s"] = ms, mr
+                out["sync_device_caller_note"] = ("tptDrawDevice + a synchronise after EVERY frame (device tile, no PCIe): the next two frames are "
+                                                  "traced ahead of such a caller; never the headline value")
             if args.persistent == 3 and args.hit_spheres != 1 and not args.animate and width * height <= 1280 * 720:
                 for k in (4, 8):
                     ms, mr = batched_rate(api, torch, width, height, per_launch=k, launches=max(4, 200 // k))

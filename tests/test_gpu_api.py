@@ -369,3 +369,49 @@ def test_sharded_batches_match_per_frame_exchange(tpt_defaults, oracle):
     mine = (np.arange(h) // stripe) % n == 0
     assert got[mine].tobytes() == want[mine].tobytes()
     assert not got[~mine].any()
+
+
+def test_synchronous_device_caller_gets_lookahead_and_the_same_bits(tpt_defaults, oracle):
+    """tptDrawDevice + a synchronise after every frame (the reference's DrawTest contract on a device tile): from the third
+    frame on the next frames are traced ahead; image, per-frame ray counts and totals equal the oracle's.  A caller that
+    streams the same frames gets no look-ahead and the same bits."""
+    import torch
+    from common import oracle_frames
+    tpt = tpt_defaults
+    w, h, frames = 320, 200, 12
+    ro, bo, per_frame = oracle_frames(oracle, w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
+    for synchronous in (True, False):
+        tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        hits0 = tpt.lookahead_hits()
+        last = tpt.ray_counter_read()
+        for f in range(frames):
+            tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+            tpt.draw_device(0.0, f, w, h, tile.data_ptr(), FLAG_PROGRESSIVE)
+            if synchronous:
+                now = tpt.ray_counter_read()  # synchronises
+                assert now - last == per_frame[f], f
+                last = now
+        total = tpt.ray_counter_read()
+        if not synchronous:
+            assert total - last == ro
+        assert tile.cpu().numpy().tobytes() == bo.tobytes(), synchronous
+        hits = tpt.lookahead_hits() - hits0
+        if synchronous:  # (a streaming caller normally gets none; a host hiccup may make it look synchronous for a moment -- harmless)
+            assert hits >= frames - 4, hits
+    # a change of configuration in the middle drops what was traced ahead
+    tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for f in range(6):
+        tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+        tpt.draw_device(0.0, f, w, h, tile.data_ptr(), FLAG_PROGRESSIVE)
+        tpt.synchronize()
+    tpt.set_samples_per_pixel(2)
+    tile2 = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    for f in range(3):
+        tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+        tpt.draw_device(0.0, f, w, h, tile2.data_ptr(), FLAG_PROGRESSIVE)
+        tpt.synchronize()
+    _, b2, _ = oracle_frames(oracle, w, h, 2, 3, seed_mode=SEED_PER_PIXEL)
+    assert tile2.cpu().numpy().tobytes() == b2.tobytes()

@@ -106,7 +106,7 @@ struct Context {
     unsigned long long* dRaysOwn = nullptr;
     long long lastTotal = 0;
 
-    f4* dStack[kMaxSlots] = {};         // recursive fold: global bounce stacks / spill levels (one per in-flight frame)
+    f4* dStack[kMaxSlots] = {};         // recursive fold: global bounce stacks / spill levels (one per trace stream: the first kMaxOverlap entries)
     size_t stackCap = 0, colourCap = 0, pathCap = 0; // bytes per slot; all reserved slots have the same capacities
     int slotsReserved = 0;              // slots [0, slotsReserved) hold buffers of those capacities
     int slotReservations = 0;           // how often the slot buffers were (re-)allocated (tptGetPipelineInfo)
@@ -121,7 +121,7 @@ struct Context {
     bool orderDone = true;
     unsigned long long orderSeq = 0;
     int lastOrderTable = 0;
-    f4* dPath[kMaxSlots] = {};          // path-queue kernel: cold path state (one per in-flight frame)
+    f4* dPath[kMaxSlots] = {};          // (unused since the path record moved into LDS; kept for the size bookkeeping)
     float* dFrame = nullptr; // device tile behind the host-pointer DrawTest
     // ---- host-pointer path (tptDraw / DrawTest)
     hipStream_t hostStream2 = nullptr;  // second stream of the banded upload / blend / download (full-duplex PCIe)
@@ -148,7 +148,7 @@ struct Context {
         int syncStreak = 0, seqStreak = 0;
     } devCaller;
     long long aheadHits = 0;            // frames that were found traced ahead when their call arrived (tptDebugLookaheadHits)
-    unsigned long long* dRaysAhead = nullptr; // [kMaxSlots] per-slot ray counters of the host path
+    unsigned long long* dRaysAhead = nullptr; // [kMaxSlots] per-slot ray counters of frames traced ahead of their call (both synchronous paths)
     unsigned long long configEpoch = 1;       // bumped by every call that changes what a frame looks like
 
     // ---- multi-GPU inside the library (one process per GPU, RCCL): tptCommInit .. tptDrawSharded

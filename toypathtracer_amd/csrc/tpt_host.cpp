@@ -418,7 +418,7 @@ int uploadBackbuffer(const float* backbuffer, int w, int h)
 int discardLookahead();
 struct TraceTicket;
 int takeAhead(TraceTicket& T, int& raySlot);
-int traceAhead(int frameCount, int w, int h, unsigned testFlags, unsigned long long key);
+int traceAhead(int frameCount, int w, int h, unsigned testFlags, unsigned long long key, int want);
 
 int requireInit()
 {
@@ -1252,10 +1252,13 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
         if (T.valid) D.lastSlot = T.slot;
         return rc;
     }
+    // one frame more than the host-pointer path looks ahead: there the PCIe copies fill the caller's time (2 ahead: 0.88 ms
+    // per frame, 3: 0.92), here nothing does (2: 0.598 ms, 3: 0.561; profiles/r02/r02_run50.log)
+    const int devAhead = g.lookahead + 1 < 3 ? g.lookahead + 1 : 3;
     struct DepthScope { // launches made from here share the machine with the frames traced ahead, not with a deep pipeline
         explicit DepthScope(int d) { g.depthOverride = d; }
         ~DepthScope() { g.depthOverride = 0; }
-    } depthScope(1 + (g.lookahead < 3 ? g.lookahead : 3));
+    } depthScope(1 + devAhead);
     int raySlot = -1;
     if (hit) {
         if ((rc = takeAhead(T, raySlot))) return rc;
@@ -1264,7 +1267,7 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
         raySlot = (int)(g.frameSeq % (unsigned long long)Context::kMaxSlots);
         if ((rc = enqueueTrace(frameCount, w, h, testFlags, g.dRaysAhead + raySlot, T))) return rc;
     }
-    if (lookAhead && T.valid && (rc = traceAhead(frameCount, w, h, testFlags, key))) return rc;
+    if (lookAhead && T.valid && (rc = traceAhead(frameCount, w, h, testFlags, key, devAhead))) return rc;
     rc = enqueueResolve(T, deviceTile, T.valid ? g.dRaysAhead + raySlot : nullptr);
     if (T.valid) D.lastSlot = T.slot;
     return rc;
@@ -1376,7 +1379,7 @@ int takeAhead(TraceTicket& T, int& raySlot)
 // Trace the frames after `frameCount` ahead of the caller, up to tptSetHostLookahead of them: the reference's hosts call
 // DrawTest(f), DrawTest(f + 1), ... with nothing else changing (TestWin.cpp:313-316, Renderer.mm:225, main.cpp:59-60); a
 // frame alone on the GPU is bound by its longest paths (one frame in flight: 1.0 ms, three: 0.55 ms per frame).
-int traceAhead(int frameCount, int w, int h, unsigned testFlags, unsigned long long key)
+int traceAhead(int frameCount, int w, int h, unsigned testFlags, unsigned long long key, int want)
 {
     int have = 0;
     while (have < 4 && g.ahead[have].used) ++have;
@@ -1384,7 +1387,7 @@ int traceAhead(int frameCount, int w, int h, unsigned testFlags, unsigned long l
     // every frame traced but not yet blended holds a slot (its colour buffer): this one plus the ones ahead must leave one
     // slot spare, whatever the hardware-queue probe clamped the pipeline to
     const int nSlots = effectiveOverlap();
-    const int maxAhead = g.lookahead < nSlots - 2 ? g.lookahead : nSlots - 2;
+    const int maxAhead = want < nSlots - 2 ? want : nSlots - 2;
     while (have < maxAhead) {
         Context::Ahead& A = g.ahead[have];
         A.frameCount = nextFrame; A.w = w; A.h = h; A.flags = testFlags; A.configKey = key;
@@ -1467,7 +1470,7 @@ int tptDraw(float time, int frameCount, int w, int h, float* backbuffer, int* ou
     }
     // ---- 2. trace the next frames ahead (a wrong guess costs GPU time only)
     if (pipelined && stable && T.valid) {
-        int rc = traceAhead(frameCount, w, h, testFlags, key);
+        int rc = traceAhead(frameCount, w, h, testFlags, key, g.lookahead);
         if (rc) return rc;
     }
     // ---- 3. the previous image: the host buffer is the source of truth (previous frame's RGB, caller-owned alpha) unless

@@ -22,14 +22,22 @@ for n in [int(v) for v in os.environ.get("TPT_EMU_N", "1,2,4,8").split(",")]:
     for f in range(0, warm, batch):
         api.UpdateTest(0.0, f, w, h, 2)
         api.draw_sharded_batch(0.0, f, batch, w, h, image.data_ptr(), 2)
-    r0 = api.sharded_finish()
-    t0 = time.perf_counter()
-    for f in range(warm, warm + frames, batch):
-        api.UpdateTest(0.0, f, w, h, 2)
-        api.draw_sharded_batch(0.0, f, batch, w, h, image.data_ptr(), 2)
-    t_enq = time.perf_counter() - t0
-    rays = api.sharded_finish() - r0
-    dt = time.perf_counter() - t0
+    best = None
+    for rep in range(2):  # best of two timed passes (a one-off stall now and then would otherwise decide the figure)
+        r0 = api.sharded_finish()
+        t0 = time.perf_counter()
+        first = warm + rep * frames
+        for f in range(first, first + frames, batch):
+            api.UpdateTest(0.0, f, w, h, 2)
+            api.draw_sharded_batch(0.0, f, batch, w, h, image.data_ptr(), 2)
+        t_enq = time.perf_counter() - t0
+        rays = api.sharded_finish() - r0
+        dt = time.perf_counter() - t0
+        if os.environ.get("TPT_EMU_VERBOSE"):
+            print("  N=%d pass %d: %.3f ms/frame" % (n, rep, dt / frames * 1e3), flush=True)
+        if best is None or dt < best[0]:
+            best = (dt, rays, t_enq)
+    dt, rays, t_enq = best
     agg = rays / dt / 1e9 * n
     base = base or agg
     print("N=%d: %.3f ms/frame  rank 0 %.2f Gray/s  aggregate %.1f Gray/s  efficiency %.0f %%  (batch %d; in flight %d; host enqueue %.3f ms/frame)" % (

@@ -133,9 +133,10 @@ class ShardedFrame:
         """With mirroring: call BEFORE the frame's draw is enqueued -- makes the render stream wait until the collective
         that last read the send buffer about to be overwritten has finished."""
         if self.world > 1 and self.on_gpu and self.steps >= self.depth:
-            ev = self.ev_free[self.steps % self.depth]
-            if not ev.query():  # usually long done (4 buffers): then no wait packet goes into the render stream's chain
-                self.render_stream.wait_event(ev)
+            # always the stream wait, never an event query as a shortcut: a query on a re-recorded event has been seen to
+            # answer "done" before the new record's work was (DESIGN.md section 2), and a blend that overwrites a snapshot the
+            # gather is still reading would corrupt the exchanged image once in a long while
+            self.render_stream.wait_event(self.ev_free[self.steps % self.depth])
 
     def exchange(self, snapshot_done=False):
         """Call after this frame's render has been enqueued on render_stream."""

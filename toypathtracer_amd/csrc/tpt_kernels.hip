@@ -1025,7 +1025,11 @@ tptTraceQueueKernel(const KernelArgs a)
             int hitId = -1;
             float hitT = 0.0f;
             bool pending = ray;
+#if TPT_MATRIX_FILTER
             while (__ballot(pending) != 0ull) {
+#else
+            while (pending) {
+#endif
 #if defined(TPT_STATS)
                 qSteps++;
 #endif

@@ -714,30 +714,6 @@ __device__ __forceinline__ int qPop(volatile unsigned short* q, unsigned* head, 
 //   [3] bounce-stack level 0 {matE + lightE, attenuation id}: 56 % of all pushes; deeper levels live in global memory
 // Everything else of a Lane is constant while a path sits in a queue (a main-chain ray, alive, no camera ray pending;
 // sp == depth with the recursive fold) or is recomputed by the class code.
-__device__ __forceinline__ void qStoreHot(const Lane& L, int id, f4* st, int p)
-{
-    const uint32_t w = ((uint32_t)L.sample & 0x7ffu) | (((uint32_t)L.depth & 15u) << 11) | ((uint32_t)L.doMatE << 15) | (((uint32_t)id & 0xffffu) << 16);
-    st[0 * TPT_Q_P + p] = mk4(L.orig.x, L.orig.y, L.orig.z, u2f(L.rng));
-    st[1 * TPT_Q_P + p] = mk4(L.dir.x, L.dir.y, L.dir.z, u2f(w));
-}
-__device__ __forceinline__ void qLoadHot(Lane& L, int& id, const f4* st, int p)
-{
-    f4 v = st[0 * TPT_Q_P + p];
-    L.orig = mk3(v.x, v.y, v.z); L.rng = f2u(v.w);
-    v = st[1 * TPT_Q_P + p];
-    L.dir = mk3(v.x, v.y, v.z);
-    const uint32_t w = f2u(v.w);
-    L.sample = (int)(w & 0x7ffu);
-    L.depth = (int)((w >> 11) & 15u);
-    L.sp = L.depth; // recursive fold: one stack entry per bounce
-    L.doMatE = ((w >> 15) & 1u) != 0;
-    id = (w >> 16) == 0xffffu ? -1 : (int)(w >> 16);
-    L.kind = KIND_MAIN;
-    L.active = true;
-    L.needCamera = false;
-    L.hitType = 0;
-}
-
 #ifndef TPT_Q_MIN_WAVES_PER_SIMD
 #define TPT_Q_MIN_WAVES_PER_SIMD 4
 #endif
@@ -895,24 +871,38 @@ tptTraceQueueKernel(const KernelArgs a)
         if (mine) { TPT_STAT(16 + pick); } // [16+pick] batches popped per queue, [48+pick] paths in them
 #endif
 
-        Lane L;
-        L.active = false;
-        L.kind = KIND_MAIN;
-        L.depth = 0;
-        L.orig = L.dir = mk3(0, 0, 0);
+        // ---- this iteration's path state, in registers: the ray the batch produces (or, from a class queue, the hit
+        //      position and the incoming direction), the rng, the flags of the record's word
+        f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0);
+        uint32_t rng = 0;
+        int sample = 0, depth = 0, recId = -1;
+        bool doMatE = true;
         bool ray = false;    // this lane holds a ray that still has to be intersected
         bool toFree = false; // this lane's path goes back to the FREE queue
-        int laneFrame = 0;   // batched launch: the frame of the batch this lane's new pixel belongs to
-        BounceStack stack;
-        stack.base = st + 3 * TPT_Q_P + p; // level 0 in the path record
-        stack.stride = 0;
-        stack.fastLevels = 1;
+        bool toEnd = false;  // Metal whose scattered ray points into the surface: the path ends (END class), nothing to intersect
+        QStack stack;
+        stack.l0 = st + 3 * TPT_Q_P + p; // level 0 in the path record
         stack.spill = a.stackBuf + ((size_t)blockIdx.x * TPT_Q_P + p);
-        stack.spillStride = a.stackStride;
+        stack.stride = a.stackStride;
+        QLambert lam;
+        lam.sdir = lam.nl = lam.albedo = lam.lightE = mk3(0, 0, 0);
+        lam.cosAMax = 0.0f;
+        if (pick != Q_FREE && mine) {
+            const f4 r0 = st[0 * TPT_Q_P + p], r1 = st[1 * TPT_Q_P + p];
+            ro = mk3(r0.x, r0.y, r0.z);
+            rng = f2u(r0.w);
+            rd = mk3(r1.x, r1.y, r1.z);
+            const uint32_t w = f2u(r1.w);
+            sample = (int)(w & 0x7ffu);
+            depth = (int)((w >> 11) & 15u);
+            doMatE = ((w >> 15) & 1u) != 0;
+            recId = (w >> 16) == 0xffffu ? -1 : (int)(w >> 16);
+        }
 
         if (pick == Q_FREE) {
             // ---- start pixels on free paths (this wave's chunk pool, refilled from the global counter)
-            bool need = mine;
+            bool need = mine, got = false;
+            int px = 0, py = 0, laneFrame = 0;
             for (;;) {
                 const unsigned long long needMask = __ballot(need);
                 if (needMask == 0ull) break;
@@ -949,129 +939,149 @@ tptTraceQueueKernel(const KernelArgs a)
                 if (need && rank < take) {
                     int x, ly;
                     if (mapItem(a, chunkNext + rank, x, ly)) {
-                        laneBeginPixel(L, fc, x, localRowToGlobal(a, ly), ly * fc.width + x, true);
-                        if (BATCH) L.rng = pixelSeed(fc.seedMode, L.x, L.y, fc.frame + chunkFrame);
+                        px = x;
+                        py = localRowToGlobal(a, ly);
                         laneFrame = chunkFrame;
+                        got = true;
                         need = false;
                     }
                 }
                 chunkNext += take;
                 if (lane == 0) atomicSub(&ctl->poolTotal, (unsigned)take);
             }
-            if (mine && L.active) {
-                L.hitType = 0;
-                laneCamera<FOLD_RECURSIVE>(L, fc);
+            if (got) {
+                rng = pixelSeed(fc.seedMode, px, py, fc.frame + (BATCH ? laneFrame : 0));
                 // colour sum = 0; the pixel: x | y << 16, or in a batched launch x | y << 13 | frame << 26
-                const uint32_t where = BATCH ? ((uint32_t)L.x | ((uint32_t)L.y << 13) | ((uint32_t)laneFrame << 26))
-                                                         : ((uint32_t)L.x | ((uint32_t)L.y << 16));
+                const uint32_t where = BATCH ? ((uint32_t)px | ((uint32_t)py << 13) | ((uint32_t)laneFrame << 26))
+                                             : ((uint32_t)px | ((uint32_t)py << 16));
                 colSum[p] = mk4(0.0f, 0.0f, 0.0f, u2f(where));
+                qCamera(fc, px, py, rng, ro, rd);
                 ray = true;
             } else if (mine) {
                 toFree = true; // no pixel left for this path
             }
         } else if (pick == Q_INT) {
-            // ---- overflow: rays of sparse batches, re-batched
+            ray = mine; // overflow: rays of sparse batches, re-batched
+        } else if (pick == Q_END) {
+            // ---- a path ended (sky / emission): fold, add the sample to the pixel's sum, next sample or pixel done
             if (mine) {
-                int id;
-                qLoadHot(L, id, st, p);
-                ray = true;
-            }
-        } else if (mine) {
-            // ---- Scatter / sky / fold of one class, at full lane utilisation
-            int id;
-            qLoadHot(L, id, st, p);
-            L.sdir = L.nl = L.lightE = L.albedo = L.matE = mk3(0, 0, 0);
-            L.cosAMax = 0.0f;
-            L.hitId = 0;
-            L.j = 0;
-            L.col = mk3(0, 0, 0); // colour of the sample that ends in this step, if one does (0 + c == c)
-            L.x = 0; L.y = 0;
-            const int sampleBefore = L.sample;
-            const bool pixelDone = lanePost<FOLD_RECURSIVE, true>(L, id, 0.0f, sv, fc, stack);
-            if (L.sample != sampleBefore) {
-                // a sample ended: add it to the pixel's running sum (same order of additions as Test.cpp:289)
+                const f3 c = qFold(sv, qEndTerm(sv, fc, rd, recId), depth, stack);
                 const f4 c3 = colSum[p];
-                L.col = mk3(c3.x, c3.y, c3.z) + L.col;
-                int plane = 0;
+                const f3 col = mk3(c3.x, c3.y, c3.z) + c; // same order of additions as Test.cpp:289
+                int px, py, plane = 0;
                 if (BATCH) {
-                    L.x = (int)(f2u(c3.w) & 0x1fffu);
-                    L.y = (int)((f2u(c3.w) >> 13) & 0x1fffu);
+                    px = (int)(f2u(c3.w) & 0x1fffu);
+                    py = (int)((f2u(c3.w) >> 13) & 0x1fffu);
                     plane = (int)(f2u(c3.w) >> 26) * a.framePlane;
                 } else {
-                    L.x = (int)(f2u(c3.w) & 0xffffu);
-                    L.y = (int)(f2u(c3.w) >> 16);
+                    px = (int)(f2u(c3.w) & 0xffffu);
+                    py = (int)(f2u(c3.w) >> 16);
                 }
-                if (pixelDone) {
-                    L.pix = plane + globalRowToLocal(a, L.y) * fc.width + L.x;
-                    storeColour(a, L);
-                    toFree = true;
-                } else {
-                    colSum[p] = mk4(L.col.x, L.col.y, L.col.z, c3.w);
-                    laneCamera<FOLD_RECURSIVE>(L, fc); // needCamera is set: next sample of the same pixel
+                sample++;
+                if (sample < fc.spp) {
+                    colSum[p] = mk4(col.x, col.y, col.z, c3.w);
+                    qCamera(fc, px, py, rng, ro, rd);
+                    depth = 0;
+                    doMatE = true;
                     ray = true;
+                } else {
+                    const f3 out = col * fc.invSpp; // Test.cpp:291
+                    a.frameColour[plane + globalRowToLocal(a, py) * fc.width + px] = mk4(out.x, out.y, out.z, 0.0f); // one 16-B store per pixel
+                    toFree = true;
                 }
-            } else {
-                ray = true; // bounce ray, or the first shadow ray of a Lambert hit
+            }
+        } else if (pick == Q_DIEL) {
+            if (mine) {
+                f3 e;
+                rd = qDielectric(sv, fc, ro, rd, recId, doMatE, rng, e);
+                qStackPush(stack, depth, e, -1);
+                depth++;
+                doMatE = true; // Test.cpp:214
+                ray = true;
+            }
+        } else if (pick == Q_METAL) {
+            if (mine) {
+                f3 e, nd;
+                if (qMetal(sv, fc, ro, rd, recId, doMatE, rng, e, nd)) {
+                    qStackPush(stack, depth, e, recId);
+                    depth++;
+                    doMatE = true;
+                    rd = nd;
+                    ray = true;
+                } else {
+                    toEnd = true; // Test.cpp:218-221: return matE -- the END class does that from the record as it stands
+                }
+            }
+        } else { // Q_LAMBERT
+            if (mine) {
+                qLambertBegin(sv, ro, rd, recId, rng, lam);
+                ray = true;
             }
         }
 
         TPT_TSTAMP(tsClass);
         TPT_TADD(64 + pick * 4 + 1, tsPop, tsClass);
-        // ---- HitWorld for the rays this batch produced.  A Lambert hit runs its whole light loop here: the shadow
-        //      ray is intersected, shaded, and the next one (or the bounce ray) generated, all in registers.
+        // ---- HitWorld for the rays this batch produced.  A Lambert batch first runs its light loop (Test.cpp:96-133), wave-
+        //      uniform in j: shadow ray, intersection, shading, all in registers; its last trip intersects the bounce ray.
         int cls = -1;
         const int nRay = __popcll(__ballot(ray));
         if (pick == Q_FREE || pick == Q_INT || pick == Q_LAMBERT || nRay >= TPT_Q_FUSE_MIN) {
+            const int nShadow = (pick == Q_LAMBERT && (fc.config & CFG_LIGHT_SAMPLING)) ? sv.nLights : 0;
             int hitId = -1;
             float hitT = 0.0f;
-            bool pending = ray;
-#if TPT_MATRIX_FILTER
-            while (__ballot(pending) != 0ull) {
-#else
-            while (pending) {
-#endif
+            for (int j = 0; j <= nShadow; ++j) {
 #if defined(TPT_STATS)
                 qSteps++;
 #endif
-                // (TPT_MATRIX_FILTER builds: phase 1 of HitSpheres for the whole wave on the matrix cores; every lane takes part,
-                //  lanes without a ray feed whatever finite values they hold and ignore their mask)
-#if TPT_MATRIX_FILTER
-                uint64_t cand = 0ull;
-                if (LDS_SCENE && useMatrix) cand = phase1Matrix(ldsA, mxR1, L.orig, L.dir);
-#endif
-                if (pending) {
+                const bool shadow = j < nShadow;
+                if (pick == Q_LAMBERT && !shadow && ray) {
+                    // the light loop is over: what this level adds to the fold, then the bounce ray (Test.cpp:91, 210-216)
+                    qStackPush(stack, depth, qLambertE(sv, recId, doMatE, lam), recId);
+                    depth++;
+                    doMatE = !(fc.config & CFG_LIGHT_SAMPLING); // Test.cpp:209-214: only with light sampling
+                    rd = lam.sdir;
+                }
+                f3 d2 = rd;
+                bool go = ray;
+                int lightId = -2;
+                f4 l1 = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (shadow) {
+                    l1 = sv.lights[j * 2 + 1];
+                    lightId = (int)f2u(l1.w);
+                    go = ray && lightId != recId; // Test.cpp:100: not the sphere itself
+                    if (go) d2 = qLightRay(sv.lights[j * 2], ro, rng, lam.cosAMax);
+                }
+                if (go) {
                     TPT_STAT(ST_STEP);
                     float t;
-#if TPT_MATRIX_FILTER
-                    const int id = (LDS_SCENE && useMatrix)
-                                       ? hitSpheresCandidates(sv, cand, L.orig, L.dir, TPT_MIN_T, TPT_MAX_T, t)
-                                       : hitSpheres<LDS_SCENE ? HS_TWO_PHASE : HS_TWO_PHASE_GROUPS>(sv, L.orig, L.dir, TPT_MIN_T, TPT_MAX_T, t);
-#else
-                    const int id = hitSpheres<LDS_SCENE ? HS_TWO_PHASE : HS_TWO_PHASE_GROUPS>(sv, L.orig, L.dir, TPT_MIN_T, TPT_MAX_T, t);
-#endif
+                    const int id = hitSpheres<LDS_SCENE ? HS_TWO_PHASE : HS_TWO_PHASE_GROUPS>(sv, ro, d2, TPT_MIN_T, TPT_MAX_T, t);
                     myRays++;
-                    if (L.kind == KIND_SHADOW) {
-                        (void)lanePost<FOLD_RECURSIVE>(L, id, t, sv, fc, stack); // Test.cpp:123-132, then next light or bounce
+                    if (shadow) {
+                        if (id == lightId) qLightShade(l1, d2, lam);
                     } else {
                         hitId = id;
                         hitT = t;
-                        pending = false;
                     }
                 }
             }
             if (ray) {
-                if (hitId < 0 || L.depth >= TPT_MAX_DEPTH)
+                if (hitId < 0 || depth >= TPT_MAX_DEPTH)
                     cls = Q_END;
                 else {
                     const int type = (int)f2u(sv.mats[hitId * 3].w);
                     cls = type == MAT_LAMBERT ? Q_LAMBERT : type == MAT_METAL ? Q_METAL : type == MAT_DIELECTRIC ? Q_DIEL : Q_END;
                 }
-                if (hitId >= 0) L.orig = L.orig + L.dir * hitT; // the hit position (Maths.cpp:195), all the class code needs of {orig, t}
-                qStoreHot(L, hitId, st, p);
+                if (hitId >= 0) ro = ro + rd * hitT; // the hit position (Maths.cpp:195), all the class code needs of {orig, t}
+                recId = hitId;
             }
         } else if (ray) {
-            qStoreHot(L, 0, st, p);
             cls = Q_INT;
+        }
+        if (toEnd) cls = Q_END;
+        if (ray || toEnd) {
+            const uint32_t w = ((uint32_t)sample & 0x7ffu) | (((uint32_t)depth & 15u) << 11) | ((uint32_t)doMatE << 15) | (((uint32_t)recId & 0xffffu) << 16);
+            st[0 * TPT_Q_P + p] = mk4(ro.x, ro.y, ro.z, u2f(rng));
+            st[1 * TPT_Q_P + p] = mk4(rd.x, rd.y, rd.z, u2f(w));
         }
         if (toFree) cls = Q_FREE;
         TPT_TSTAMP(tsInt);

@@ -883,6 +883,174 @@ TPT_HD bool laneStep(Lane& L, const SceneView& sv, const FrameConsts& fc, const 
     return lanePost<FOLD>(L, id, t, sv, fc, stack);
 }
 
+// ---------------------------------------------------------------- class code of the path-queue kernel
+// The same Scatter / Trace logic as lanePost, cut into one straight-line function per material class: in the path-queue
+// kernel a whole batch needs the SAME code (the class is wave-uniform), so nothing of the generic state machine's flag
+// merging is left -- each function reads what its class needs and returns the bounce.  (lanePost stays the code of the
+// lane-refill fallback kernel; tests/lane_emu.cpp runs both against the oracle.)
+// Bounce stack of a path in the queue kernel: level 0 in the path record (LDS), levels 1..9 in global memory.
+struct QStack {
+    f4* l0;
+    f4* spill;  // level k >= 1 at spill[(k - 1) * stride]
+    int stride;
+};
+TPT_HD void qStackPush(const QStack& s, int level, f3 e, int attId)
+{
+    f4 v;
+    v.x = e.x; v.y = e.y; v.z = e.z; v.w = u2f((uint32_t)attId);
+    if (level == 0)
+        *s.l0 = v;
+    else
+        s.spill[(level - 1) * s.stride] = v;
+}
+// hit normal, Maths.cpp:196-197
+TPT_HD f3 qNormal(const SceneView& sv, int id, f3 pos)
+{
+    const f4 s = sv.sph4[id];
+    return (pos - mk3(s.x, s.y, s.z)) * sv.invR[id];
+}
+// camera ray of the next sample of pixel (x, y), Test.cpp:286-288
+TPT_HD void qCamera(const FrameConsts& fc, int x, int y, uint32_t& rng, f3& o, f3& d)
+{
+    TPT_STAT(ST_CAMERA);
+    const float u = ((float)x + rnd01(rng)) * fc.invWidth;
+    const float v = ((float)y + rnd01(rng)) * fc.invHeight;
+    cameraGetRay(fc.cam, u, v, rng, o, d);
+}
+// what a path that ends contributes before the fold: sky (Test.cpp:226-231) or the un-zeroed emission of the sphere it
+// stopped on (depth cap / failed scatter / unknown material, Test.cpp:207,218-221,187-191)
+TPT_HD f3 qEndTerm(const SceneView& sv, const FrameConsts& fc, f3 dir, int id)
+{
+    if (id < 0) {
+        TPT_STAT(ST_SKY);
+        return (fc.config & CFG_MITSUBA_COMPARE) ? mk3(0.15f, 0.21f, 0.3f) : sky(dir);
+    }
+    const f4 m1 = sv.mats[id * 3 + 1];
+    return mk3(m1.x, m1.y, m1.z);
+}
+// matE + lightE + attenuation * Trace(...), Test.cpp:216, innermost level first.  All levels are requested before the
+// first is used (one memory latency, not one per level); two groups of five keep the register cost at 20.
+TPT_HD f3 qFold(const SceneView& sv, f3 term, int depth, const QStack& s)
+{
+    TPT_STAT(ST_FINISH);
+    f3 c = term;
+#pragma unroll
+    for (int g5 = 1; g5 >= 0; --g5) {
+        f4 ent[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            ent[k].x = ent[k].y = ent[k].z = ent[k].w = 0.0f;
+            const int lvl = g5 * 5 + k;
+            if (lvl < depth) ent[k] = lvl == 0 ? *s.l0 : s.spill[(lvl - 1) * s.stride];
+        }
+#pragma unroll
+        for (int k = 4; k >= 0; --k) {
+            if (g5 * 5 + k < depth) {
+                const f4 e = ent[k];
+                const int a = (int)f2u(e.w);
+                f3 at = mk3(1, 1, 1);
+                if (a >= 0) {
+                    const f4 m0 = sv.mats[a * 3];
+                    at = mk3(m0.x, m0.y, m0.z);
+                }
+                c = mk3(e.x, e.y, e.z) + at * c;
+            }
+        }
+    }
+    return c;
+}
+// Dielectric, Test.cpp:151-186: always scatters.  e = what this level adds (matE + lightE, lightE = 0), attenuation (1,1,1).
+TPT_HD f3 qDielectric(const SceneView& sv, const FrameConsts& fc, f3 pos, f3 rdir, int id, bool doMatE, uint32_t& rng, f3& e)
+{
+    TPT_STAT(ST_DIELECTRIC);
+    (void)fc;
+    const f3 normal = qNormal(sv, id, pos);
+    const f4 m1 = sv.mats[id * 3 + 1];
+    const float ri = sv.mats[id * 3 + 2].x;
+    const f3 refl = reflect(rdir, normal);
+    f3 outwardN, refr = mk3(0, 0, 0);
+    float nint, cosine, reflProb;
+    const float dn = dot(rdir, normal);
+    if (dn > 0) {
+        outwardN = -normal;
+        nint = ri;
+        cosine = ri * dn;
+    } else {
+        outwardN = normal;
+        nint = 1.0f / ri;
+        cosine = -dn;
+    }
+    if (refract(rdir, outwardN, nint, refr))
+        reflProb = schlick(cosine, ri);
+    else
+        reflProb = 1;
+    const f3 pick = rnd01(rng) < reflProb ? refl : refr;
+    e = (doMatE ? mk3(m1.x, m1.y, m1.z) : mk3(0, 0, 0)) + mk3(0, 0, 0); // matE + lightE, Test.cpp:216
+    return normalize(pick);
+}
+// Metal, Test.cpp:137-150: false = the scattered ray points into the surface (the path ends with the sphere's emission).
+TPT_HD bool qMetal(const SceneView& sv, const FrameConsts& fc, f3 pos, f3 rdir, int id, bool doMatE, uint32_t& rng, f3& e, f3& newDir)
+{
+    TPT_STAT(ST_METAL);
+    const f3 normal = qNormal(sv, id, pos);
+    const f4 m1 = sv.mats[id * 3 + 1];
+    const f3 refl = reflect(rdir, normal);
+    const float roughness = (fc.config & CFG_MITSUBA_COMPARE) ? 0.0f : m1.w; // Test.cpp:143-145 (the samples are drawn either way)
+    newDir = normalize(refl + roughness * randomInUnitSphere(rng));
+    e = (doMatE ? mk3(m1.x, m1.y, m1.z) : mk3(0, 0, 0)) + mk3(0, 0, 0);
+    return dot(newDir, normal) > 0;
+}
+// Lambert, Test.cpp:86-136, in three pieces so that the kernel can intersect the shadow rays in between:
+//   qLambertBegin: the bounce direction (drawn first, Test.cpp:89-91) and the shading frame;
+//   qLightRay:     light j's sample direction, Test.cpp:102-120 (false: j is the sphere itself, Test.cpp:100);
+//   qLightShade:   Test.cpp:123-132 once the shadow ray's nearest hit is known.
+struct QLambert {
+    f3 sdir, nl, albedo, lightE;
+    float cosAMax;
+};
+TPT_HD void qLambertBegin(const SceneView& sv, f3 pos, f3 rdir, int id, uint32_t& rng, QLambert& q)
+{
+    TPT_STAT(ST_LAMBERT);
+    const f3 normal = qNormal(sv, id, pos);
+    const f4 m0 = sv.mats[id * 3];
+    const f3 target = pos + normal + randomUnitVector(rng);
+    q.sdir = normalize(target - pos);
+    q.albedo = mk3(m0.x, m0.y, m0.z);
+    q.nl = dot(normal, rdir) < 0 ? normal : -normal; // Test.cpp:129 (uses r_in.dir)
+    q.lightE = mk3(0, 0, 0);
+    q.cosAMax = 0.0f;
+}
+TPT_HD f3 qLightRay(const f4 l0, f3 pos, uint32_t& rng, float& cosAMax)
+{
+    TPT_STAT(ST_LIGHTGEN);
+    const f3 sc = mk3(l0.x, l0.y, l0.z);
+    const f3 sw = normalize(sc - pos);
+    const f3 su = normalize(cross((sw.x < 0 ? -sw.x : sw.x) > 0.01f ? mk3(0, 1, 0) : mk3(1, 0, 0), sw));
+    const f3 sv_ = cross(sw, su);
+    cosAMax = tsqrt(1.0f - l0.w * l0.w / sqLength(pos - sc));
+    const float eps1 = rnd01(rng), eps2 = rnd01(rng);
+    const float cosA = 1.0f - eps1 + eps1 * cosAMax;
+    const float sinA = tsqrt(1.0f - cosA * cosA);
+    const float phi = 2 * TPT_PI * eps2;
+    float sn, cs;
+    tsincosf(phi, sn, cs);
+    return su * (cs * sinA) + sv_ * (sn * sinA) + sw * cosA;
+}
+// what the Lambert level adds to the fold: matE (unless the previous bounce already sampled the lights, Test.cpp:210) + lightE
+TPT_HD f3 qLambertE(const SceneView& sv, int id, bool doMatE, const QLambert& q)
+{
+    const f4 m1 = sv.mats[id * 3 + 1];
+    return (doMatE ? mk3(m1.x, m1.y, m1.z) : mk3(0, 0, 0)) + q.lightE;
+}
+TPT_HD void qLightShade(const f4 l1, f3 l, QLambert& q)
+{
+    TPT_STAT(ST_SHADOW);
+    const float omega = 2 * TPT_PI * (1 - q.cosAMax);
+    const float dln = dot(l, q.nl);
+    const float mx = 0.0f < dln ? dln : 0.0f; // std::max(0.0f, dln)
+    q.lightE = q.lightE + (q.albedo * mk3(l1.x, l1.y, l1.z)) * (mx * omega / TPT_PI);
+}
+
 // Pixel complete: the frame's colour of this pixel, averaged over the samples (Test.cpp:291).
 TPT_HD f3 lanePixelColour(const Lane& L, const FrameConsts& fc) { return L.col * fc.invSpp; }
 

@@ -212,6 +212,9 @@ int tptTestMath(int op, const float* a, const float* b, float* out, int n);
 /* intersect n host rays ([n][6] = origin, UNIT direction -- the reference asserts it, Maths.h:337; the two-phase
  * filter's error bound assumes it) with the current scene on the GPU */
 int tptTestHitSpheres(int hitSpheres, const float* rays, int* outId, float* outT, int n);
+/* self-check: tpt_math.h's fast correctly-rounded sqrt (op 0) / 1.0f / sqrtf (op 1) against the compiler's correctly rounded
+ * expansions for EVERY binary32 bit pattern in [lo, hi] on the device; mismatch count + the first offending inputs */
+int tptTestMathExhaustive(int op, unsigned lo, unsigned hi, unsigned long long* outMismatches, unsigned* outFirst8);
 /* phase 1 of HitSpheres evaluated on the matrix cores (v_mfma_f32_32x32x2_f32 over a 12-term expansion of the filter's
  * discriminant; scenes of <= 64 spheres): candidate masks, sphere p at bit 63 - p, of n host rays.  A measured-and-rejected
  * variant kept as a unit-tested building block; the shipped kernels run the packed-VALU filter. */

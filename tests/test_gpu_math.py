@@ -25,6 +25,16 @@ def test_sqrt_correctly_rounded(tpt):
     assert np.array_equal(bits(tpt.test_math(0, x)), bits(np.sqrt(x)))
 
 
+@pytest.mark.parametrize("op", [0, 1], ids=["sqrt", "normalize_scale"])
+def test_fast_sqrt_paths_equal_the_compilers_expansion_for_all_2_to_32_inputs(tpt, op):
+    """tpt_math.h's 5-instruction sqrt and 8-instruction 1.0f / sqrtf (guarded to [2^-96, 2^96], the compiler's expansion
+    outside) against hipcc's correctly rounded sqrt / divide for EVERY binary32 bit pattern.  Together with
+    test_sqrt_correctly_rounded / test_schlick_rng_normalize (the compiler's expansion == the host's IEEE results) this
+    pins the fast paths to IEEE for all inputs."""
+    bad, first = tpt.test_math_exhaustive(op)
+    assert bad == 0, ["%08x" % v for v in first]
+
+
 def test_div_correctly_rounded(tpt):
     rng = np.random.default_rng(1)
     a = rnd_floats(rng, 1 << 20, -40, 40, signed=True)

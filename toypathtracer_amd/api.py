@@ -36,7 +36,7 @@ C_ABI_SYMBOLS = [
     "tptInitialize", "tptShutdown", "tptUpdate", "tptDraw", "tptGetObjectCount", "tptGetSceneDesc",
     "tptSetSamplesPerPixel", "tptSetConfig", "tptSetSeedMode", "tptSetFoldMode", "tptSetScene", "tptSetCamera", "tptSetStream",
     "tptSetRowShard", "tptLocalRowCount", "tptLocalRowToGlobal", "tptDrawDevice", "tptRayCounterRead", "tptSetRayCounter", "tptSetFrameOverlap", "tptDisplayRGBA8", "tptKernelTimingBegin", "tptKernelTimingEnd",
-    "tptSynchronize", "tptTimerBegin", "tptTimerEnd", "tptSetKernelVariant", "tptTestMath", "tptTestHitSpheres",
+    "tptSynchronize", "tptTimerBegin", "tptTimerEnd", "tptSetKernelVariant", "tptTestMath", "tptTestMathExhaustive", "tptTestHitSpheres",
     "tptDrawDeviceBatch", "tptDrawShardedBatch", "tptDebugLookaheadHits", "tptCommGetUniqueId", "tptCommInit", "tptCommInitLoopback", "tptCommDestroy", "tptDrawSharded", "tptShardedFinish", "tptGetLaunchInfo", "tptGetPipelineInfo", "tptSetHostBufferMode", "tptSetHostLookahead", "tptTestMatrixFilter", "tptSetTileMirror", "tptGetLastError", "tptGetDeviceName", "tptDebugStats", "tptDebugChunkOrder",
 ]
 # the reference's own C++ symbols (nm of the compiled Test.cpp), exported for link-level drop-in
@@ -79,7 +79,7 @@ def load_library():
         "tptSetRayCounter": [p], "tptSetTileMirror": [p, p], "tptSetFrameOverlap": [i], "tptDisplayRGBA8": [p, i, i, p], "tptKernelTimingBegin": [i],
         "tptKernelTimingEnd": [C.POINTER(f), C.POINTER(i)],
         "tptSynchronize": [], "tptTimerBegin": [], "tptTimerEnd": [C.POINTER(f)], "tptSetKernelVariant": [i, i, i],
-        "tptDebugStats": [p, i], "tptDebugChunkOrder": [p, p, i], "tptTestMath": [i, p, p, p, i], "tptTestHitSpheres": [i, p, p, p, i], "tptTestMatrixFilter": [p, p, i], "tptGetLaunchInfo": [C.POINTER(i)] * 4, "tptGetPipelineInfo": [C.POINTER(i)] * 4, "tptCommGetUniqueId": [p], "tptCommInit": [p, i, i, i], "tptCommInitLoopback": [i, i], "tptCommDestroy": [], "tptDrawSharded": [f, i, i, i, p, u], "tptDrawShardedBatch": [f, i, i, i, i, p, u], "tptDrawDeviceBatch": [f, i, i, i, i, p, u], "tptShardedFinish": [C.POINTER(C.c_int64)], "tptSetHostBufferMode": [i], "tptDebugLookaheadHits": [C.POINTER(C.c_longlong)], "tptSetHostLookahead": [i],
+        "tptDebugStats": [p, i], "tptDebugChunkOrder": [p, p, i], "tptTestMath": [i, p, p, p, i], "tptTestMathExhaustive": [i, u, u, p, p], "tptTestHitSpheres": [i, p, p, p, i], "tptTestMatrixFilter": [p, p, i], "tptGetLaunchInfo": [C.POINTER(i)] * 4, "tptGetPipelineInfo": [C.POINTER(i)] * 4, "tptCommGetUniqueId": [p], "tptCommInit": [p, i, i, i], "tptCommInitLoopback": [i, i], "tptCommDestroy": [], "tptDrawSharded": [f, i, i, i, p, u], "tptDrawShardedBatch": [f, i, i, i, i, p, u], "tptDrawDeviceBatch": [f, i, i, i, i, p, u], "tptShardedFinish": [C.POINTER(C.c_int64)], "tptSetHostBufferMode": [i], "tptDebugLookaheadHits": [C.POINTER(C.c_longlong)], "tptSetHostLookahead": [i],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -357,6 +357,15 @@ def test_math(op, a, b=None):
         bp = b.ctypes.data
     _chk(load_library().tptTestMath(op, a.ctypes.data, bp, out.ctypes.data, a.size), "tptTestMath")
     return out
+
+
+def test_math_exhaustive(op, lo=0, hi=0xFFFFFFFF):
+    """fast correctly-rounded sqrt (op 0) / 1/sqrt-then-reciprocal (op 1) vs the compiler's expansions for every bit
+    pattern in [lo, hi], on the device -> (mismatches, first offending inputs)"""
+    bad = C.c_ulonglong(0)
+    first = (C.c_uint * 8)()
+    _chk(load_library().tptTestMathExhaustive(op, lo, hi, C.byref(bad), first), "tptTestMathExhaustive")
+    return int(bad.value), [int(v) for v in first][: min(8, int(bad.value))]
 
 
 def test_hit_spheres(rays, hit_spheres=0):

@@ -1856,6 +1856,26 @@ int tptTestMath(int op, const float* a, const float* b, float* out, int n)
     return 0;
 }
 
+// The fast correctly-rounded sqrt / normalize scale of tpt_math.h against the compiler's expansions for EVERY bit pattern in
+// [lo, hi] (op 0: tsqrt, op 1: trsqrt2); returns the mismatch count and the first offending inputs.
+int tptTestMathExhaustive(int op, unsigned lo, unsigned hi, unsigned long long* outMismatches, unsigned* outFirst8)
+{
+    if (requireInit()) return -1;
+    if (!outMismatches || !outFirst8 || hi < lo || op < 0 || op > 1) return fail("tptTestMathExhaustive: bad arguments");
+    unsigned long long* dBad = nullptr;
+    unsigned* dFirst = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&dBad), sizeof(unsigned long long)));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&dFirst), sizeof(unsigned) * 8));
+    HIPCHK(hipMemsetAsync(dBad, 0, sizeof(unsigned long long), g.stream));
+    HIPCHK(hipMemsetAsync(dFirst, 0, sizeof(unsigned) * 8, g.stream));
+    HIPCHK(tptLaunchMathExhaustive(op, lo, hi, dBad, dFirst, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    HIPCHK(hipMemcpy(outMismatches, dBad, sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(outFirst8, dFirst, sizeof(unsigned) * 8, hipMemcpyDeviceToHost));
+    (void)hipFree(dBad); (void)hipFree(dFirst);
+    return 0;
+}
+
 // Phase 1 on the matrix cores alone: candidate masks (sphere p at bit 63 - p) of n host rays against the current scene
 // (<= 64 spheres).  The CPU tests hold the bit-exact restatement (phase1MatrixRef).
 int tptTestMatrixFilter(const float* rays, unsigned long long* outMask, int n)

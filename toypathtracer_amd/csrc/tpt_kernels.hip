@@ -1143,6 +1143,24 @@ __global__ void tptMathTestKernel(int op, const float* __restrict__ a, const flo
     out[i] = r;
 }
 
+// Exhaustive self-check of the fast correctly-rounded paths of tpt_math.h against the compiler's own correctly rounded
+// expansions, for every binary32 bit pattern in [lo, hi]: op 0 tsqrt(x) vs sqrtf(x), op 1 trsqrt2(x) vs 1.0f / sqrtf(x).
+// (NaN results compare equal to NaN.)  out[0] = mismatches, firstBad[0..7] = the first few offending inputs.
+__global__ void __launch_bounds__(256) tptMathExhaustiveKernel(int op, uint32_t lo, uint32_t hi, unsigned long long* nBad, uint32_t* firstBad)
+{
+    const uint64_t n = (uint64_t)hi - lo + 1;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t b = lo + (uint32_t)i;
+        const float x = u2f(b);
+        const float want = op == 0 ? __builtin_sqrtf(x) : 1.0f / __builtin_sqrtf(x);
+        const float got = op == 0 ? tsqrt(x) : trsqrt2(x);
+        if (f2u(got) != f2u(want) && !(got != got && want != want)) {
+            const unsigned long long k = atomicAdd(nBad, 1ull);
+            if (k < 8) firstBad[k] = b;
+        }
+    }
+}
+
 // rays: [n][6] orig,dir -> outId[n], outT[n]
 template <int HS>
 __global__ void tptHitTestKernel(const KernelArgs a, const float* __restrict__ rays, int* __restrict__ outId,
@@ -1380,6 +1398,11 @@ hipError_t tptLaunchResolveBatch(float* tile, const f4* frameColour, int nPixels
 hipError_t tptLaunchMathTest(int op, const float* a, const float* b, float* out, int n, hipStream_t stream)
 {
     hipLaunchKernelGGL(tptMathTestKernel, dim3((n + 255) / 256), dim3(256), 0, stream, op, a, b, out, n);
+    return hipGetLastError();
+}
+hipError_t tptLaunchMathExhaustive(int op, unsigned lo, unsigned hi, unsigned long long* nBad, unsigned* firstBad, hipStream_t stream)
+{
+    hipLaunchKernelGGL(tptMathExhaustiveKernel, dim3(8192), dim3(256), 0, stream, op, lo, hi, nBad, firstBad);
     return hipGetLastError();
 }
 hipError_t tptLaunchMatrixFilterTest(const KernelArgs& a, const float* rays, unsigned long long* outMask, int n, hipStream_t stream)

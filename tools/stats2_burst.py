@@ -26,5 +26,8 @@ for rep in range(2):
     print("  waves %d  mean lifetime %.3f ms  steps/wave %.0f  lane utilisation %.3f  batches/wave %.0f  wave-time per step %.2f us" % (
         st[109], st[108] / waves * 1e-5, st[106] / waves, st[107] / max(64.0 * st[106], 1), st[110] / waves, st[108] * 0.01 / max(st[106], 1)))
     tot = float(sum(st[112:117])) or 1.0
+    tot = float(sum(st[112:117])) or 1.0
+    print("  hitSpheres: phase 1 %.1f %% of wave time, phase 2 %.1f %%; phase-2 trips per step %.2f, lanes busy per trip %.1f" % (
+        100.0 * st[120] / tot, 100.0 * st[121] / tot, st[122] / max(st[106], 1), st[123] / max(st[122], 1)))
     print("  wave time: pick+pop %.1f %%  class code %.1f %%  intersect %.1f %%  push %.1f %%  idle %.1f %%" % tuple(100.0 * st[112 + k] / tot for k in range(5)))
 api.ShutdownTest()

@@ -731,21 +731,27 @@ __global__ void __launch_bounds__(TPT_Q_T, TPT_Q_MIN_WAVES_PER_SIMD) __attribute
 tptTraceQueueKernel(const KernelArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // LDS layout: everything of fixed size first, at compile-time offsets (immediates in the DS instructions instead of base
+    // registers): path records, rings, control block, frame constants; then the scene arrays, whose sizes the launch decides
+    constexpr int kOffQ = TPT_Q_NF4 * TPT_Q_P * 16;
+    constexpr int kOffCtl = kOffQ + Q_COUNT * TPT_Q_P * 2;
+    constexpr int kOffFc = kOffCtl + (((int)sizeof(QueueCtl) + 63) & ~63);
+    constexpr int kOffScene = kOffFc + (((int)sizeof(FrameConsts) + 15) & ~15);
+    f4* st = reinterpret_cast<f4*>(smem);
+    volatile unsigned short* q = reinterpret_cast<volatile unsigned short*>(smem + kOffQ);
+    QueueCtl* ctl = reinterpret_cast<QueueCtl*>(smem + kOffCtl);
+    // the frame constants the camera code reads (22 camera floats, 1/w, 1/h): in LDS, read where a sample starts, instead of
+    // ~30 SGPRs held (and spilled) across the whole loop
+    FrameConsts* ldsFc = reinterpret_cast<FrameConsts*>(smem + kOffFc);
     const int nPad = a.scene.nPairs * 2;
-    f4* ldsSph = reinterpret_cast<f4*>(smem);
-    int off = LDS_SCENE ? nPad * 16 : 0;
+    f4* ldsSph = reinterpret_cast<f4*>(smem + kOffScene);
+    int off = kOffScene + (LDS_SCENE ? nPad * 16 : 0);
     float* ldsInvR = reinterpret_cast<float*>(smem + off);
     off += LDS_SCENE ? ((nPad * 4 + 15) & ~15) : 0;
     f4* ldsLights = reinterpret_cast<f4*>(smem + off);
     off += a.scene.nLights * 32;
     f4* ldsMats = reinterpret_cast<f4*>(smem + off);
     off += LDS_SCENE ? a.scene.nSpheres * 48 : 0;
-    f4* st = reinterpret_cast<f4*>(smem + off);
-    off += TPT_Q_NF4 * TPT_Q_P * 16;
-    volatile unsigned short* q = reinterpret_cast<volatile unsigned short*>(smem + off);
-    off += Q_COUNT * TPT_Q_P * 2;
-    QueueCtl* ctl = reinterpret_cast<QueueCtl*>(smem + off);
-    off += (int)sizeof(QueueCtl) + 64 - (int)sizeof(QueueCtl) % 64;
 #if TPT_MATRIX_FILTER
     // phase 1 on the matrix cores (scenes of <= 64 spheres): the A-operand table, 3 KB
     const bool useMatrix = LDS_SCENE && a.scene.mxR1 >= 0;
@@ -771,6 +777,10 @@ tptTraceQueueKernel(const KernelArgs a)
         for (int i = tid; i < 2 * 6 * 64; i += TPT_Q_T) ldsA[i] = a.scene.amat[i];
     const int mxR1 = a.scene.mxR1;
 #endif
+#if defined(__HIP_DEVICE_COMPILE__) && defined(TPT_STATS) && TPT_STATS >= 2
+    if (tid < 4) g_hsLds[tid] = 0ull;
+#endif
+    for (int i = tid; i < (int)(sizeof(FrameConsts) / 4); i += TPT_Q_T) reinterpret_cast<uint32_t*>(ldsFc)[i] = reinterpret_cast<const uint32_t*>(&a.fc)[i];
     // every path starts in the FREE queue; all other queues empty (sentinel everywhere)
     for (int i = tid; i < Q_COUNT * TPT_Q_P; i += TPT_Q_T) q[i] = (unsigned short)(i < TPT_Q_P ? i : 0xFFFF);
     if (tid < 8) {
@@ -955,7 +965,7 @@ tptTraceQueueKernel(const KernelArgs a)
                 const uint32_t where = BATCH ? ((uint32_t)px | ((uint32_t)py << 13) | ((uint32_t)laneFrame << 26))
                                              : ((uint32_t)px | ((uint32_t)py << 16));
                 colSum[p] = mk4(0.0f, 0.0f, 0.0f, u2f(where));
-                qCamera(fc, px, py, rng, ro, rd);
+                qCamera(*ldsFc, px, py, rng, ro, rd);
                 ray = true;
             } else if (mine) {
                 toFree = true; // no pixel left for this path
@@ -980,7 +990,7 @@ tptTraceQueueKernel(const KernelArgs a)
                 sample++;
                 if (sample < fc.spp) {
                     colSum[p] = mk4(col.x, col.y, col.z, c3.w);
-                    qCamera(fc, px, py, rng, ro, rd);
+                    qCamera(*ldsFc, px, py, rng, ro, rd);
                     depth = 0;
                     doMatE = true;
                     ray = true;
@@ -1103,6 +1113,10 @@ tptTraceQueueKernel(const KernelArgs a)
             a.work[1] = 0u;
         }
     }
+#if defined(__HIP_DEVICE_COMPILE__) && defined(TPT_STATS) && TPT_STATS >= 2
+    __syncthreads();
+    if (tid < 4) TPT_COUNT(120 + tid, g_hsLds[tid]);
+#endif
 #if defined(TPT_STATS)
     if (lane == 0) {
         const unsigned long long qT1 = wall_clock64();
@@ -1323,7 +1337,7 @@ size_t tptQueueLdsBytes(const KernelArgs& a, bool ldsScene)
     size_t bytes = 0;
     if (ldsScene) bytes += (size_t)nPad * 16 + (((size_t)nPad * 4 + 15) & ~(size_t)15) + (size_t)a.scene.nSpheres * 48;
     bytes += (size_t)a.scene.nLights * 32;
-    bytes += (size_t)TPT_Q_NF4 * TPT_Q_P * 16 + (size_t)Q_COUNT * TPT_Q_P * 2 + sizeof(QueueCtl) + 64;
+    bytes += (size_t)TPT_Q_NF4 * TPT_Q_P * 16 + (size_t)Q_COUNT * TPT_Q_P * 2 + ((sizeof(QueueCtl) + 63) & ~(size_t)63) + ((sizeof(FrameConsts) + 15) & ~(size_t)15);
 #if TPT_MATRIX_FILTER
     if (ldsScene && a.scene.mxR1 >= 0) bytes += 2 * 6 * 64 * sizeof(float) + 64;
 #endif

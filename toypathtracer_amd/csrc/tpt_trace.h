@@ -238,6 +238,39 @@ TPT_HD uint64_t phase1Chunk(PairPtr rec, int cnt, v2f ox, v2f oy, v2f oz, v2f dx
 // Measured alternatives (profiles/r01/run8*.log, run9*.log): scalar VOP2 arithmetic instead of packed VOP3P is
 // a wash (packed ops issue at half rate on gfx950); software-pipelining the scalar loads one 4-pair block
 // ahead costs 64 more SGPRs, spills, and is 8-15 % slower than letting 3-4 waves per SIMD hide the latency.
+// profiling build (-DTPT_STATS=2): s_memtime around the two phases, [120] phase-1 ticks, [121] phase-2 ticks,
+// [122] phase-2 trips of a wave, [123] lanes busy in them (first active lane adds for the wave)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(TPT_STATS) && TPT_STATS >= 2
+#define TPT_HS_STAMP(v)                    \
+    __builtin_amdgcn_sched_barrier(0);     \
+    __builtin_amdgcn_s_waitcnt(0);         \
+    const unsigned long long v = __builtin_amdgcn_s_memtime(); \
+    __builtin_amdgcn_sched_barrier(0)
+__shared__ unsigned long long g_hsLds[4]; // per-workgroup sums, flushed to g_tptStats[120..123] when the workgroup ends
+#define TPT_HS_FIRST() ((int)__ffsll((long long)__ballot(1)) - 1 == (int)(threadIdx.x & 63))
+#define TPT_HS_TRIP() (hsTrips_++)
+#define TPT_HS_ADD(a, b, c)                                                                                         \
+    do {                                                                                                            \
+        const unsigned long long act_ = __ballot(1);                                                                \
+        unsigned sum_ = hsTrips_, max_ = hsTrips_;                                                                  \
+        for (int off_ = 32; off_ > 0; off_ >>= 1) {                                                                 \
+            const unsigned os_ = __shfl_xor(sum_, off_, 64), om_ = __shfl_xor(max_, off_, 64);                      \
+            const bool ok_ = (act_ >> ((threadIdx.x & 63) ^ off_)) & 1ull;                                          \
+            sum_ += ok_ ? os_ : 0u;                                                                                 \
+            max_ = (ok_ && om_ > max_) ? om_ : max_;                                                                \
+        }                                                                                                           \
+        if (TPT_HS_FIRST()) {                                                                                       \
+            atomicAdd(&g_hsLds[0], (b) - (a));                                                                 \
+            atomicAdd(&g_hsLds[1], (c) - (b));                                                                 \
+            atomicAdd(&g_hsLds[2], (unsigned long long)max_);                                                  \
+            atomicAdd(&g_hsLds[3], (unsigned long long)sum_);                                                  \
+        }                                                                                                           \
+    } while (0)
+#else
+#define TPT_HS_STAMP(v) do { } while (0)
+#define TPT_HS_TRIP() do { } while (0)
+#define TPT_HS_ADD(a, b, c) do { } while (0)
+#endif
 TPT_HD int hitSpheresTwoPhase(const SceneView& sv, f3 o, f3 d, float tMin, float tMax, float& outT)
 {
     float hitT = tMax;
@@ -248,14 +281,21 @@ TPT_HD int hitSpheresTwoPhase(const SceneView& sv, f3 o, f3 d, float tMin, float
     for (int pb = 0; pb < sv.nPairs; pb += 32) { // chunks of 64 spheres
         int cnt = sv.nPairs - pb;
         if (cnt > 32) cnt = 32;
+        unsigned hsTrips_ = 0;
+        (void)hsTrips_;
+        TPT_HS_STAMP(t0_);
         uint64_t cand = phase1Chunk(pairPtr(sv.pairs + (size_t)pb * 8), cnt, ox, oy, oz, dx, dy, dz);
+        TPT_HS_STAMP(t1_);
         while (cand) {
             int k = __builtin_clzll(cand);
             cand &= ~(0x8000000000000000ull >> k);
             int i = pb * 2 + k;
             TPT_STAT(ST_PHASE2);
+            TPT_HS_TRIP();
             testSphere(sv.sph4[i], i, o, d, tMin, hitT, id);
         }
+        TPT_HS_STAMP(t2_);
+        TPT_HS_ADD(t0_, t1_, t2_);
     }
     outT = hitT;
     return id;

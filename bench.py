@@ -10,17 +10,23 @@ A step = UpdateTest + DrawTest of ONE frame of the workload (default: BASELINE.j
 buffer resident in HBM when the timed region starts.  Mray/s = rays (HitWorld calls: camera + bounce +
 shadow, exactly the reference's counter, Test.cpp:122,199) of the K timed frames, summed over all
 ranks, divided by the max-over-ranks wall time between two barrier+synchronize brackets.
-For N > 1 the frame's rows are dealt out in 8-row stripes round-robin over the ranks
-(toypathtracer_amd/sharding.py); every step includes its exchange (one RCCL gather of the tiles to
-rank 0 + one 8-byte sum-reduce of the ray counters), software-pipelined against the next frame.
-Total work is fixed as N grows -> "scaling": "strong".
+For N > 1 the frame's rows are dealt out in 8-row stripes round-robin over the ranks and every step
+includes its exchange -- ONE RCCL gather to rank 0 of each rank's blended tile plus a row carrying its
+64-bit ray counter, software-pipelined against the next frames.  By default that exchange is the
+product's own: the C ABI a Test.h host uses (tptCommGetUniqueId / tptCommInit / tptDrawSharded /
+tptShardedFinish, include/tpt_hip.h section 3; the 128-byte id travels over torch.distributed's
+store) -- "exchange": "cabi" in the JSON line.  --exchange torch drives the torch.distributed twin
+(toypathtracer_amd/sharding.py) instead.  Total work is fixed as N grows -> "scaling": "strong".
 
 One JSON line on rank 0, with
   roofline     : the trace kernel against the HBM roofline the north_star names (algorithmic bytes =
                  W*H*16 B written per frame) -- plus the FP32 VALU fraction, which is what actually binds;
                  durations from HIP events on the kernel's stream over the timed region;
   cpu_baseline : the pristine reference (oracle/_ref, SIMD path, all host cores via enkiTS) timed on
-                 the same workload for a bounded ~10 s sample, rank 0 at N = 1 only.
+                 the same workload for a bounded ~10 s sample, rank 0 at N = 1 only;
+  image_fnv / parity_checked : FNV-1a-32 of the final float image of THIS run, and whether it (and the
+                 run's ray total) equalled the oracle's render of the same frames (untimed checker leg,
+                 like cpu_baseline; default scene, runs of up to 64 frames).
 """
 import argparse
 import json
@@ -115,6 +121,26 @@ def cpu_baseline(width, height, spp, budget_s=5.0):
                 sample="%d frames of %dx%dx%dspp, oracle/tpt_oracle.c (OpenMP over rows), %.1f s" % (frames, width, height, spp, dt))
 
 
+def image_parity(image, rays_total, width, height, spp, frames, max_frames=64):
+    """Checker leg (untimed, never the product path): the final image of the run that was just timed -- every frame from
+    frame 0 on a zeroed tile -- against the oracle's PER_PIXEL render of the same frames, byte for byte, ray totals equal.
+    -> dict for the JSON line."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import SEED_PER_PIXEL, Oracle, fnv1a
+    img = np.ascontiguousarray(image.detach().cpu().numpy() if hasattr(image, "detach") else image, np.float32)
+    out = {"image_fnv": "%08x" % fnv1a(img), "parity_checked": False}
+    if frames > max_frames:
+        out["parity_note"] = "run of %d frames: the oracle leg is bounded to %d (use --parity-frames to raise it)" % (frames, max_frames)
+        return out
+    t0 = time.perf_counter()
+    ro, bo = Oracle.get().render_frames(width, height, spp, frames, seed_mode=SEED_PER_PIXEL)
+    out.update(parity_checked=True, parity_ok=bool(img.tobytes() == bo.tobytes() and int(rays_total) == int(ro)),
+               oracle_fnv="%08x" % fnv1a(bo), oracle_rays=int(ro), run_rays=int(rays_total), parity_frames=frames,
+               parity_seconds=time.perf_counter() - t0,
+               parity_note="final image + ray total of this run (frames 0..%d, zeroed tile) vs oracle/tpt_oracle.c, PER_PIXEL seeds, bytes equal" % (frames - 1))
+    return out
+
+
 def drawtest_host_path(api, width, height, frames=24):
     """The reference's own contract: synchronous DrawTest on a HOST backbuffer (upload + trace + blend + download)."""
     bb = np.zeros((height, width, 4), np.float32)
@@ -205,6 +231,11 @@ def main():
                     help="trace kernels of up to this many consecutive frames may be in flight (0 = auto: 16, or 8 when the frame is "
                          "sharded over more than 2 ranks -- with small tiles the per-packet latency of many active queues costs more "
                          "than the extra overlap buys)")
+    ap.add_argument("--exchange", default="auto", choices=["auto", "none", "cabi", "torch"],
+                    help="how a sharded frame is exchanged: cabi = the library's own RCCL gather (tptCommInit / tptDrawSharded / "
+                         "tptShardedFinish, what a C++ Test.h host uses; default for N > 1), torch = toypathtracer_amd/sharding.py over "
+                         "torch.distributed, none = no exchange (default for N = 1: plain tptDrawDevice)")
+    ap.add_argument("--parity-frames", type=int, default=64, help="check the final image against the oracle when the run has at most this many frames (0 = never)")
     ap.add_argument("--prime", type=int, default=-1,
                     help="untimed frames rendered BEFORE the warm-up so that the frame pipeline (buffers of all slots, the library's "
                          "estimate of how deep this caller pipelines) is in its steady state when warm-up and timing start; "
@@ -224,10 +255,11 @@ def main():
     device = torch.device("cuda", local_rank)
     os.environ.setdefault("TPT_DEVICE", str(local_rank))
     dist = None
-    if world > 1:
+    if world > 1 or args.exchange == "torch":  # (--exchange torch at world size 1: a one-rank process group, so the gather path really runs)
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from toypathtracer_amd import api
@@ -248,35 +280,71 @@ def main():
         api.set_scene(s, m)
         api.set_camera(**STRESS_CAMERA)
         n_spheres = 4096
-    api.set_row_shard(args.stripe_rows, world, rank)
-
-    sf = ShardedFrame(width, height, args.stripe_rows, rank, world, device, dist)
-    api.set_stream(sf.render_stream.cuda_stream)
-    api.set_ray_counter(sf.ray_counter.data_ptr())
-    tile_ptr = sf.tile.data_ptr()
-
+    exchange = args.exchange
+    if exchange == "auto":
+        exchange = "cabi" if world > 1 else "none"
+    if exchange == "none" and world > 1:
+        sys.exit("--exchange none needs --gpus 1")
     flags = FLAG_PROGRESSIVE | (FLAG_ANIMATE if args.animate else 0)
-
-    def step(frame):
-        t = frame / 60.0 if args.animate else 0.0
-        mirror = sf.mirror_pointers()  # sharded: the resolve kernel also fills the snapshot the gather sends
-        if mirror:
-            sf.begin_frame()
-            api.set_tile_mirror(*mirror)
-        api.UpdateTest(t, frame, width, height, flags)
-        if args.batch > 1:
-            api.draw_device_batch(t, frame, args.batch, width, height, tile_ptr, flags)
-        else:
-            api.draw_device(t, frame, width, height, tile_ptr, flags)
-        sf.exchange(snapshot_done=bool(mirror))
-
-    def fence():
-        sf.render_stream.synchronize()
-        sf.comm_stream.synchronize()
-        torch.cuda.synchronize()
+    sf = None
+    image_on_root = None
+    if exchange == "cabi":
+        # the product's own multi-GPU path: RCCL inside the library, nothing of torch.distributed in the data path
+        uid = [api.comm_get_unique_id() if rank == 0 else None]
         if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
+            dist.broadcast_object_list(uid, src=0, device=device)
+        api.comm_init(uid[0], world, rank, args.stripe_rows)
+        image_on_root = torch.zeros((height, width, 4), dtype=torch.float32, device=device)
+        img_ptr = image_on_root.data_ptr()
+
+        def step(frame):
+            t = frame / 60.0 if args.animate else 0.0
+            api.UpdateTest(t, frame, width, height, flags)
+            if args.batch > 1:
+                api.draw_sharded_batch(t, frame, args.batch, width, height, img_ptr, flags)
+            else:
+                api.draw_sharded(t, frame, width, height, img_ptr, flags)
+
+        def rays_so_far():  # rank 0: sum over the ranks as of the last gathered frame; others: their own (both exact after a drain)
+            return api.sharded_finish()
+
+        def fence():
+            api.sharded_finish()
+            api.synchronize()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+    else:
+        api.set_row_shard(args.stripe_rows, world, rank)
+        sf = ShardedFrame(width, height, args.stripe_rows, rank, world, device, dist)
+        api.set_stream(sf.render_stream.cuda_stream)
+        api.set_ray_counter(sf.ray_counter.data_ptr())
+        tile_ptr = sf.tile.data_ptr()
+
+        def step(frame):
+            t = frame / 60.0 if args.animate else 0.0
+            mirror = sf.mirror_pointers()  # sharded: the resolve kernel also fills the snapshot the gather sends
+            if mirror:
+                sf.begin_frame()
+                api.set_tile_mirror(*mirror)
+            api.UpdateTest(t, frame, width, height, flags)
+            if args.batch > 1:
+                api.draw_device_batch(t, frame, args.batch, width, height, tile_ptr, flags)
+            else:
+                api.draw_device(t, frame, width, height, tile_ptr, flags)
+            sf.exchange(snapshot_done=bool(mirror))
+
+        def rays_so_far():
+            return int(sf.ray_counter.item())
+
+        def fence():
+            sf.render_stream.synchronize()
+            sf.comm_stream.synchronize()
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
 
     if args.prime < 0:
         args.prime = args.overlap
@@ -293,7 +361,7 @@ def main():
     for f in range(args.prime, args.prime + args.warmup, B):
         step(f)
     fence()
-    rays0 = int(sf.ray_counter.item())
+    rays0 = rays_so_far()
     api.kernel_timing_begin(args.steps // B)  # a HIP event pair around every trace launch, on the stream it is launched on
     api.timer_begin()                     # + one pair around the whole timed region on the context's stream
     t0 = time.perf_counter()
@@ -304,8 +372,16 @@ def main():
     dt = time.perf_counter() - t0
     launch_ms_sum, launches = api.kernel_timing_end()
     kernel_ms = launch_ms_sum / max(launches, 1) * args.steps  # = steps x average duration of one trace launch (a launch of --batch frames counts once per frame: trace_launch_ms_avg is per LAUNCH)
-    rays_local = int(sf.ray_counter.item()) - rays0
-    image, _total = sf.finish()
+    rays_end = rays_so_far()
+    rays_local = rays_end - rays0
+    if exchange == "cabi":
+        image = image_on_root
+        rays_all_frames = rays_end  # rank 0: every rank's rays since tptInitialize
+        if rank != 0:
+            rays_local = 0  # rank 0's difference already is the sum over the ranks (the counters ride in the gathered tiles)
+    else:
+        image, _total = sf.finish()
+        rays_all_frames = None
 
     stats = torch.tensor([dt, float(rays_local), kernel_ms, pipeline_ms], dtype=torch.float64, device=device)
     if dist is not None:
@@ -314,8 +390,13 @@ def main():
         tsum = stats.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt, rays_total, kernel_ms, pipeline_ms = float(tmax[0]), float(tsum[1]), float(tmax[2]), float(tmax[3])
+        if rays_all_frames is None:
+            tot = torch.tensor([float(rays_end)], dtype=torch.float64, device=device)
+            dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+            rays_all_frames = int(tot[0])
     else:
         rays_total = float(rays_local)
+        rays_all_frames = rays_end
 
     if rank == 0:
         info = api.launch_info()
@@ -329,14 +410,20 @@ def main():
         rays_per_launch = rays_total / args.steps / world * args.batch
         hbm_write_gbs = px * 16 / (k_ms * 1e-3) / 1e9      # 16 B written per pixel
         valu_tflops = rays_per_launch * FLOP_PER_SPHERE_TEST * n_spheres / (k_ms * 1e-3) / 1e12
-        traffic = None
+        # HBM traffic per trace launch: counter passes serialise kernels and cannot run inside the timed region, so the
+        # figure is a STATIC one from profiles/pmc_traffic.json -- and only the entry measured for this workload at this
+        # very launch geometry (workgroups per launch); no entry -> null, never a neighbour's number.
+        traffic, traffic_src = None, "profiles/pmc_traffic.json has no entry for (%s, %d workgroups per launch)" % (args.workload, info["grid_blocks"])
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get(args.workload if args.persistent == 3 else "%s_persist%d" % (args.workload, args.persistent))
+        if os.path.exists(tpath) and args.persistent == 3 and args.batch == 1 and world == 1:
+            ent = json.load(open(tpath)).get("by_workload_and_grid", {}).get(args.workload, {}).get(str(info["grid_blocks"]))
+            if ent:
+                traffic, traffic_src = ent["bytes_per_launch"], ent["source"]
         out = {
             "metric": "Mray/s", "value": rays_total / dt / 1e6, "unit": "Mray/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "exchange": exchange, "rccl_ranks": world if exchange != "none" else 0,
             "config": {"workload": label, "width": width, "height": height, "spp": spp, "spheres": n_spheres,
                        "seed_mode": "per_pixel", "fold": "forward" if args.fold else "recursive",
                        "hit_spheres": ["two_phase" + ("+groups" if n_spheres >= 256 else ""), "simple", "two_phase_brute_force", "two_phase"][args.hit_spheres], "kernel": ["thread_per_pixel", "persistent_waves", "lane_sorting", "path_queues"][args.persistent], "frame_overlap": args.overlap, "frames_per_launch": args.batch,
@@ -353,10 +440,11 @@ def main():
             # pipeline (ms_per_step measured by HIP events on the render stream) -- up to `frame_overlap` launches share
             # the GPU, so bytes / one launch's own duration (frac_per_launch) understates the chip by that factor
             "roofline": {"bound": "hbm", "achieved": hbm_write_gbs * k_ms / pl_ms, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": hbm_write_gbs * k_ms / pl_ms / PEAK_HBM_GBS, "traffic": (traffic or {}).get("bytes_per_launch") if isinstance(traffic, dict) else traffic,
-                         "traffic_static": True,
+                         "frac": hbm_write_gbs * k_ms / pl_ms / PEAK_HBM_GBS, "traffic": traffic,
+                         "traffic_static": True, "traffic_source": traffic_src,
                          "traffic_note": ("NOT measured in this run: bytes per trace launch on the L2's fabric side (WRITE_SIZE + 2 x FETCH_SIZE, "
-                                          "separate rocprofv3 --pmc passes of this same command, profiles/pmc_traffic.json names the run)"),
+                                          "separate rocprofv3 --pmc passes, tools/traffic.sh) taken for this workload at THIS launch geometry "
+                                          "(config.grid_blocks workgroups per launch); null when no such measurement is on file"),
                          "achieved_per_launch": hbm_write_gbs, "frac_per_launch": hbm_write_gbs / PEAK_HBM_GBS,
                          "achieved_read_plus_write": 2 * hbm_write_gbs * k_ms / pl_ms, "launch_ms_avg": k_ms, "launches": launches,
                          "note": "north_star's HBM-write roofline (W*H*16 B per frame).  The kernel is FP32-VALU bound (arithmetic "
@@ -371,7 +459,12 @@ def main():
                                       + ("; this scene is traversed through sphere groups, so the figure is the brute-force-EQUIVALENT rate "
                                          "(most of those tests are never executed)" if (n_spheres >= 256 and args.hit_spheres == 0) else "")},
         }
-        if world == 1 and not args.no_extras:
+        total_frames = args.prime + args.warmup + args.steps
+        if scene == "default" and not args.animate and args.parity_frames > 0:
+            out.update(image_parity(image, rays_all_frames, width, height, spp, total_frames, args.parity_frames))
+        else:
+            out.update(parity_checked=False, parity_note="oracle leg runs for the static default scene only (this workload's parity: tests/test_gpu_parity.py)")
+        if world == 1 and exchange != "cabi" and not args.no_extras:
             # the same workload through the reference's own contract (host backbuffer, synchronous) and in its own seed mode
             api.set_ray_counter(None)
             api.set_stream(None)
@@ -401,6 +494,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(width, height, spp)
         print(json.dumps(out), flush=True)
 
+    if exchange == "cabi":
+        api.comm_destroy()
     api.set_tile_mirror(None)
     api.set_ray_counter(None)
     api.set_stream(None)

@@ -294,6 +294,30 @@ def test_bench_runs_on_two_ranks_over_rccl(tmp_path):
                                    "--warmup", "4", "--no-cpu-baseline"], stderr=subprocess.DEVNULL, env=env, timeout=600).decode()
     line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 2 and line["value"] > 1000
+    assert line["exchange"] == "cabi" and line["rccl_ranks"] == 2  # the driver's command times the C-ABI exchange
+    assert line["parity_checked"] and line["parity_ok"]
+
+
+def test_bench_exchanges_agree_at_world_size_one():
+    """bench.py's three data paths at world size 1 -- no exchange (plain tptDrawDevice), the library's own RCCL exchange
+    (tptCommInit / tptDrawSharded / tptShardedFinish: a real one-rank RCCL communicator) and the torch.distributed twin --
+    give the same final image (FNV-1a of the float buffer) and the same ray total, and each equals the oracle (the bench's
+    own checker leg)."""
+    import json
+    import sys
+    lines = {}
+    for ex in ("none", "cabi", "torch"):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+        out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--prime", "3",
+                                       "--workload", "c1", "--exchange", ex, "--no-cpu-baseline", "--no-extras"], stderr=subprocess.DEVNULL, env=env,
+                                      timeout=600).decode()
+        lines[ex] = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+    for ex, line in lines.items():
+        assert line["exchange"] == ex and line["rccl_ranks"] == (0 if ex == "none" else 1)
+        assert line["parity_checked"] and line["parity_ok"], (ex, line.get("parity_note"))
+        assert line["image_fnv"] == lines["none"]["image_fnv"] == line["oracle_fnv"]
+        assert line["run_rays"] == lines["none"]["run_rays"] == line["oracle_rays"]
+        assert line["value"] > 100
 
 
 def test_draw_sharded_in_process_single_rank(tpt_defaults, oracle):

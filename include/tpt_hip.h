@@ -215,10 +215,11 @@ int tptTestHitSpheres(int hitSpheres, const float* rays, int* outId, float* outT
 /* self-check: tpt_math.h's fast correctly-rounded sqrt (op 0) / 1.0f / sqrtf (op 1) against the compiler's correctly rounded
  * expansions for EVERY binary32 bit pattern in [lo, hi] on the device; mismatch count + the first offending inputs */
 int tptTestMathExhaustive(int op, unsigned lo, unsigned hi, unsigned long long* outMismatches, unsigned* outFirst8);
-/* phase 1 of HitSpheres evaluated on the matrix cores (v_mfma_f32_32x32x2_f32 over a 12-term expansion of the filter's
- * discriminant; scenes of <= 64 spheres): candidate masks, sphere p at bit 63 - p, of n host rays.  A measured-and-rejected
- * variant kept as a unit-tested building block; the shipped kernels run the packed-VALU filter. */
-int tptTestMatrixFilter(const float* rays, unsigned long long* outMask, int n);
+/* phase 1 of HitSpheres as the path-queue kernel runs it for scenes of <= 64 spheres: on the matrix cores
+ * (v_mfma_f32_32x32x16_f16 over an 11-term expansion of the filter's discriminant, every f32 factor split into two binary16
+ * pieces).  n host rays -> candidate masks (sphere p at bit 63 - p; may be NULL) and / or the nearest hit through the filter
+ * + the exact test of its candidates (outId / outT; may be NULL). */
+int tptTestMatrixFilter(const float* rays, unsigned long long* outMask, int* outId, float* outT, int n);
 /* kernel resource facts for DESIGN/bench: occupancy (blocks/CU), LDS bytes/block, grid size of the last launch */
 int tptGetLaunchInfo(int* outBlocksPerCU, int* outLdsBytes, int* outGridBlocks, int* outNumCUs);
 /* Facts about the frame pipeline: hardware queues the runtime really runs side by side for this process (measured at

@@ -1,5 +1,6 @@
 // tests/adversarial_filter.cpp -- TEST HARNESS ONLY.  Randomised adversarial search: does the conservative phase-1 filter
-// (memberFilter = the per-lane form of phase1Pair) or the group-bound filter of hitSpheresGrouped ever reject a sphere
+// (memberFilter = the per-lane form of phase1Pair), the group-bound filter of hitSpheresGrouped or the matrix-core filter
+// (phase1MatrixH, worst case of its error model) ever reject a sphere
 // the reference's discriminant accepts?  Near-tangent rays, centre distances 1e-2..1e4, radii down to 1e-3 of that,
 // offsets 1e-9..1e-2 radii on both sides, group bounds with |c - C| / r up to 64.  Exit code 1 on any miss.
 #include <stdio.h>
@@ -10,8 +11,8 @@ using namespace tpt;
 static inline double urand(uint64_t& s) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return (double)(s >> 11) * (1.0 / 9007199254740992.0); }
 int main(int argc, char** argv) {
     long long N = argc > 1 ? atoll(argv[1]) : 200000000LL;
-    long long bad = 0, refpos = 0, filtpos = 0, badGroup = 0, badMatrix = 0, matrixpos = 0;
-#pragma omp parallel reduction(+:bad,refpos,filtpos,badGroup,badMatrix,matrixpos)
+    long long bad = 0, refpos = 0, filtpos = 0, badGroup = 0, badMatrix = 0, matrixpos = 0, matrixTested = 0;
+#pragma omp parallel reduction(+:bad,refpos,filtpos,badGroup,badMatrix,matrixpos,matrixTested)
     {
         uint64_t s = 0x9E3779B97F4A7C15ull * (omp_get_thread_num() + 1);
 #pragma omp for schedule(static)
@@ -40,15 +41,29 @@ int main(int argc, char** argv) {
             bool filt = memberFilter(sp, of, dk);
             refpos += ref; filtpos += filt;
             if (ref && !filt) bad++;
-            // matrix-core filter (phase1Matrix): the sphere alone in a table, same a_k / b_k / fmaf chain as the device
+            // matrix-core filter (phase1MatrixH): the sphere's 32 A-side slot values as packScene builds them, the ray's as the
+            // device packs them; the MFMA's accumulation is the hardware's, so the WORST CASE the error model allows is
+            // tested: exact slot sum (binary64) minus 64 u x (sum of the slot products' magnitudes) must not be negative.
+            // Spheres / rays outside binary16 range have no table / keep every candidate: nothing to miss there.
             {
-                float am[TPT_MX_K], bm[TPT_MX_K], cm = 0.0f;
+                float am[TPT_MX_K], bm[TPT_MX_K], bs[TPT_MXH_SLOTS], as[TPT_MXH_SLOTS];
                 matrixSphereSide(sp.x, sp.y, sp.z, sp.w, am);
                 matrixRaySide(of, df, bm);
-                for (int k = 0; k < TPT_MX_K; ++k) cm = fma1(am[k], bm[k], cm);
-                const bool mf = (f2u(cm) >> 31) == 0u;
-                matrixpos += mf;
-                if (ref && !mf) badMatrix++;
+                bool inRange = matrixRayInRange(of, bm);
+                for (int k = 0; k < 10; ++k) inRange = inRange && fabsf(am[k]) < 60000.0f;
+                if (inRange) {
+                    matrixRaySlots(bm, bs);
+                    float hi[10], lo[10];
+                    for (int k = 0; k < 10; ++k) { hi[k] = f16val(f16rtz(am[k])); lo[k] = f16val(f16rtz(am[k] - hi[k])); }
+                    for (int t = 0; t < TPT_MXH_TERMS; ++t) { as[2 * t] = hi[t]; as[2 * t + 1] = hi[t]; }
+                    for (int u = 0; u < 4; ++u) { as[18 + 2 * u] = lo[2 * u]; as[19 + 2 * u] = lo[2 * u + 1]; }
+                    as[26] = lo[8]; as[27] = 1.0f; as[28] = 1.0f; as[29] = hi[9]; as[30] = lo[9]; as[31] = 0.0f;
+                    double sum = 0.0, mag = 0.0;
+                    for (int k = 0; k < TPT_MXH_SLOTS; ++k) { const double pr = (double)as[k] * (double)bs[k]; sum += pr; mag += fabs(pr); }
+                    const bool mf = sum - 64.0 * 5.9604644775390625e-08 * mag >= 0.0;
+                    matrixpos += mf; matrixTested++;
+                    if (ref && !mf) badMatrix++;
+                }
             }
             // group filter: a bounding sphere R = a + r around a centre displaced by a (rho = a / r up to 64)
             double rho = 64 * urand(s), a = rho * r, R = (a + r) * 1.00001;
@@ -65,7 +80,7 @@ int main(int argc, char** argv) {
             if (ref && !gf) badGroup++;
         }
     }
-    printf("trials %lld  reference accepts %lld  filter passes %lld  matrix filter passes %lld  FILTER MISSES %lld  GROUP FILTER MISSES %lld  MATRIX FILTER MISSES %lld\n",
-           N, refpos, filtpos, matrixpos, bad, badGroup, badMatrix);
-    return bad || badGroup || badMatrix ? 1 : 0;
+    printf("trials %lld  reference accepts %lld  filter passes %lld  matrix filter passes %lld of %lld in binary16 range  FILTER MISSES %lld  GROUP FILTER MISSES %lld  MATRIX FILTER MISSES %lld\n",
+           N, refpos, filtpos, matrixpos, matrixTested, bad, badGroup, badMatrix);
+    return bad || badGroup || badMatrix || matrixTested * 4 < N ? 1 : 0;
 }

@@ -82,3 +82,23 @@ def grazing_rays(spheres, n, seed=11):
     d = tan.astype(np.float32)
     d = (d / np.linalg.norm(d.astype(np.float64), axis=1, keepdims=True)).astype(np.float32)
     return np.concatenate([o.astype(np.float32), d], 1).astype(np.float32)
+
+
+def matrix_scene(oracle, n, seed=3):
+    """n (<= 64) spheres the matrix-core filter has a table for (every |a_k| in binary16 range): the first spheres of the
+    built-in scene (ground r = 100 included), then copies of them shifted and shrunk at random."""
+    s0, m0 = oracle.default_scene()
+    rng = np.random.default_rng(seed)
+    k = max(0, n - len(s0))
+    s, m = s0[: min(n, len(s0))].copy(), m0[: min(n, len(s0))].copy()
+    if k:
+        idx = rng.integers(1, len(s0), k)
+        es, em = s0[idx].copy(), m0[idx].copy()
+        es["cx"] += rng.uniform(-3, 3, k).astype(np.float32)
+        es["cy"] += rng.uniform(0.5, 3, k).astype(np.float32)
+        es["cz"] += rng.uniform(-3, 3, k).astype(np.float32)
+        es["radius"] *= rng.uniform(0.3, 1.0, k).astype(np.float32)
+        em["emissive"][:] = 0  # keep the light list short
+        s, m = np.concatenate([s, es]), np.concatenate([m, em])
+    s["invRadius"] = np.float32(1.0) / s["radius"]
+    return s, m

@@ -44,6 +44,7 @@ int64_t emu_render_ex(const void* spheres, const void* mats, int count, const vo
     packScene(S, M, P);
     SceneView sv = viewOf(P);
     if (hs == 2) sv.nGroups = 0; // two-phase, brute force even for a large scene
+    if (hs == 3) sv.mxR1 = -1;   // the packed VALU filter everywhere (tptSetKernelVariant(3, ., .))
     CameraPOD c;
     memcpy(&c, cam, sizeof(c));
     FrameConsts fc = makeFrameConsts(c, w, h, spp, frame, flags, seedMode, g_emuConfig, g_emuSmoothing);
@@ -67,7 +68,7 @@ int64_t emu_render_ex(const void* spheres, const void* mats, int count, const vo
                 if (hs == HS_SIMPLE)
                     done = fold == FOLD_FORWARD ? laneStep<HS_SIMPLE, FOLD_FORWARD>(L, sv, fc, stack)
                                                 : laneStep<HS_SIMPLE, FOLD_RECURSIVE>(L, sv, fc, stack);
-                else if (hs == HS_MATRIX && sv.mxR1 >= 0) // phase 1 = the matrix-core filter's restatement
+                else if (hs == 0 && sv.mxR1 >= 0) // as the product: phase 1 = the matrix-core filter (its host restatement) when the scene has a table
                     done = fold == FOLD_FORWARD ? laneStep<HS_MATRIX, FOLD_FORWARD>(L, sv, fc, stack)
                                                 : laneStep<HS_MATRIX, FOLD_RECURSIVE>(L, sv, fc, stack);
                 else
@@ -118,9 +119,10 @@ float emu_sinf(float x) { return tsinf(x); }
 float emu_cosf(float x) { return tcosf(x); }
 float emu_pow5f(float x) { return tpow5f(x); }
 
-// HitSpheres alone: n rays [n][6] = origin, unit direction; hs 0 = two-phase (conservative FMA filter + exact test),
-// 1 = simple loop (the reference's arithmetic for every sphere).  Returns the number of phase-1 candidates is not
-// exposed; ids/ts must be identical between the two variants.
+// HitSpheres alone: n rays [n][6] = origin, unit direction; hs as tptSetKernelVariant numbers it: 0 = the product's default
+// (conservative filter + exact test: matrix-core filter's restatement for scenes with a table, groups for large scenes),
+// 1 = simple loop (the reference's arithmetic for every sphere), 2 = no groups, 3 = packed VALU filter everywhere.
+// ids/ts must be identical between all of them.
 void emu_hit_spheres(const void* spheres, const void* mats, int count, int hs, const float* rays, int n, int* outId, float* outT)
 {
     std::vector<SpherePOD> S((const SpherePOD*)spheres, (const SpherePOD*)spheres + count);
@@ -129,19 +131,22 @@ void emu_hit_spheres(const void* spheres, const void* mats, int count, int hs, c
     packScene(S, M, P);
     SceneView sv = viewOf(P);
     if (hs == 2) sv.nGroups = 0;
+    if (hs == 3) sv.mxR1 = -1;
     for (int i = 0; i < n; ++i) {
         f3 o = mk3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]), d = mk3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
         float t;
         outId[i] = hs == 1                       ? hitSpheres<HS_SIMPLE>(sv, o, d, TPT_MIN_T, TPT_MAX_T, t)
-                   : (hs == 3 && sv.mxR1 >= 0) ? hitSpheres<HS_MATRIX>(sv, o, d, TPT_MIN_T, TPT_MAX_T, t)
+                   : (hs == 0 && sv.mxR1 >= 0) ? hitSpheres<HS_MATRIX>(sv, o, d, TPT_MIN_T, TPT_MAX_T, t)
                                                : hitSpheres<HS_TWO_PHASE_GROUPS>(sv, o, d, TPT_MIN_T, TPT_MAX_T, t);
         outT[i] = t;
     }
 }
 
-// Candidate masks of the matrix-core filter's restatement (phase1MatrixRef: same table, same ray vector, the fmaf chain
-// the MFMA runs): the GPU test compares the device's masks with these bit for bit.  Returns mxR1 (< 0: no table).
-int emu_matrix_masks(const void* spheres, const void* mats, int count, const float* rays, int n, unsigned long long* outMask)
+// Candidate masks of the matrix-core filter's host restatement (phase1MatrixHRef: same table, same ray slots, f32
+// accumulation in slot order) and, per (ray, sphere), the EXACT slot sum and the sum of the slot products' magnitudes in
+// binary64 (outSum / outAbs, [n][nSpheres], optional): the GPU test holds the device's sign bits against them within the
+// error model's bound.  Returns mxR1 (< 0: no table).
+int emu_matrix_masks(const void* spheres, const void* mats, int count, const float* rays, int n, unsigned long long* outMask, double* outSum, double* outAbs)
 {
     std::vector<SpherePOD> S((const SpherePOD*)spheres, (const SpherePOD*)spheres + count);
     std::vector<MaterialPOD> M((const MaterialPOD*)mats, (const MaterialPOD*)mats + count);
@@ -150,7 +155,8 @@ int emu_matrix_masks(const void* spheres, const void* mats, int count, const flo
     if (P.mxR1 < 0) return -1;
     for (int i = 0; i < n; ++i) {
         f3 o = mk3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]), d = mk3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
-        outMask[i] = phase1MatrixRef(P.amat.data(), P.mxR1, P.nSpheres, o, d);
+        outMask[i] = phase1MatrixHRef(P.amatH.data(), P.mxR1, P.nSpheres, o, d, outSum ? outSum + (size_t)i * count : nullptr,
+                                      outAbs ? outAbs + (size_t)i * count : nullptr);
     }
     return P.mxR1;
 }

@@ -548,42 +548,78 @@ def test_config5_stress_scene_full_parity(tpt_defaults, oracle):
 
 
 # ---- phase 1 on the matrix cores
-def test_matrix_filter_masks_equal_the_restatement(tpt_defaults, emu, oracle):
-    """The candidate masks v_mfma_f32_32x32x2_f32 + the lane swaps produce on the device are, bit for bit, those of the
-    host restatement (same table, same ray vector, fmaf chain in k order) -- which the CPU suite proves conservative.
-    Checks the A/B/accumulator layouts, the padding rows and the mask assembly for one and two sphere tiles."""
-    import ctypes as C
+def _mixed_rays(rng, s, n):
     from common import grazing_rays
+    g = grazing_rays(s, n // 2)
+    o = rng.uniform(-12, 12, (n - n // 2, 3))
+    d = rng.normal(size=(n - n // 2, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    d = (d / np.linalg.norm(d.astype(np.float64), axis=1, keepdims=True)).astype(np.float32)
+    return np.concatenate([g, np.concatenate([o.astype(np.float32), d], 1)], 0).astype(np.float32)
+
+
+def test_matrix_filter_sign_agrees_with_the_exact_slot_sum(tpt_defaults, emu, oracle):
+    """The error model behind the matrix-core filter's slack (tpt_trace.h, phase1MatrixH), checked on the device: the sign
+    bit v_mfma_f32_32x32x16_f16 delivers for a (sphere, ray) equals the sign of the EXACT sum of the 32 slot products
+    (binary64 on the host, same table, same ray slots) whenever that sum is further than 64 u x (sum of magnitudes) from
+    zero -- the accumulation-error bound the proof and tests/adversarial_filter.cpp assume.  Also checks the A / B /
+    accumulator layouts, the padding rows and the mask assembly for one and two sphere tiles, and that rays outside
+    binary16 range keep every sphere."""
+    from test_lane_logic import _matrix_masks
     from toypathtracer_amd.scenes import stress_scene
     tpt = tpt_defaults
-    emu.emu_matrix_masks.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
-    emu.emu_matrix_masks.restype = C.c_int
     rng = np.random.default_rng(5)
-    scenes = [oracle.default_scene()] + [stress_scene(n, 8) for n in (1, 3, 17, 32, 33, 40, 47, 56, 64)]
+    from common import matrix_scene
+    scenes = [oracle.default_scene()] + [matrix_scene(oracle, n) for n in (1, 3, 17, 32, 33, 40, 47, 56, 64)]
+    worst = 0.0
     for (s, m) in scenes:
         tpt.set_scene(s, m)
+        ns = len(s)
         n = 6400 + 13  # not a multiple of 64
-        g = grazing_rays(s, n // 2)
-        o = rng.uniform(-12, 12, (n - n // 2, 3))
-        d = rng.normal(size=(n - n // 2, 3))
-        d /= np.linalg.norm(d, axis=1, keepdims=True)
-        d = d.astype(np.float32)
-        d = (d / np.linalg.norm(d.astype(np.float64), axis=1, keepdims=True)).astype(np.float32)
-        rays = np.concatenate([g, np.concatenate([o.astype(np.float32), d], 1)], 0).astype(np.float32)
-        want = np.zeros(n, np.uint64)
-        assert emu.emu_matrix_masks(s.ctypes.data, m.ctypes.data, len(s), rays.ctypes.data, n, want.ctypes.data) >= 0
+        rays = _mixed_rays(rng, s, n)
+        rays[-1] = [300.0, 5.0, 1.0, 0.0, 1.0, 0.0]  # |o|^2 > 60000: every sphere stays a candidate
+        r1, _, S, T = _matrix_masks(emu, s, m, rays, sums=True)
+        assert r1 >= 0
         got = tpt.test_matrix_filter(rays)
-        assert np.array_equal(got, want), len(s)
+        assert int(got[-1]) == ((1 << ns) - 1) << (64 - ns)
+        assert (got & np.uint64((1 << (64 - ns)) - 1)).max() == 0 if ns < 64 else True  # padding bits never set
+        bits = ((got[:-1, None] >> (np.uint64(63) - np.arange(ns, dtype=np.uint64))[None, :]) & np.uint64(1)).astype(bool)
+        S, T = S[:-1], T[:-1]
+        clear = np.abs(S) > 64 * 2.0 ** -24 * T
+        assert np.array_equal(bits[clear], (S > 0)[clear]), ns
+        wrong = bits != (S > 0)
+        if wrong.any():
+            worst = max(worst, float((np.abs(S[wrong]) / T[wrong]).max()) / 2.0 ** -24)
+    assert worst < 64  # (sign flips only ever happen within this many u of zero, relative to the sum of magnitudes)
     tpt.set_scene(None)
 
 
-@pytest.mark.parametrize("n", [1, 3, 32, 33, 47, 64, 65])
+def test_matrix_filter_hits_equal_the_exact_loop_on_grazing_rays(tpt_defaults, oracle):
+    """Conservative in practice: for two million rays that graze a sphere within 1e-8..1e-3 radii, the nearest hit through the
+    matrix-core filter + exact test of its candidates equals the all-exact loop (the reference's arithmetic for every
+    sphere), id and t bit for bit."""
+    from common import grazing_rays
+    tpt = tpt_defaults
+    s, m = oracle.default_scene()
+    tpt.set_scene(s, m)
+    n = 1 << 21
+    rays = grazing_rays(s, n)
+    _, ids, ts = tpt.test_matrix_filter(rays, hits=True)
+    ids1, ts1 = tpt.test_hit_spheres(rays, 1)
+    assert np.array_equal(ids, ids1) and np.array_equal(ts.view(np.uint32), ts1.view(np.uint32))
+    assert (ids1 >= 0).mean() > 0.3
+    tpt.set_scene(None)
+
+
+@pytest.mark.parametrize("n", [1, 3, 32, 33, 47, 64, 65, -3, -32, -33, -64])
 def test_small_scenes_bit_exact(tpt_defaults, oracle, n):
-    """Scenes of 1..64 spheres take the matrix-core filter in the path-queue kernel (65: back to the packed VALU filter);
-    image and ray count against the oracle, and against the VALU filter (variant 3)."""
+    """Scenes of 1..64 spheres in binary16 range take the matrix-core filter in the path-queue kernel (n < 0: built from the
+    default scene's spheres); the stress scenes (n > 0: a 1000-unit ground sphere, no table) and 65 spheres the packed VALU
+    filter.  Image and ray count against the oracle, and against the VALU filter everywhere (variant 3)."""
+    from common import matrix_scene
     from toypathtracer_amd.scenes import stress_scene
     tpt = tpt_defaults
-    s, m = stress_scene(n, 8)
+    s, m = stress_scene(n, 8) if n > 0 else matrix_scene(oracle, -n)
     w, h, spp = 200, 120, 2
     tpt.set_scene(s, m)
     tpt.set_samples_per_pixel(spp)

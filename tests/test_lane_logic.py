@@ -83,8 +83,8 @@ def test_two_phase_filter_is_conservative_on_grazing_rays(emu, oracle):
     for (s, m), n in ((oracle.default_scene(), 400000), (stress_scene(4096, 64), 20000)):
         rays = grazing_rays(s, n)
         out = []
-        # 0: two-phase (grouped for the 4096-sphere scene), 1: all-exact loop, 2: two-phase flat, 3: matrix-core filter's
-        # restatement as phase 1 (<= 64 spheres; the 4096-sphere scene has no table and takes the VALU filter)
+        # 0: the product's default (matrix-core filter's restatement as phase 1 for <= 64 spheres, groups for the 4096-sphere
+        # scene), 1: all-exact loop, 2: two-phase flat, 3: packed VALU filter everywhere
         for hs in (0, 1, 2, 3):
             ids, ts = np.empty(n, np.int32), np.empty(n, np.float32)
             emu.emu_hit_spheres(s.ctypes.data, m.ctypes.data, len(s), hs, rays.ctypes.data, n, ids.ctypes.data, ts.ctypes.data)
@@ -164,38 +164,55 @@ def test_filters_never_miss_in_an_adversarial_search(tmp_path):
 
 
 def test_matrix_filter_restatement_renders_the_oracle_image(emu, oracle):
-    """Phase 1 on the matrix cores (tpt_trace.h, phase1Matrix) is a different conservative filter: expanded around the
-    coordinate origin, evaluated as a 12-term fmaf chain.  With its host restatement as phase 1 the lane logic must still
-    render the oracle's image bit for bit -- default scene (46 spheres: two sphere tiles, R1 = 8) and small scenes that
-    fill one tile, one tile exactly (32), and both completely (64)."""
+    """Phase 1 on the matrix cores (tpt_trace.h, phase1MatrixH) is a different conservative filter: expanded around the
+    coordinate origin, every factor split into two binary16 pieces, 32 slot products summed.  With its host restatement as
+    phase 1 (hs 0: what the product runs for scenes with a table) the lane logic must still render the oracle's image bit
+    for bit -- default scene (46 spheres: two sphere tiles, R1 = 8) and small scenes that fill one tile, one tile exactly
+    (32), and both completely (64) -- and so must the packed VALU filter (hs 3)."""
     from toypathtracer_amd.scenes import stress_scene
     w, h, spp = 96, 54, 2
     s, m = oracle.default_scene()
     cam = oracle.default_camera(w, h)
     ro, bo = oracle.render(s, m, cam, w, h, spp, 0, seed_mode=1)
-    re, be = emu_frames(emu, s, m, cam, w, h, spp, 1, FLAG_PROGRESSIVE, 1, 3, 0)
-    assert re == ro and be.tobytes() == bo.tobytes()
+    for hs in (0, 3):
+        re, be = emu_frames(emu, s, m, cam, w, h, spp, 1, FLAG_PROGRESSIVE, 1, hs, 0)
+        assert re == ro and be.tobytes() == bo.tobytes()
+    from common import matrix_scene
     for n in (3, 32, 33, 64):
-        s, m = stress_scene(n, 8)
+        s, m = matrix_scene(oracle, n)
+        assert _matrix_masks(emu, s, m, np.zeros((1, 6), np.float32))[0] >= 0  # the scene does have a table
         ro, bo = oracle.render(s, m, cam, w, h, spp, 0, seed_mode=1)
-        re, be = emu_frames(emu, s, m, cam, w, h, spp, 1, FLAG_PROGRESSIVE, 1, 3, 0)
+        re, be = emu_frames(emu, s, m, cam, w, h, spp, 1, FLAG_PROGRESSIVE, 1, 0, 0)
         assert re == ro and be.tobytes() == bo.tobytes(), n
+    s, m = stress_scene(40, 8)  # a 1000-unit ground sphere: outside binary16 range, no table, packed VALU filter
+    assert _matrix_masks(emu, s, m, np.zeros((1, 6), np.float32))[0] < 0
+
+
+def _matrix_masks(emu, s, m, rays, sums=False):
+    import ctypes as C
+    emu.emu_matrix_masks.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    emu.emu_matrix_masks.restype = C.c_int
+    n = len(rays)
+    masks = np.zeros(n, np.uint64)
+    S = np.zeros((n, len(s)), np.float64) if sums else None
+    T = np.zeros((n, len(s)), np.float64) if sums else None
+    r1 = emu.emu_matrix_masks(s.ctypes.data, m.ctypes.data, len(s), rays.ctypes.data, n, masks.ctypes.data,
+                              S.ctypes.data if sums else None, T.ctypes.data if sums else None)
+    return r1, masks, S, T
 
 
 def test_matrix_filter_mask_layout(emu, oracle):
     """The candidate mask lists the spheres in ascending index (bit 63 - p): every sphere the exact test hits must have
-    its bit set, padding bits are clear, and a far-away ray pointing away from everything has (almost) no candidates."""
+    its bit set, padding bits are clear, a ray outside binary16 range keeps every sphere, and the filter filters."""
     import ctypes as C
     from common import grazing_rays
-    emu.emu_matrix_masks.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
-    emu.emu_matrix_masks.restype = C.c_int
     emu.emu_hit_spheres.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     emu.emu_hit_spheres.restype = None
     s, m = oracle.default_scene()
     n = 20000
     rays = grazing_rays(s, n)
-    masks = np.zeros(n, np.uint64)
-    assert emu.emu_matrix_masks(s.ctypes.data, m.ctypes.data, 46, rays.ctypes.data, n, masks.ctypes.data) == 8
+    r1, masks, S, T = _matrix_masks(emu, s, m, rays, sums=True)
+    assert r1 == 8
     ids, ts = np.empty(n, np.int32), np.empty(n, np.float32)
     emu.emu_hit_spheres(s.ctypes.data, m.ctypes.data, 46, 1, rays.ctypes.data, n, ids.ctypes.data, ts.ctypes.data)
     hit = ids >= 0
@@ -204,6 +221,14 @@ def test_matrix_filter_mask_layout(emu, oracle):
     assert (masks & np.uint64((1 << 18) - 1)).max() == 0  # bits of spheres 46..63 never set
     counts = np.array([bin(int(x)).count("1") for x in masks[:2000]])
     assert counts.mean() < 6  # a filter, not a pass-through
+    # the exact slot sum reproduces the filter's real-number value D + m: the f32 restatement's sign agrees with it
+    # wherever the sum is not within the error model's bound of zero
+    bits = ((masks[:, None] >> (np.uint64(63) - np.arange(46, dtype=np.uint64))[None, :]) & np.uint64(1)).astype(bool)
+    clear = np.abs(S) > 64 * 2.0 ** -24 * T
+    assert np.array_equal(bits[clear], (S > 0)[clear])
+    far = np.float32([[300.0, 5.0, 1.0, 0.0, 1.0, 0.0], [np.nan, 0, 0, 0, 1, 0], [0, 0, 0, np.inf, 0, 0]])  # |o|^2 > 60000 / NaN / inf
+    _, mfar, _, _ = _matrix_masks(emu, s, m, far)
+    assert all(int(x) == ((1 << 46) - 1) << 18 for x in mfar)
 
 
 @pytest.mark.parametrize("case", config_goldens(), ids=lambda c: c["variant"])

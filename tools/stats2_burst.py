@@ -2,7 +2,7 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["TPT_LIB"] = os.path.join(ROOT, "tools", "_stats2", "libtoypathtracer_hip.so")
+os.environ.setdefault("TPT_LIB", os.path.join(ROOT, "tools", "_stats2", "libtoypathtracer_hip.so"))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
 import torch
 from toypathtracer_amd import api

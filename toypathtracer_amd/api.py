@@ -79,7 +79,7 @@ def load_library():
         "tptSetRayCounter": [p], "tptSetTileMirror": [p, p], "tptSetFrameOverlap": [i], "tptDisplayRGBA8": [p, i, i, p], "tptKernelTimingBegin": [i],
         "tptKernelTimingEnd": [C.POINTER(f), C.POINTER(i)],
         "tptSynchronize": [], "tptTimerBegin": [], "tptTimerEnd": [C.POINTER(f)], "tptSetKernelVariant": [i, i, i],
-        "tptDebugStats": [p, i], "tptDebugChunkOrder": [p, p, i], "tptTestMath": [i, p, p, p, i], "tptTestMathExhaustive": [i, u, u, p, p], "tptTestHitSpheres": [i, p, p, p, i], "tptTestMatrixFilter": [p, p, i], "tptGetLaunchInfo": [C.POINTER(i)] * 4, "tptGetPipelineInfo": [C.POINTER(i)] * 4, "tptCommGetUniqueId": [p], "tptCommInit": [p, i, i, i], "tptCommInitLoopback": [i, i], "tptCommDestroy": [], "tptDrawSharded": [f, i, i, i, p, u], "tptDrawShardedBatch": [f, i, i, i, i, p, u], "tptDrawDeviceBatch": [f, i, i, i, i, p, u], "tptShardedFinish": [C.POINTER(C.c_int64)], "tptSetHostBufferMode": [i], "tptDebugLookaheadHits": [C.POINTER(C.c_longlong)], "tptSetHostLookahead": [i],
+        "tptDebugStats": [p, i], "tptDebugChunkOrder": [p, p, i], "tptTestMath": [i, p, p, p, i], "tptTestMathExhaustive": [i, u, u, p, p], "tptTestHitSpheres": [i, p, p, p, i], "tptTestMatrixFilter": [p, p, p, p, i], "tptGetLaunchInfo": [C.POINTER(i)] * 4, "tptGetPipelineInfo": [C.POINTER(i)] * 4, "tptCommGetUniqueId": [p], "tptCommInit": [p, i, i, i], "tptCommInitLoopback": [i, i], "tptCommDestroy": [], "tptDrawSharded": [f, i, i, i, p, u], "tptDrawShardedBatch": [f, i, i, i, i, p, u], "tptDrawDeviceBatch": [f, i, i, i, i, p, u], "tptShardedFinish": [C.POINTER(C.c_int64)], "tptSetHostBufferMode": [i], "tptDebugLookaheadHits": [C.POINTER(C.c_longlong)], "tptSetHostLookahead": [i],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -378,10 +378,14 @@ def test_hit_spheres(rays, hit_spheres=0):
     return ids, ts
 
 
-def test_matrix_filter(rays):
-    """Candidate masks (sphere p at bit 63 - p) of the matrix-core phase-1 filter for n rays, current scene."""
+def test_matrix_filter(rays, hits=False):
+    """phase 1 of HitSpheres on the matrix cores for the current scene (<= 64 spheres): candidate masks (sphere p at bit
+    63 - p); hits=True: (masks, ids, ts) with the nearest hit through the filter + the exact test of its candidates"""
     rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
     n = rays.shape[0]
-    masks = np.zeros(n, np.uint64)
-    _chk(load_library().tptTestMatrixFilter(rays.ctypes.data, masks.ctypes.data, n), "tptTestMatrixFilter")
-    return masks
+    masks = np.empty(n, np.uint64)
+    ids = np.empty(n, np.int32) if hits else None
+    ts = np.empty(n, np.float32) if hits else None
+    _chk(load_library().tptTestMatrixFilter(rays.ctypes.data, masks.ctypes.data, ids.ctypes.data if hits else None,
+                                            ts.ctypes.data if hits else None, n), "tptTestMatrixFilter")
+    return (masks, ids, ts) if hits else masks

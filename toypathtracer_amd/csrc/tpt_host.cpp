@@ -271,7 +271,7 @@ int stageScene()
                  offLights = offMats + align256(bMats), offGPairs = offLights + align256(bLights + 32),
                  offGSph = offGPairs + align256(bGPairs), offGId = offGSph + align256(bGSph), offBSph = offGId + align256(bGId),
                  offBId = offBSph + align256(bBSph), offAmat = offBId + align256(bBId + 32);
-    const size_t bAmat = (g.useMatrix && P.mxR1 >= 0) ? P.amat.size() * sizeof(float) : 0, total = offAmat + align256(bAmat + 32);
+    const size_t bAmat = (g.useMatrix && tptQueueMatrixFilter() && P.mxR1 >= 0) ? P.amatH.size() * sizeof(uint32_t) : 0, total = offAmat + align256(bAmat + 32);
     if (!S.evUploaded) HIPCHK(hipEventCreateWithFlags(&S.evUploaded, kOrderingEvent));
     // the previous copy out of this staging blob (kSceneSets uploads ago) must have left the host before we overwrite it:
     // only ever waits when the host has run more than 16 animated frames ahead of the GPU
@@ -310,7 +310,7 @@ int stageScene()
         if (bBSph) memcpy(S.stage + offBSph, P.bsph.data(), bBSph);
         if (bBId) memcpy(S.stage + offBId, P.bid.data(), bBId);
     }
-    if (bAmat) memcpy(S.stage + offAmat, P.amat.data(), bAmat);
+    if (bAmat) memcpy(S.stage + offAmat, P.amatH.data(), bAmat);
     S.bytes = offAmat + bAmat;
     S.offAmat = offAmat;
     S.mxR1 = bAmat ? P.mxR1 : -1;
@@ -352,7 +352,7 @@ SceneView deviceView()
     sv.nGroups = S->nGroups;
     sv.nGroupPairs = S->nGroupPairs;
     sv.nBig = S->nBig;
-    sv.amat = reinterpret_cast<const float*>(S->dev + S->offAmat);
+    sv.amatH = reinterpret_cast<const uint32_t*>(S->dev + S->offAmat);
     sv.mxR1 = S->mxR1;
     return sv;
 }
@@ -486,7 +486,16 @@ int tptInitialize(void)
     g.device = dev;
     g.numCUs = prop.multiProcessorCount;
     g.deviceName = std::string(prop.name) + " (" + prop.gcnArchName + ")";
-    HIPCHK(hipStreamCreateWithFlags(&g.ownStream, hipStreamNonBlocking));
+    {
+        // the context's own stream carries the ordered blend chain (and the exchange kernels of a sharded frame): short
+        // kernels that every following frame waits for.  env TPT_RESOLVE_PRIO=1 (experiment): a high-priority queue.
+        int lo = 0, hi = 0;
+        const char* pe = getenv("TPT_RESOLVE_PRIO");
+        if (pe && atoi(pe) > 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo)
+            HIPCHK(hipStreamCreateWithPriority(&g.ownStream, hipStreamNonBlocking, hi));
+        else
+            HIPCHK(hipStreamCreateWithFlags(&g.ownStream, hipStreamNonBlocking));
+    }
     g.stream = g.ownStream;
     HIPCHK(hipEventCreateWithFlags(&g.evOrder, kOrderingEvent));
     g.orderDone = true;
@@ -703,7 +712,7 @@ int tptSetFrameOverlap(int frames)
 int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene)
 {
     g.hs = hitSpheres == 1 ? HS_SIMPLE : HS_TWO_PHASE;
-    const int allow = hitSpheres == 2 ? 0 : 1, matrix = hitSpheres == 3 ? 0 : 1;
+    const int allow = hitSpheres == 2 ? 0 : 1, matrix = hitSpheres == 3 ? 0 : 1; // 3: the packed VALU filter everywhere (no matrix-core table)
     if (allow != g.allowGroups || matrix != g.useMatrix) {
         g.allowGroups = allow;
         g.useMatrix = matrix;
@@ -1876,12 +1885,12 @@ int tptTestMathExhaustive(int op, unsigned lo, unsigned hi, unsigned long long* 
     return 0;
 }
 
-// Phase 1 on the matrix cores alone: candidate masks (sphere p at bit 63 - p) of n host rays against the current scene
-// (<= 64 spheres).  The CPU tests hold the bit-exact restatement (phase1MatrixRef).
-int tptTestMatrixFilter(const float* rays, unsigned long long* outMask, int n)
+// Phase 1 on the matrix cores (phase1MatrixH) for n host rays against the current scene: candidate masks (sphere p at bit
+// 63 - p) and / or the nearest hit through the filter + the exact test of its candidates, as the path-queue kernel runs it.
+int tptTestMatrixFilter(const float* rays, unsigned long long* outMask, int* outId, float* outT, int n)
 {
     if (requireInit()) return -1;
-    if (!rays || !outMask || n <= 0) return fail("tptTestMatrixFilter: bad arguments");
+    if (!rays || (!outMask && !outId) || (outId && !outT) || n <= 0) return fail("tptTestMatrixFilter: bad arguments");
     if (g.sceneDirty || (g.curSet < 0 && g.pendingSet < 0)) {
         int rc = stageScene();
         if (rc) return rc;
@@ -1893,19 +1902,27 @@ int tptTestMatrixFilter(const float* rays, unsigned long long* outMask, int n)
     KernelArgs a;
     memset(&a, 0, sizeof(a));
     a.scene = deviceView();
-    if (a.scene.mxR1 < 0) return fail("tptTestMatrixFilter: the current scene has no matrix table (more than 64 spheres, or variant 3)");
+    if (a.scene.mxR1 < 0)
+        return fail("tptTestMatrixFilter: the current scene has no matrix table (more than 64 spheres, a sphere outside binary16 range, hit-spheres variant 3, or a build without the filter)");
     const int nPad = (n + 63) / 64 * 64;
     std::vector<float> padded((size_t)nPad * 6, 0.0f);
     memcpy(padded.data(), rays, sizeof(float) * 6 * (size_t)n);
-    float* dr = nullptr;
+    float *dr = nullptr, *dt = nullptr;
+    int* di = nullptr;
     unsigned long long* dm = nullptr;
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&dr), sizeof(float) * 6 * nPad));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&dm), sizeof(unsigned long long) * nPad));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&di), sizeof(int) * nPad));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&dt), sizeof(float) * nPad));
     HIPCHK(hipMemcpy(dr, padded.data(), sizeof(float) * 6 * nPad, hipMemcpyHostToDevice));
-    HIPCHK(tptLaunchMatrixFilterTest(a, dr, dm, nPad, g.stream));
+    HIPCHK(tptLaunchMatrixFilterTest(a, dr, dm, outId ? di : nullptr, dt, nPad, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
-    HIPCHK(hipMemcpy(outMask, dm, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
-    (void)hipFree(dr); (void)hipFree(dm);
+    if (outMask) HIPCHK(hipMemcpy(outMask, dm, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost));
+    if (outId) {
+        HIPCHK(hipMemcpy(outId, di, sizeof(int) * n, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(outT, dt, sizeof(float) * n, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(dr); (void)hipFree(dm); (void)hipFree(di); (void)hipFree(dt);
     return 0;
 }
 

@@ -77,14 +77,16 @@ __global__ void __launch_bounds__(256) tptResolveKernel(float* __restrict__ tile
     // AGE: the newcomer gets the leftover slots (a 6-us kernel took 40-1000 us; the ordered resolve chain is what bounds
     // small frames).  Raise the wave's priority for its short life.
     __builtin_amdgcn_s_setprio(3);
-    int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0 && frameRays) atomicAdd(totalRays, *frameRays);
-    if (i >= nPixels) return;
-    f4 t = reinterpret_cast<const f4*>(tile)[i];
-    f4 c = colour[i];
-    f3 r = blendPixel(mk3(t.x, t.y, t.z), mk3(c.x, c.y, c.z), lerpFac);
-    t.x = r.x; t.y = r.y; t.z = r.z;
-    reinterpret_cast<f4*>(tile)[i] = t;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && frameRays) atomicAdd(totalRays, *frameRays);
+    // grid-stride: a few hundred workgroups however large the tile is (tptLaunchResolve) -- every workgroup is one more
+    // dispatch that has to find a slot on a machine full of persistent trace workgroups
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nPixels; i += gridDim.x * 256) {
+        f4 t = reinterpret_cast<const f4*>(tile)[i];
+        f4 c = colour[i];
+        f3 r = blendPixel(mk3(t.x, t.y, t.z), mk3(c.x, c.y, c.z), lerpFac);
+        t.x = r.x; t.y = r.y; t.z = r.z;
+        reinterpret_cast<f4*>(tile)[i] = t;
+    }
 }
 // Same, and the blended pixel also goes to `mirror` (the snapshot a sharded host hands to its collective while the
 // next frames keep accumulating into the tile) and the current value of the ray counter to `counterOut`: one kernel
@@ -94,15 +96,15 @@ __global__ void __launch_bounds__(256) tptResolveMirrorKernel(float* __restrict_
                                                               unsigned long long* counterOut)
 {
     __builtin_amdgcn_s_setprio(3); // see tptResolveKernel
-    int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0 && counterOut) *counterOut = __hip_atomic_load(rayCounter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (i >= nPixels) return;
-    f4 t = reinterpret_cast<const f4*>(tile)[i];
-    f4 c = colour[i];
-    f3 r = blendPixel(mk3(t.x, t.y, t.z), mk3(c.x, c.y, c.z), lerpFac);
-    t.x = r.x; t.y = r.y; t.z = r.z;
-    reinterpret_cast<f4*>(tile)[i] = t;
-    mirror[i] = t;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && counterOut) *counterOut = __hip_atomic_load(rayCounter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nPixels; i += gridDim.x * 256) {
+        f4 t = reinterpret_cast<const f4*>(tile)[i];
+        f4 c = colour[i];
+        f3 r = blendPixel(mk3(t.x, t.y, t.z), mk3(c.x, c.y, c.z), lerpFac);
+        t.x = r.x; t.y = r.y; t.z = r.z;
+        reinterpret_cast<f4*>(tile)[i] = t;
+        mirror[i] = t;
+    }
 }
 
 // The blends of a batch of frames (tptDrawDeviceBatch), applied in frame order to each pixel by one launch: exactly the
@@ -112,18 +114,18 @@ __global__ void __launch_bounds__(256) tptResolveBatchKernel(float* __restrict__
                                                              const unsigned long long* rayCounter, unsigned long long* counterOut)
 {
     __builtin_amdgcn_s_setprio(3); // see tptResolveKernel
-    int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0 && counterOut) *counterOut = __hip_atomic_load(rayCounter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (i >= nPixels) return;
-    f4 t = reinterpret_cast<const f4*>(tile)[i];
-    f3 r = mk3(t.x, t.y, t.z);
-    for (int j = 0; j < nFrames; ++j) {
-        const f4 c = colour[(size_t)j * planeStride + i];
-        r = blendPixel(r, mk3(c.x, c.y, c.z), lerp.v[j]);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && counterOut) *counterOut = __hip_atomic_load(rayCounter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nPixels; i += gridDim.x * 256) {
+        f4 t = reinterpret_cast<const f4*>(tile)[i];
+        f3 r = mk3(t.x, t.y, t.z);
+        for (int j = 0; j < nFrames; ++j) {
+            const f4 c = colour[(size_t)j * planeStride + i];
+            r = blendPixel(r, mk3(c.x, c.y, c.z), lerp.v[j]);
+        }
+        t.x = r.x; t.y = r.y; t.z = r.z;
+        reinterpret_cast<f4*>(tile)[i] = t;
+        if (mirror) mirror[i] = t;
     }
-    t.x = r.x; t.y = r.y; t.z = r.z;
-    reinterpret_cast<f4*>(tile)[i] = t;
-    if (mirror) mirror[i] = t;
 }
 
 // Rank 0 of a sharded frame: the gathered tiles [rank][padRows + 1][width] f4 (row stripes dealt round-robin, one extra row
@@ -616,15 +618,20 @@ __global__ void __launch_bounds__(TPT_SORT_T) tptTraceSortedKernel(const KernelA
 #endif
 #define TPT_Q_T (64 * TPT_Q_WAVES)
 #ifndef TPT_Q_P
-#define TPT_Q_P 1024 // paths per workgroup (power of two)
+#define TPT_Q_P 1024 // capacity of every ring (power of two)
+#endif
+#ifndef TPT_MATRIX_FILTER
+#define TPT_MATRIX_FILTER 1 // phase 1 of HitSpheres on the matrix cores (v_mfma_f32_32x32x16_f16, f16-split operands) for scenes with a table; 0: packed VALU filter only
+#endif
+#ifndef TPT_Q_PATHS
+// paths per workgroup (<= TPT_Q_P): what the path records in LDS are sized for.  960 with the matrix filter: its 4-KB operand
+// table has to fit beside them for two workgroups per CU (2 x 80 KB); measured no slower than 1024 (profiles/r03/r03_run10.log)
+#define TPT_Q_PATHS (TPT_MATRIX_FILTER ? 960 : TPT_Q_P)
 #endif
 #ifndef TPT_Q_FUSE_MIN
 #define TPT_Q_FUSE_MIN 48 // a batch intersects its own rays when at least this many lanes still hold one
 #endif
 #define TPT_Q_NF4 4
-#ifndef TPT_MATRIX_FILTER
-#define TPT_MATRIX_FILTER 0 // 1: phase 1 on v_mfma_f32_32x32x2_f32 for scenes of <= 64 spheres (measured slower)
-#endif
 enum { Q_FREE = 0, Q_INT = 1, Q_END = 2, Q_DIEL = 3, Q_METAL = 4, Q_LAMBERT = 5, Q_COUNT = 6 };
 struct QueueCtl {
     unsigned head[8];
@@ -733,7 +740,7 @@ tptTraceQueueKernel(const KernelArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS layout: everything of fixed size first, at compile-time offsets (immediates in the DS instructions instead of base
     // registers): path records, rings, control block, frame constants; then the scene arrays, whose sizes the launch decides
-    constexpr int kOffQ = TPT_Q_NF4 * TPT_Q_P * 16;
+    constexpr int kOffQ = TPT_Q_NF4 * TPT_Q_PATHS * 16;
     constexpr int kOffCtl = kOffQ + Q_COUNT * TPT_Q_P * 2;
     constexpr int kOffFc = kOffCtl + (((int)sizeof(QueueCtl) + 63) & ~63);
     constexpr int kOffScene = kOffFc + (((int)sizeof(FrameConsts) + 15) & ~15);
@@ -753,9 +760,9 @@ tptTraceQueueKernel(const KernelArgs a)
     f4* ldsMats = reinterpret_cast<f4*>(smem + off);
     off += LDS_SCENE ? a.scene.nSpheres * 48 : 0;
 #if TPT_MATRIX_FILTER
-    // phase 1 on the matrix cores (scenes of <= 64 spheres): the A-operand table, 3 KB
+    // phase 1 on the matrix cores (scenes with a table: <= 64 spheres in binary16 range): the A-operand table, 4 KB
     const bool useMatrix = LDS_SCENE && a.scene.mxR1 >= 0;
-    float* ldsA = reinterpret_cast<float*>(smem + off);
+    uint32_t* ldsA = reinterpret_cast<uint32_t*>(smem + off);
 #endif
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -774,7 +781,7 @@ tptTraceQueueKernel(const KernelArgs a)
     sv.lights = ldsLights;
 #if TPT_MATRIX_FILTER
     if (useMatrix)
-        for (int i = tid; i < 2 * 6 * 64; i += TPT_Q_T) ldsA[i] = a.scene.amat[i];
+        for (int i = tid; i < TPT_MXH_TABLE_DWORDS; i += TPT_Q_T) ldsA[i] = a.scene.amatH[i];
     const int mxR1 = a.scene.mxR1;
 #endif
 #if defined(__HIP_DEVICE_COMPILE__) && defined(TPT_STATS) && TPT_STATS >= 2
@@ -782,10 +789,10 @@ tptTraceQueueKernel(const KernelArgs a)
 #endif
     for (int i = tid; i < (int)(sizeof(FrameConsts) / 4); i += TPT_Q_T) reinterpret_cast<uint32_t*>(ldsFc)[i] = reinterpret_cast<const uint32_t*>(&a.fc)[i];
     // every path starts in the FREE queue; all other queues empty (sentinel everywhere)
-    for (int i = tid; i < Q_COUNT * TPT_Q_P; i += TPT_Q_T) q[i] = (unsigned short)(i < TPT_Q_P ? i : 0xFFFF);
+    for (int i = tid; i < Q_COUNT * TPT_Q_P; i += TPT_Q_T) q[i] = (unsigned short)(i < TPT_Q_PATHS ? i : 0xFFFF);
     if (tid < 8) {
         ctl->head[tid] = 0u;
-        ctl->tail[tid] = tid == Q_FREE ? (unsigned)TPT_Q_P : 0u;
+        ctl->tail[tid] = tid == Q_FREE ? (unsigned)TPT_Q_PATHS : 0u;
     }
     if (tid == 0) {
         ctl->poolTotal = 0u;
@@ -795,7 +802,7 @@ tptTraceQueueKernel(const KernelArgs a)
 
     const FrameConsts& fc = a.fc;
     const unsigned long long laneBelow = (1ull << lane) - 1ull;
-    f4* colSum = st + 2 * TPT_Q_P;                        // plane 2: per-path colour sums + pixel coordinates
+    f4* colSum = st + 2 * TPT_Q_PATHS;                        // plane 2: per-path colour sums + pixel coordinates
     int chunkNext = 0, chunkEnd = 0; // this wave's private pixel pool
     int chunkFrame = 0;              // batched launch: the frame of the batch that pool belongs to
     bool noMoreChunks = false;
@@ -856,7 +863,7 @@ tptTraceQueueKernel(const KernelArgs a)
             // nothing to do for this wave right now: done if every path is free and no pixel is left anywhere
             const unsigned pool = __hip_atomic_load(&ctl->poolTotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const unsigned exhausted = __hip_atomic_load(&ctl->globalExhausted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (avail[Q_FREE] == (unsigned)TPT_Q_P && pool == 0u && exhausted != 0u && !canStart) break;
+            if (avail[Q_FREE] == (unsigned)TPT_Q_PATHS && pool == 0u && exhausted != 0u && !canStart) break;
             if (exhausted != 0u && pool == 0u) noMoreChunks = true;
             TPT_STAT(ST_REFILL); // idle polls
 #if defined(TPT_STATS)
@@ -891,14 +898,14 @@ tptTraceQueueKernel(const KernelArgs a)
         bool toFree = false; // this lane's path goes back to the FREE queue
         bool toEnd = false;  // Metal whose scattered ray points into the surface: the path ends (END class), nothing to intersect
         QStack stack;
-        stack.l0 = st + 3 * TPT_Q_P + p; // level 0 in the path record
-        stack.spill = a.stackBuf + ((size_t)blockIdx.x * TPT_Q_P + p);
+        stack.l0 = st + 3 * TPT_Q_PATHS + p; // level 0 in the path record
+        stack.spill = a.stackBuf + ((size_t)blockIdx.x * TPT_Q_PATHS + p);
         stack.stride = a.stackStride;
         QLambert lam;
         lam.sdir = lam.nl = lam.albedo = lam.lightE = mk3(0, 0, 0);
         lam.cosAMax = 0.0f;
         if (pick != Q_FREE && mine) {
-            const f4 r0 = st[0 * TPT_Q_P + p], r1 = st[1 * TPT_Q_P + p];
+            const f4 r0 = st[0 * TPT_Q_PATHS + p], r1 = st[1 * TPT_Q_PATHS + p];
             ro = mk3(r0.x, r0.y, r0.z);
             rng = f2u(r0.w);
             rd = mk3(r1.x, r1.y, r1.z);
@@ -1061,10 +1068,21 @@ tptTraceQueueKernel(const KernelArgs a)
                     go = ray && lightId != recId; // Test.cpp:100: not the sphere itself
                     if (go) d2 = qLightRay(sv.lights[j * 2], ro, rng, lam.cosAMax);
                 }
+#if TPT_MATRIX_FILTER
+                // phase 1 of HitSpheres for the whole wave on the matrix cores: every lane takes part (this loop is wave-uniform);
+                // lanes without a ray feed the finite values they hold and ignore their mask
+                uint64_t cand = 0ull;
+                if (LDS_SCENE && useMatrix) cand = phase1MatrixH(ldsA, mxR1, sv.nSpheres, ro, d2);
+#endif
                 if (go) {
                     TPT_STAT(ST_STEP);
                     float t;
+#if TPT_MATRIX_FILTER
+                    const int id = (LDS_SCENE && useMatrix) ? hitSpheresCandidates(sv, cand, ro, d2, TPT_MIN_T, TPT_MAX_T, t)
+                                                            : hitSpheres<LDS_SCENE ? HS_TWO_PHASE : HS_TWO_PHASE_GROUPS>(sv, ro, d2, TPT_MIN_T, TPT_MAX_T, t);
+#else
                     const int id = hitSpheres<LDS_SCENE ? HS_TWO_PHASE : HS_TWO_PHASE_GROUPS>(sv, ro, d2, TPT_MIN_T, TPT_MAX_T, t);
+#endif
                     myRays++;
                     if (shadow) {
                         if (id == lightId) qLightShade(l1, d2, lam);
@@ -1090,8 +1108,8 @@ tptTraceQueueKernel(const KernelArgs a)
         if (toEnd) cls = Q_END;
         if (ray || toEnd) {
             const uint32_t w = ((uint32_t)sample & 0x7ffu) | (((uint32_t)depth & 15u) << 11) | ((uint32_t)doMatE << 15) | (((uint32_t)recId & 0xffffu) << 16);
-            st[0 * TPT_Q_P + p] = mk4(ro.x, ro.y, ro.z, u2f(rng));
-            st[1 * TPT_Q_P + p] = mk4(rd.x, rd.y, rd.z, u2f(w));
+            st[0 * TPT_Q_PATHS + p] = mk4(ro.x, ro.y, ro.z, u2f(rng));
+            st[1 * TPT_Q_PATHS + p] = mk4(rd.x, rd.y, rd.z, u2f(w));
         }
         if (toFree) cls = Q_FREE;
         TPT_TSTAMP(tsInt);
@@ -1189,15 +1207,23 @@ __global__ void tptHitTestKernel(const KernelArgs a, const float* __restrict__ r
     outT[i] = t;
 }
 
-// matrix-core filter alone: n rays (n a multiple of 64; one wave per 64), candidate masks out
-__global__ void __launch_bounds__(64) tptMatrixFilterTestKernel(const KernelArgs a, const float* __restrict__ rays, unsigned long long* __restrict__ outMask, int n)
+// matrix-core filter alone: n rays (n a multiple of 64; one wave per 64), candidate masks out; outId / outT (optional): the
+// nearest hit through the filter + the exact test for its candidates (what the path-queue kernel runs)
+__global__ void __launch_bounds__(64) tptMatrixFilterTestKernel(const KernelArgs a, const float* __restrict__ rays, unsigned long long* __restrict__ outMask,
+                                                                int* __restrict__ outId, float* __restrict__ outT, int n)
 {
-    __shared__ float ldsA[2 * 6 * 64];
-    for (int i = threadIdx.x; i < 2 * 6 * 64; i += 64) ldsA[i] = a.scene.amat[i];
+    __shared__ __attribute__((aligned(16))) uint32_t ldsA[TPT_MXH_TABLE_DWORDS];
+    for (int i = threadIdx.x; i < TPT_MXH_TABLE_DWORDS; i += 64) ldsA[i] = a.scene.amatH[i];
     __syncthreads();
     const int i = blockIdx.x * 64 + threadIdx.x; // n is padded to whole waves by the caller
     f3 o = mk3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]), d = mk3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
-    outMask[i] = phase1Matrix(ldsA, a.scene.mxR1, o, d);
+    const uint64_t cand = phase1MatrixH(ldsA, a.scene.mxR1, a.scene.nSpheres, o, d);
+    if (outMask) outMask[i] = cand;
+    if (outId) {
+        float t;
+        outId[i] = hitSpheresCandidates(a.scene, cand, o, d, TPT_MIN_T, TPT_MAX_T, t);
+        outT[i] = t;
+    }
 }
 
 } // namespace tpt
@@ -1337,9 +1363,9 @@ size_t tptQueueLdsBytes(const KernelArgs& a, bool ldsScene)
     size_t bytes = 0;
     if (ldsScene) bytes += (size_t)nPad * 16 + (((size_t)nPad * 4 + 15) & ~(size_t)15) + (size_t)a.scene.nSpheres * 48;
     bytes += (size_t)a.scene.nLights * 32;
-    bytes += (size_t)TPT_Q_NF4 * TPT_Q_P * 16 + (size_t)Q_COUNT * TPT_Q_P * 2 + ((sizeof(QueueCtl) + 63) & ~(size_t)63) + ((sizeof(FrameConsts) + 15) & ~(size_t)15);
+    bytes += (size_t)TPT_Q_NF4 * TPT_Q_PATHS * 16 + (size_t)Q_COUNT * TPT_Q_P * 2 + ((sizeof(QueueCtl) + 63) & ~(size_t)63) + ((sizeof(FrameConsts) + 15) & ~(size_t)15);
 #if TPT_MATRIX_FILTER
-    if (ldsScene && a.scene.mxR1 >= 0) bytes += 2 * 6 * 64 * sizeof(float) + 64;
+    if (ldsScene && a.scene.mxR1 >= 0) bytes += TPT_MXH_TABLE_DWORDS * sizeof(uint32_t) + 64;
 #endif
     return bytes;
 }
@@ -1360,7 +1386,7 @@ hipError_t tptLaunchTraceQueue(const KernelArgs& a, bool ldsScene, int blocks, s
     if (e != hipSuccess) return e;
     return hipGetLastError();
 }
-int tptQueuePathsPerBlock() { return TPT_Q_P; }
+int tptQueuePathsPerBlock() { return TPT_Q_PATHS; }
 int tptQueueMatrixFilter() { return TPT_MATRIX_FILTER; }
 int tptQueueThreadsPerBlock() { return TPT_Q_T; }
 
@@ -1388,15 +1414,27 @@ hipError_t tptLaunchChunkOrder(const unsigned* cost, unsigned* snap, unsigned* o
     return hipGetLastError();
 }
 
+// Workgroups of a blend launch: one per 256 pixels up to a cap (env TPT_RESOLVE_BLOCKS for experiments), grid-stride beyond.
+static int g_resolveCap = -1;
+static int tptResolveBlocks(int nPixels)
+{
+    if (g_resolveCap < 0) {
+        const char* e = getenv("TPT_RESOLVE_BLOCKS");
+        g_resolveCap = (e && atoi(e) > 0) ? atoi(e) : 512;
+    }
+    const int need = (nPixels + 255) / 256;
+    return need < g_resolveCap ? need : g_resolveCap;
+}
 hipError_t tptLaunchResolve(float* tile, const f4* frameColour, int nPixels, float lerpFac, float* mirror,
                             unsigned long long* rayCounter, unsigned long long* counterOut, const unsigned long long* frameRays, hipStream_t stream)
 {
     if (nPixels <= 0) return hipSuccess;
+    const int blocks = tptResolveBlocks(nPixels);
     if (mirror)
-        hipLaunchKernelGGL(tptResolveMirrorKernel, dim3((nPixels + 255) / 256), dim3(256), 0, stream, tile, frameColour, nPixels, lerpFac,
+        hipLaunchKernelGGL(tptResolveMirrorKernel, dim3(blocks), dim3(256), 0, stream, tile, frameColour, nPixels, lerpFac,
                            reinterpret_cast<f4*>(mirror), rayCounter, counterOut);
     else
-        hipLaunchKernelGGL(tptResolveKernel, dim3((nPixels + 255) / 256), dim3(256), 0, stream, tile, frameColour, nPixels, lerpFac, frameRays, rayCounter);
+        hipLaunchKernelGGL(tptResolveKernel, dim3(blocks), dim3(256), 0, stream, tile, frameColour, nPixels, lerpFac, frameRays, rayCounter);
     return hipGetLastError();
 }
 
@@ -1404,7 +1442,7 @@ hipError_t tptLaunchResolveBatch(float* tile, const f4* frameColour, int nPixels
                                  float* mirror, unsigned long long* rayCounter, unsigned long long* counterOut, hipStream_t stream)
 {
     if (nPixels <= 0) return hipSuccess;
-    hipLaunchKernelGGL(tptResolveBatchKernel, dim3((nPixels + 255) / 256), dim3(256), 0, stream, tile, frameColour, nPixels, planeStride, nFrames, lerp,
+    hipLaunchKernelGGL(tptResolveBatchKernel, dim3(tptResolveBlocks(nPixels)), dim3(256), 0, stream, tile, frameColour, nPixels, planeStride, nFrames, lerp,
                        reinterpret_cast<f4*>(mirror), rayCounter, counterOut);
     return hipGetLastError();
 }
@@ -1419,9 +1457,9 @@ hipError_t tptLaunchMathExhaustive(int op, unsigned lo, unsigned hi, unsigned lo
     hipLaunchKernelGGL(tptMathExhaustiveKernel, dim3(8192), dim3(256), 0, stream, op, lo, hi, nBad, firstBad);
     return hipGetLastError();
 }
-hipError_t tptLaunchMatrixFilterTest(const KernelArgs& a, const float* rays, unsigned long long* outMask, int n, hipStream_t stream)
+hipError_t tptLaunchMatrixFilterTest(const KernelArgs& a, const float* rays, unsigned long long* outMask, int* outId, float* outT, int n, hipStream_t stream)
 {
-    hipLaunchKernelGGL(tptMatrixFilterTestKernel, dim3(n / 64), dim3(64), 0, stream, a, rays, outMask, n);
+    hipLaunchKernelGGL(tptMatrixFilterTestKernel, dim3(n / 64), dim3(64), 0, stream, a, rays, outMask, outId, outT, n);
     return hipGetLastError();
 }
 hipError_t tptLaunchHitTest(const KernelArgs& a, int hs, const float* rays, int* outId, float* outT, int n, hipStream_t stream)

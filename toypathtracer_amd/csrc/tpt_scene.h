@@ -125,46 +125,71 @@ struct PackedScene {
     std::vector<f4> bsph;      // the big spheres {centre, r^2} ...
     std::vector<int> bid;      // ... and their original indices (ascending)
     int nGroups = 0, nGroupPairs = 0, nBig = 0;
-    std::vector<float> amat; // [2][6][64] A operands of the matrix-core filter (phase1Matrix); empty: not available
+    std::vector<uint32_t> amatH; // [2][2][64][4] A operands of the matrix-core filter (phase1MatrixH); empty: not available
     int mxR1 = -1;
 };
 
-// a_k of one sphere for the matrix-core filter (tpt_trace.h, phase1Matrix): binary64, rounded once
+// a_k of one sphere for the matrix-core filter (tpt_trace.h, phase1MatrixH): binary64, rounded once; a_9 carries the
+// sphere side of the slack, m_s = 2^-13 |c|^2 + 2^-14 r^2 + 2^-20
 inline void matrixSphereSide(float fcx, float fcy, float fcz, float fr2, float* a)
 {
     const double cx = fcx, cy = fcy, cz = fcz, r2 = fr2;
     const double cc = cx * cx + cy * cy + cz * cz;
     const double v[TPT_MX_K] = {cx * cx, cy * cy, cz * cz, 2 * cx * cy, 2 * cx * cz, 2 * cy * cz, 2 * cx, 2 * cy, 2 * cz,
-                                (r2 - cc) + cc / 65536.0 + r2 / 131072.0, 1.0, 0.0};
+                                (r2 - cc) + cc / 8192.0 + r2 / 16384.0 + 1.0 / 1048576.0, 1.0};
     for (int k = 0; k < TPT_MX_K; ++k) a[k] = (float)v[k];
 }
 
-// Sphere side of the matrix-core filter (tpt_trace.h, phase1Matrix): a_k of every sphere, computed in binary64 and
-// rounded once, laid out as the lanes of v_mfma_f32_32x32x2_f32 read their A operand.  Scenes of up to 64 finite spheres.
+// Sphere side of the matrix-core filter: per sphere the 32 K-slot values (tpt_trace.h: slot table at phase1MatrixH), two
+// binary16 per dword, laid out as the lanes of v_mfma_f32_32x32x16_f16 read their A operand:
+// amatH[((mt * 2 + j) * 64 + lane) * 4 + w] holds slots 16 j + 8 (lane / 32) + 2 w, + 1 of the sphere in row lane % 32 of
+// sphere tile mt.  Scenes of up to 64 spheres whose a_k all fit binary16 (|a_k| < 60000); otherwise no table (mxR1 = -1)
+// and the packed VALU filter runs.
 inline void buildMatrixTable(const std::vector<SpherePOD>& S, PackedScene& P)
 {
-    P.amat.clear();
+    P.amatH.clear();
     P.mxR1 = -1;
     const int n = (int)S.size();
     if (n < 1 || n > 64) return;
-    for (int i = 0; i < n; ++i) {
-        const float r2 = S[i].radius * S[i].radius;
-        if (!(fabsf(S[i].cx) < 1e15f) || !(fabsf(S[i].cy) < 1e15f) || !(fabsf(S[i].cz) < 1e15f) || !(r2 < 1e30f)) return; // overflow / NaN: VALU filter
-    }
     int R1 = 0;
     if (n > 32) R1 = ((n - 32 + 1) / 2 + 3) / 4 * 4; // rows per half of tile 1, multiple of 4: capacity 2 (16 + R1) >= n
-    const float negInf = u2f(0xff800000u);
-    P.amat.assign(2 * 6 * 64, 0.0f);
-    // padding rows: a9 = -inf, everything else 0 -> the chain ends at -inf, sign set, never a candidate
+    std::vector<uint32_t> T(TPT_MXH_TABLE_DWORDS, 0u);
+    auto put = [&](int mt, int row, int slot, uint32_t h) {
+        const int j = slot / 16, within = slot % 16, lane = row + 32 * (within / 8), w = (within % 8) / 2;
+        uint32_t& d = T[(size_t)((mt * 2 + j) * 64 + lane) * 4 + w];
+        d = (slot & 1) ? ((d & 0x0000ffffu) | (h << 16)) : ((d & 0xffff0000u) | h);
+    };
+    // padding rows: a9_hi = -inf (slot 29, whose B value is 1), everything else 0: the sum is -inf, sign set, never a candidate
     for (int mt = 0; mt < 2; ++mt)
-        for (int row = 0; row < 32; ++row) P.amat[(size_t)(mt * 6 + 4) * 64 + 32 + row] = negInf; // k = 9: pair 4, upper half
+        for (int row = 0; row < 32; ++row) put(mt, row, 29, 0xfc00u);
     for (int p = 0; p < n; ++p) {
         int mt, row;
         matrixSlot(p, R1, mt, row);
         float a[TPT_MX_K];
         matrixSphereSide(S[p].cx, S[p].cy, S[p].cz, S[p].radius * S[p].radius, a); // r^2 as the exact test sees it (Test.cpp:329)
-        for (int k = 0; k < TPT_MX_K; ++k) P.amat[(size_t)(mt * 6 + k / 2) * 64 + 32 * (k & 1) + row] = a[k];
+        uint32_t hi[10], lo[10];
+        for (int k = 0; k < 10; ++k) {
+            if (!(fabsf(a[k]) < 60000.0f)) return; // (also NaN) binary16 cannot carry this sphere
+            hi[k] = f16rtz(a[k]);
+            lo[k] = f16rtz(a[k] - f16val(hi[k]));
+        }
+        const uint32_t one = 0x3c00u;
+        for (int t = 0; t < TPT_MXH_TERMS; ++t) {
+            put(mt, row, 2 * t, hi[t]);
+            put(mt, row, 2 * t + 1, hi[t]);
+        }
+        for (int u = 0; u < 4; ++u) {
+            put(mt, row, 18 + 2 * u, lo[2 * u]);
+            put(mt, row, 19 + 2 * u, lo[2 * u + 1]);
+        }
+        put(mt, row, 26, lo[8]);
+        put(mt, row, 27, one);
+        put(mt, row, 28, one);
+        put(mt, row, 29, hi[9]);
+        put(mt, row, 30, lo[9]);
+        put(mt, row, 31, 0u);
     }
+    P.amatH.swap(T);
     P.mxR1 = R1;
 }
 
@@ -352,7 +377,7 @@ inline SceneView viewOf(const PackedScene& P)
     sv.nGroups = P.nGroups;
     sv.nGroupPairs = P.nGroupPairs;
     sv.nBig = P.nBig;
-    sv.amat = P.amat.empty() ? nullptr : P.amat.data();
+    sv.amatH = P.amatH.empty() ? nullptr : P.amatH.data();
     sv.mxR1 = P.mxR1;
     return sv;
 }

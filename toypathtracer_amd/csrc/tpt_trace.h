@@ -72,10 +72,10 @@ struct SceneView {
     const f4* bsph;
     const int* bid;
     int nGroups, nGroupPairs, nBig;
-    // Matrix-core form of the phase-1 filter (scenes of <= 64 spheres; see phase1Matrix): amat = [2][6][64] f32, the A
-    // operands of the 2 x 6 v_mfma_f32_32x32x2_f32 a ray tile needs; mxR1 = rows per half of the second sphere tile that
-    // hold spheres (0, 4, ..., 16); mxR1 < 0: no table.
-    const float* amat;
+    // Matrix-core form of the phase-1 filter (scenes of <= 64 spheres in binary16 range; see phase1MatrixH): amatH =
+    // [2][2][64][4] dwords, the A operands of the 2 x 2 v_mfma_f32_32x32x16_f16 a ray tile needs; mxR1 = rows per half of the
+    // second sphere tile that hold spheres (0, 4, ..., 16); mxR1 < 0: no table.
+    const uint32_t* amatH;
     int mxR1;
 };
 #ifndef TPT_GROUP
@@ -306,22 +306,47 @@ TPT_HD int hitSpheresTwoPhase(const SceneView& sv, f3 o, f3 d, float tMin, float
 // origin instead of the ray origin:
 //   D = (co.d)^2 - |co|^2 + r^2,  co = c - o
 //     = (c.d)^2 + c.(2 o - 2 (o.d) d) + (r^2 - |c|^2) + ((o.d)^2 - |o|^2)
-//     = sum_k a_k(sphere) b_k(ray),  k = 0..11:
-//        a = { cx^2, cy^2, cz^2, 2 cx cy, 2 cx cz, 2 cy cz,  2 cx, 2 cy, 2 cz,  r^2 - |c|^2 + m_s,  1,  0 }
-//        b = { dx^2, dy^2, dz^2,   dx dy,   dx dz,   dy dz,   ex,   ey,   ez,                  1,  q,  0 },
-//   e = o - (o.d) d,  q = (o.d)^2 - |o|^2 (1 - 2^-16),  m_s = 2^-16 |c|^2 + 2^-17 r^2.
-// That is a [spheres x 12] x [12 x rays] product: six v_mfma_f32_32x32x2_f32 per 32 x 32 tile (f32 in, f32 accumulate,
-// an fmaf chain in k order), on the matrix pipe -- which this VALU-bound kernel otherwise leaves idle -- instead of 10
-// packed VALU instructions per sphere pair.  What is left for the VALU: 17 instructions for b, 6 lane swaps to lay b
-// out as B operands, one v_alignbit per (sphere, ray) for the sign, one swap to bring a ray's two row groups together.
-// Still a CONSERVATIVE filter (phase 2 re-tests everything that passes with the reference's arithmetic): the expansion
-// cancels at the scale (|c| + |o|)^2 instead of |c - o|^2, so the slack is m = 2^-16 (|c|^2 + |o|^2) + 2^-17 r^2
-// >= 2^-17 ((|c| + |o|)^2 + r^2) = 128 u (...).  Needed: the reference's own rounding, 13 u (|co|^2 + r^2) (phase1Pair),
-// plus this evaluation's: <= 3 u per term for the rounded a_k, b_k and 12 u for the chain, on
-// T = sum |a_k b_k| <= 2 (|c| + |o|)^2 + r^2, plus 4 u |c||o| + 4 u |o|^2 for e and q, i.e. < 38 u ((|c| + |o|)^2 + r^2):
-// 51 u in all, 2.5 x below the slack (same safety factor as phase1Pair; tests/adversarial_filter.cpp searches for misses).
-// For a 0.5-radius sphere ten units from the origin that inflates r^2 by 0.3 %.
-#define TPT_MX_K 12
+//     = sum_k a_k(sphere) b_k(ray),  k = 0..10:
+//        a = { cx^2, cy^2, cz^2, 2 cx cy, 2 cx cz, 2 cy cz,  2 cx, 2 cy, 2 cz,  r^2 - |c|^2 + m_s,  1 }
+//        b = { dx^2, dy^2, dz^2,   dx dy,   dx dz,   dy dz,   ex,   ey,   ez,                  1,  q },
+//   e = o - (o.d) d,  q = (o.d)^2 - |o|^2 (1 - 2^-13),  m_s = 2^-13 |c|^2 + 2^-14 r^2 + 2^-20.
+// That is a [spheres x K] x [K x rays] product, and the matrix pipe -- which this VALU-bound kernel otherwise leaves idle --
+// runs it at 16x the rate of the f32 vector unit if the operands are binary16.  They are made so WITHOUT giving up f32
+// accuracy: every factor is split into two binary16 pieces, x = hi + lo (hi = x truncated to binary16, lo = x - hi truncated
+// likewise), and a product a b becomes a_hi b_hi + a_hi b_lo + a_lo b_hi -- exact binary16 x binary16 products accumulated
+// in f32 by v_mfma_f32_32x32x16_f16; only a_lo b_lo is dropped.  32 K-slots per (sphere, ray) = two MFMAs per 32 x 32 tile:
+//   slots 2t, 2t+1      (t = 0..8): A = {a_hi[t], a_hi[t]},        B = {b_hi[t], b_lo[t]}
+//   slots 18+2u, 19+2u  (u = 0..3): A = {a_lo[2u], a_lo[2u+1]},    B = {b_hi[2u], b_hi[2u+1]}
+//   slots 26, 27:                   A = {a_lo[8], 1},              B = {b_hi[8], q_hi}
+//   slots 28, 29:                   A = {1, a9_hi},                B = {q_lo, 1}
+//   slots 30, 31:                   A = {a9_lo, 0},                B = {1, 0}
+// What is left for the VALU per 64 rays: 17 instructions for b, 35 to split and pack (v_and / v_sub / v_cvt_pkrtz), 8 lane
+// swaps to lay b out as B operands, one v_alignbit per (sphere, ray) for the sign, one swap to bring a ray's two row groups
+// together -- ~115 instead of the packed filter's 276 (configs[1]: 43.3 -> 55.2 Gray/s, configs[2]: 49.5 -> 65.1).
+//
+// Still a CONSERVATIVE filter (phase 2 re-tests everything that passes with the reference's arithmetic).  What has to hold:
+// D_ref > 0 (the reference's rounded discriminant, within 13 u (|co|^2 + r^2) of the real one, u = 2^-24: phase1Pair)  =>
+// the sum the MFMA delivers is >= 0.  With T = sum |a_k b_k| <= 2 (|c| + |o|)^2 + r^2, the delivered sum differs from
+// D + m (m = m_s + 2^-13 |o|^2) by at most
+//    2 u T                     a_k rounded once from binary64; b_k: one f32 rounding each (products of d) ...
+//  + 17 u (|c| + |o|)^2        ... and e, q: the 3-rounding dot products o.d, |o|^2 feeding them
+//  + 48 u T                    the split: |x - hi - lo| <= 2^-20 |x| = 16 u |x| on either side, and the dropped a_lo b_lo <= 16 u |a b|
+//  + 2 u (3 |c|^2 + 4 |c| + 2 |o| + 5)   binary16 subnormals: hi / lo below 2^-14 are kept to 2^-24 absolute (the conversion
+//                              and the MFMA honour subnormals on this device: tools/exhaustive/mfma_f16_probe.hip)
+//  + 64 u T                    the MFMA's own accumulation (32 products + the carried sum; measured on the device <= 2 ulp
+//                              of the largest term per instruction, i.e. ~8 u T; 64 u T is the bound the tests enforce:
+//                              test_matrix_filter_sign_agrees_with_the_exact_slot_sum)
+// <= 245 u (|c| + |o|)^2 + 114 u r^2 + ..., and with the reference's 13 u: < 520 u (|c|^2 + |o|^2) + 130 u r^2 + 10 u,
+// against the slack m = 2048 u (|c|^2 + |o|^2) + 1024 u r^2 + 16 u: a factor 3.9 to spare (tests/adversarial_filter.cpp
+// searches near-tangent configurations over six decades of scale for a miss of the WORST CASE, exact slot sum minus 64 u T).
+// For a 0.5-radius sphere eight units from the origin the slack inflates r^2 by 3 %.  Rays the binary16 range cannot carry
+// (|o|^2 >= 60000, or a direction that is not finite and about unit length) keep every sphere as a candidate; spheres it
+// cannot carry (|a_k| >= 60000, e.g. a 1000-unit ground sphere) or scenes of more than 64 spheres have no table and run the
+// packed VALU filter (phase1Pair).
+#define TPT_MX_K 11
+#define TPT_MXH_TERMS 9 /* product terms a_t b_t, t = 0..8; b_9 = 1 and a_10 = 1 are the two special terms */
+#define TPT_MXH_SLOTS 32
+#define TPT_MXH_TABLE_DWORDS (2 * 2 * 64 * 4) /* [sphere tile][k step][lane][4]: the A operands as the lanes read them */
 TPT_HD void matrixRaySide(f3 o, f3 d, float* b)
 {
     b[0] = d.x * d.x; b[1] = d.y * d.y; b[2] = d.z * d.z;
@@ -330,13 +355,57 @@ TPT_HD void matrixRaySide(f3 o, f3 d, float* b)
     b[6] = fma1(-od, d.x, o.x); b[7] = fma1(-od, d.y, o.y); b[8] = fma1(-od, d.z, o.z);
     const float oo = fma1(o.z, o.z, fma1(o.y, o.y, o.x * o.x));
     b[9] = 1.0f;
-    b[10] = fma1(od, od, -(oo * 0.9999847412109375f)); // 1 - 2^-16
-    b[11] = 0.0f;
+    b[10] = fma1(od, od, -(oo * 0.9998779296875f)); // 1 - 2^-13
 }
-// position of sphere p in the table: tile mt, row i of v_mfma_f32_32x32x2_f32's A operand.  The accumulator register r
-// of lane l holds row 8 (r / 4) + 4 (l / 32) + r % 4 of column l % 32: a lane's 16 + R1 sign bits, taken in register
-// order through tile 0 then tile 1, belong to spheres g n + 0 .. g n + n - 1 (g = l / 32, n = 16 + R1) -- so that the
-// assembled 64-bit mask lists the spheres in ascending index (phase 2's tie-break depends on that order).
+// rays the binary16 operands can carry: |o|^2 < 60000 (so |e|, |q| fit) and a finite direction of about unit length
+TPT_HD bool matrixRayInRange(f3 o, const float* b)
+{
+    const float oo = fma1(o.z, o.z, fma1(o.y, o.y, o.x * o.x)), dd = b[0] + b[1] + b[2];
+    return oo < 60000.0f && dd < 2.0f;
+}
+TPT_HD float f16hi(float x) { return u2f(f2u(x) & 0xffffe000u); } // x truncated to 11 significant bits (= binary16 for |x| >= 2^-14)
+// binary16 bit pattern of x rounded toward zero (x finite, |x| < 65520) and its value -- what v_cvt_pkrtz_f16_f32 delivers,
+// subnormals included -- for the sphere-side table and the host restatement
+TPT_HD uint32_t f16rtz(float x)
+{
+    const uint32_t u = f2u(x), sign = (u >> 16) & 0x8000u;
+    const int e = (int)((u >> 23) & 0xffu) - 127;
+    const uint32_t m = (u & 0x7fffffu) | 0x800000u;
+    if (e < -24 || (u & 0x7fffffffu) == 0u) return sign;
+    if (e < -14) return sign | (m >> (-1 - e)); // subnormal: multiples of 2^-24
+    return sign | ((uint32_t)(e + 15) << 10) | ((u >> 13) & 0x3ffu);
+}
+TPT_HD float f16val(uint32_t h)
+{
+    const int e = (int)((h >> 10) & 31u), f = (int)(h & 0x3ffu);
+    const float v = e == 0 ? (float)f * 5.9604644775390625e-08f : (float)(f | 0x400) * u2f((uint32_t)(e - 25 + 127) << 23); // f 2^-24 : (1.f) 2^(e-15)
+    return (h & 0x8000u) ? -v : v;
+}
+// the 32 B-side slot values of a ray, as the device packs them
+TPT_HD void matrixRaySlots(const float* b, float* slot)
+{
+    float hi[TPT_MXH_TERMS];
+    for (int t = 0; t < TPT_MXH_TERMS; ++t) {
+        hi[t] = f16hi(b[t]);
+        slot[2 * t] = f16val(f16rtz(hi[t]));
+        slot[2 * t + 1] = f16val(f16rtz(b[t] - hi[t]));
+    }
+    for (int u = 0; u < 4; ++u) {
+        slot[18 + 2 * u] = slot[4 * u];      // b_hi[2u]
+        slot[19 + 2 * u] = slot[4 * u + 2];  // b_hi[2u + 1]
+    }
+    const float qh = f16hi(b[10]);
+    slot[26] = slot[16];
+    slot[27] = f16val(f16rtz(qh));
+    slot[28] = f16val(f16rtz(b[10] - qh));
+    slot[29] = 1.0f;
+    slot[30] = 1.0f;
+    slot[31] = 0.0f;
+}
+// position of sphere p in the table: tile mt, row i of the A operand.  The accumulator register r of lane l holds row
+// 8 (r / 4) + 4 (l / 32) + r % 4 of column l % 32: a lane's 16 + R1 sign bits, taken in register order through tile 0 then
+// tile 1, belong to spheres g n + 0 .. g n + n - 1 (g = l / 32, n = 16 + R1) -- so that the assembled 64-bit mask lists the
+// spheres in ascending index (phase 2's tie-break depends on that order).
 TPT_HD void matrixSlot(int p, int R1, int& mt, int& row)
 {
     const int n = 16 + R1, g = p / n, q = p % n;
@@ -344,55 +413,103 @@ TPT_HD void matrixSlot(int p, int R1, int& mt, int& row)
     const int r = q < 16 ? q : q - 16;
     row = 8 * (r / 4) + 4 * g + r % 4;
 }
-// Host restatement of phase1Matrix for the CPU tests: same table, same b, the fmaf chain the MFMA runs.
-TPT_HD uint64_t phase1MatrixRef(const float* amat, int R1, int nSpheres, f3 o, f3 d)
+// A-side slot value of the sphere in (mt, row) from the table
+TPT_HD float matrixTableSlot(const uint32_t* amatH, int mt, int row, int slot)
 {
-    float b[TPT_MX_K];
+    const int j = slot / 16, within = slot % 16, lane = row + 32 * (within / 8), w = (within % 8) / 2;
+    const uint32_t d = amatH[((mt * 2 + j) * 64 + lane) * 4 + w];
+    return f16val((slot & 1) ? (d >> 16) : (d & 0xffffu));
+}
+// Host restatement of phase1MatrixH for the CPU tests: same table, same ray slots, the 32 products accumulated in f32 one
+// after the other (the MFMA's own order and internal width are the hardware's: within the bound above of each other, so the
+// two masks may differ where the sum is within ~100 u T of zero -- both are conservative).  outSum / outAbs (optional, per
+// sphere): the exact slot sum and sum of magnitudes in binary64, for the tests of the error model.
+TPT_HD uint64_t phase1MatrixHRef(const uint32_t* amatH, int R1, int nSpheres, f3 o, f3 d, double* outSum = nullptr, double* outAbs = nullptr)
+{
+    float b[TPT_MX_K], slot[TPT_MXH_SLOTS];
     matrixRaySide(o, d, b);
+    matrixRaySlots(b, slot);
+    const bool ok = matrixRayInRange(o, b);
     uint64_t cand = 0;
     for (int p = 0; p < nSpheres; ++p) {
         int mt, row;
         matrixSlot(p, R1, mt, row);
         float c = 0.0f;
-        for (int k = 0; k < TPT_MX_K; ++k) c = fma1(amat[(mt * 6 + k / 2) * 64 + 32 * (k & 1) + row], b[k], c);
-        if ((f2u(c) >> 31) == 0u) cand |= 0x8000000000000000ull >> p;
+        double cs = 0.0, ca = 0.0;
+        for (int k = 0; k < TPT_MXH_SLOTS; ++k) {
+            const float av = matrixTableSlot(amatH, mt, row, k);
+            c = c + av * slot[k]; // (a product of two binary16 values is exact in f32)
+            cs += (double)av * (double)slot[k];
+            ca += (double)av * (double)slot[k] < 0 ? -((double)av * (double)slot[k]) : (double)av * (double)slot[k];
+        }
+        if (outSum) outSum[p] = cs;
+        if (outAbs) outAbs[p] = ca;
+        if (!ok || (f2u(c) >> 31) == 0u) cand |= 0x8000000000000000ull >> p;
     }
     return cand;
 }
 #if defined(__HIPCC__) && !defined(__HIP_DEVICE_COMPILE__)
-__device__ uint64_t phase1Matrix(const float* ldsA, int R1, f3 o, f3 d); // (host pass of a .hip file: declaration only)
+__device__ uint64_t phase1MatrixH(const uint32_t* ldsA, int R1, int nSpheres, f3 o, f3 d); // (host pass of a .hip file: declaration only)
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef float v16f __attribute__((ext_vector_type(16)));
-__device__ __forceinline__ void swapHalves(float& x, float& y) // x <- {x.lo, y.lo}, y <- {x.hi, y.hi} (32-lane halves)
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef __fp16 v2h __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pkh(float a, float b) // {binary16(a), binary16(b)} (round toward zero), a in the low half
 {
-    auto r = __builtin_amdgcn_permlane32_swap(f2u(x), f2u(y), false, false);
-    x = u2f(r[0]);
-    y = u2f(r[1]);
+    const v2h h = __builtin_amdgcn_cvt_pkrtz(a, b);
+    uint32_t u;
+    __builtin_memcpy(&u, &h, 4);
+    return u;
 }
 // Candidate mask (sphere p at bit 63 - p) of the ray in this lane.  Must be called by ALL 64 lanes of the wave (lanes
-// without a ray pass anything finite and ignore the result).  ldsA: the scene's A-operand table in LDS.
-__device__ __forceinline__ uint64_t phase1Matrix(const float* ldsA, int R1, f3 o, f3 d)
+// without a ray ignore the result; a lane's operands reach its own column only, so whatever it feeds cannot disturb another
+// ray).  ldsA: the scene's A-operand table in LDS, [sphere tile][k step][lane] uint4.
+__device__ __forceinline__ uint64_t phase1MatrixH(const uint32_t* ldsA, int R1, int nSpheres, f3 o, f3 d)
 {
     float b[TPT_MX_K];
     matrixRaySide(o, d, b);
-    // B operand of k-pair kk for the ray tile nt: lane l holds b[2 kk + l / 32] of ray 32 nt + l % 32
-    float B0[6], B1[6];
+    const bool ok = matrixRayInRange(o, b);
+    uint32_t V[16];
+    float hi[TPT_MXH_TERMS];
 #pragma unroll
-    for (int kk = 0; kk < 6; ++kk) {
-        B0[kk] = b[2 * kk];
-        B1[kk] = b[2 * kk + 1];
-        swapHalves(B0[kk], B1[kk]);
+    for (int t = 0; t < TPT_MXH_TERMS; ++t) {
+        hi[t] = f16hi(b[t]);
+        V[t] = pkh(hi[t], b[t] - hi[t]);
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) V[9 + u] = pkh(hi[2 * u], hi[2 * u + 1]);
+    const float qh = f16hi(b[10]);
+    V[13] = pkh(hi[8], qh);
+    V[14] = pkh(b[10] - qh, 1.0f);
+    V[15] = 0x00003c00u; // {1, 0}
+    // B operands: MFMA j of ray tile 0 / 1 reads slots 16 j .. 16 j + 7 from lanes 0..31 and 16 j + 8 .. 16 j + 15 from lanes
+    // 32..63 -- of the SAME ray: one half-swap per register pair hands every lane's upper slots to its partner lane
+    uint32_t B0[2][4], B1[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            auto sw = __builtin_amdgcn_permlane32_swap(V[8 * j + r], V[8 * j + 4 + r], false, false);
+            B0[j][r] = sw[0];
+            B1[j][r] = sw[1];
+        }
     const int lane = (int)(threadIdx.x & 63u);
+    const uint4* A = reinterpret_cast<const uint4*>(ldsA);
     uint32_t W0 = 0, W1 = 0; // sign bits of this lane's accumulator rows, ray tile 0 / 1
+    auto asH = [](const uint32_t* p) {
+        v8h h;
+        __builtin_memcpy(&h, p, 16);
+        return h;
+    };
     {
         v16f c0 = {0}, c1 = {0};
 #pragma unroll
-        for (int kk = 0; kk < 6; ++kk) {
-            const float a = ldsA[kk * 64 + lane];
-            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, B0[kk], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, B1[kk], c1, 0, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+            const uint4 a4 = A[j * 64 + lane];
+            const uint32_t aw[4] = {a4.x, a4.y, a4.z, a4.w};
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(asH(aw), asH(B0[j]), c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(asH(aw), asH(B1[j]), c1, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -403,10 +520,11 @@ __device__ __forceinline__ uint64_t phase1Matrix(const float* ldsA, int R1, f3 o
     if (R1 > 0) {
         v16f c0 = {0}, c1 = {0};
 #pragma unroll
-        for (int kk = 0; kk < 6; ++kk) {
-            const float a = ldsA[(6 + kk) * 64 + lane];
-            c0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, B0[kk], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, B1[kk], c1, 0, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+            const uint4 a4 = A[(2 + j) * 64 + lane];
+            const uint32_t aw[4] = {a4.x, a4.y, a4.z, a4.w};
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(asH(aw), asH(B0[j]), c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(asH(aw), asH(B1[j]), c1, 0, 0, 0);
         }
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
@@ -425,8 +543,8 @@ __device__ __forceinline__ uint64_t phase1Matrix(const float* ldsA, int R1, f3 o
     const uint32_t G0 = sw[0], G1 = sw[1];
     const int n = 16 + R1; // spheres per row group
     const uint64_t rejected = ((uint64_t)G0 << (64 - n)) | ((uint64_t)G1 << (64 - 2 * n));
-    const uint64_t valid = n == 32 ? ~0ull : ~(~0ull >> (2 * n));
-    return ~rejected & valid;
+    const uint64_t valid = ~0ull << (64 - nSpheres); // (padding rows end at -inf, but a NaN ray must not keep them either)
+    return ok ? (~rejected & valid) : valid;
 }
 #endif
 // phase 2 over a candidate mask (sphere p at bit 63 - p): the reference's arithmetic, ascending index
@@ -434,12 +552,18 @@ TPT_HD int hitSpheresCandidates(const SceneView& sv, uint64_t cand, f3 o, f3 d, 
 {
     float hitT = tMax;
     int id = -1;
+    unsigned hsTrips_ = 0;
+    (void)hsTrips_;
+    TPT_HS_STAMP(t1_);
     while (cand) {
         const int i = __builtin_clzll(cand);
         cand &= ~(0x8000000000000000ull >> i);
         TPT_STAT(ST_PHASE2);
+        TPT_HS_TRIP();
         testSphere(sv.sph4[i], i, o, d, tMin, hitT, id);
     }
+    TPT_HS_STAMP(t2_);
+    TPT_HS_ADD(t1_, t1_, t2_);
     outT = hitT;
     return id;
 }
@@ -578,8 +702,8 @@ TPT_HD int hitSpheres(const SceneView& sv, f3 o, f3 d, float tMin, float tMax, f
 {
     if (HS == HS_SIMPLE) return hitSpheresSimple(sv, o, d, tMin, tMax, outT);
 #if !defined(__HIP_DEVICE_COMPILE__)
-    // host tests: the matrix filter's restatement (on the device the kernels call phase1Matrix wave-wide themselves)
-    if (HS == HS_MATRIX && sv.mxR1 >= 0) return hitSpheresCandidates(sv, phase1MatrixRef(sv.amat, sv.mxR1, sv.nSpheres, o, d), o, d, tMin, tMax, outT);
+    // host tests: the matrix filter's restatement (on the device the kernels call phase1MatrixH wave-wide themselves)
+    if (HS == HS_MATRIX && sv.mxR1 >= 0) return hitSpheresCandidates(sv, phase1MatrixHRef(sv.amatH, sv.mxR1, sv.nSpheres, o, d), o, d, tMin, tMax, outT);
 #endif
     // (kernels that stage the scene in LDS are instantiated without the grouped code: such scenes are small and never
     //  grouped, and the extra registers cost the 46-sphere kernel 4 %)

@@ -209,6 +209,26 @@ def row_serial_rate(api, width, height, frames=3):
     return dt / frames * 1e3, rays / dt / 1e6
 
 
+def row_serial_batched_rate(api, torch, width, height, per_launch=32, launches=3):
+    """ROW_SERIAL seeds through tptDrawDeviceBatch: per_launch frames x rows lanes per launch (rows AND frames are independent
+    RNG streams in the reference, Test.cpp:280) -- the reference's exact image, bit for bit, at GPU speed."""
+    api.set_seed_mode(0)
+    tile = torch.zeros((height, width, 4), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    api.UpdateTest(0.0, 0, width, height, FLAG_PROGRESSIVE)
+    api.draw_device_batch(0.0, 0, per_launch, width, height, tile.data_ptr(), FLAG_PROGRESSIVE)
+    r0 = api.ray_counter_read()  # synchronises
+    t0 = time.perf_counter()
+    f = per_launch
+    for _ in range(launches):
+        api.draw_device_batch(0.0, f, per_launch, width, height, tile.data_ptr(), FLAG_PROGRESSIVE)
+        f += per_launch
+    rays = api.ray_counter_read() - r0
+    dt = time.perf_counter() - t0
+    api.set_seed_mode(1)
+    return dt / (launches * per_launch) * 1e3, rays / dt / 1e6
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -218,8 +238,8 @@ def main():
     ap.add_argument("--stripe-rows", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the host-pointer DrawTest and ROW_SERIAL legs after the timed region")
-    ap.add_argument("--hit-spheres", type=int, default=0, help="0 two-phase, grouped traversal for >= 256 spheres (default); 1 simple loop; 2 two-phase brute force; 3 as 0 without the matrix-core filter table (only matters for -DTPT_MATRIX_FILTER=1 builds)")
-    ap.add_argument("--persistent", type=int, default=3, help="3 path queues (default) 1 persistent waves with lane refill 0 thread-per-pixel 2 lane-sorting")
+    ap.add_argument("--hit-spheres", type=int, default=0, help="0 two-phase: matrix-core filter for <= 64 spheres, grouped traversal for >= 256 (default); 1 simple loop; 2 two-phase brute force; 3 as 0 with the packed VALU filter instead of the matrix-core one")
+    ap.add_argument("--persistent", type=int, default=3, choices=[1, 3], help="3 path queues (default) 1 persistent waves with lane refill (the fallback kernel)")
     ap.add_argument("--fold", type=int, default=0, help="0 recursive (reference order, default) 1 forward")
     ap.add_argument("--lds-scene", type=int, default=-1)
     ap.add_argument("--batch", type=int, default=1,
@@ -426,7 +446,7 @@ def main():
             "exchange": exchange, "rccl_ranks": world if exchange != "none" else 0,
             "config": {"workload": label, "width": width, "height": height, "spp": spp, "spheres": n_spheres,
                        "seed_mode": "per_pixel", "fold": "forward" if args.fold else "recursive",
-                       "hit_spheres": ["two_phase" + ("+groups" if n_spheres >= 256 else ""), "simple", "two_phase_brute_force", "two_phase"][args.hit_spheres], "kernel": ["thread_per_pixel", "persistent_waves", "lane_sorting", "path_queues"][args.persistent], "frame_overlap": args.overlap, "frames_per_launch": args.batch,
+                       "hit_spheres": ["two_phase" + ("+groups" if n_spheres >= 256 else "+matrix_core_filter" if n_spheres <= 64 else ""), "simple", "two_phase_brute_force", "two_phase_valu_filter"][args.hit_spheres], "kernel": {1: "persistent_waves", 3: "path_queues"}[args.persistent], "frame_overlap": args.overlap, "frames_per_launch": args.batch,
                        "untimed_priming_frames": args.prime,
                        "flags": "progressive|animate" if args.animate else "progressive",
                        "sharding": "none" if world == 1 else "row stripes of %d, round-robin over %d ranks, pipelined gather to rank 0" % (args.stripe_rows, world),
@@ -449,7 +469,7 @@ def main():
                          "achieved_read_plus_write": 2 * hbm_write_gbs * k_ms / pl_ms, "launch_ms_avg": k_ms, "launches": launches,
                          "note": "north_star's HBM-write roofline (W*H*16 B per frame).  The kernel is FP32-VALU bound (arithmetic "
                                  "intensity ~440 flop/B against a machine balance of ~20): see roofline_valu, the binding one",
-                         "kernel": ["tptTraceKernel", "tptTraceKernel", "tptTraceSortedKernel", "tptTraceQueueKernel"][args.persistent]},
+                         "kernel": {1: "tptTraceKernel", 3: "tptTraceQueueKernel"}[args.persistent]},
             "roofline_valu": {"bound": "valu_fp32", "achieved": valu_tflops * k_ms / pl_ms, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                               "frac": valu_tflops * k_ms / pl_ms / PEAK_FP32_TFLOPS,
                               "achieved_per_launch": valu_tflops, "frac_per_launch": valu_tflops / PEAK_FP32_TFLOPS,
@@ -489,7 +509,11 @@ def main():
             if scene == "default" and width * height <= 1280 * 720:
                 ms, mr = row_serial_rate(api, width, height)
                 out["row_serial_ms"], out["row_serial_Mray_s"] = ms, mr
-                out["row_serial_note"] = "seed mode 0: the reference's per-row RNG streams (bit-identical CPU image), one lane per image row"
+                out["row_serial_note"] = "seed mode 0: the reference's per-row RNG streams (bit-identical CPU image), one lane per image row, frame by frame through DrawTest(host buffer)"
+                ms, mr = row_serial_batched_rate(api, torch, width, height)
+                out["row_serial_batched_32_ms_per_frame"], out["row_serial_batched_32_Mray_s"] = ms, mr
+                out["row_serial_batched_note"] = ("seed mode 0 through tptDrawDeviceBatch: 32 frames x rows lanes per launch on a device tile -- the reference's exact "
+                                                  "image (golden hashes 609aacda / 46afd557 reproduced by tests/test_gpu_parity.py) at GPU speed")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(width, height, spp)
         print(json.dumps(out), flush=True)

@@ -199,13 +199,15 @@ int tptKernelTimingEnd(float* outSumMilliseconds, int* outLaunches);
 
 /* ================= 4. tuning / test hooks ================= */
 
-/* hitSpheres: 0 = two-phase (default: conservative FMA filter + the reference's exact test for what passes; scenes of
- * 256 spheres or more are traversed through compact groups of <= 16 spheres with bounding spheres -- same hits, same
- * tie-break, ~4x faster on the 4096-sphere scene), 1 = simple loop (exact test for every sphere), 2 = two-phase
- * without grouping (brute force over all spheres, the reference's cost model).  persistent: 3 = path queues in LDS (default; per-pixel seeds,
- * recursive fold, two-phase only -- anything else falls back to 1), 1 = persistent waves with lane refill,
- * 0 = one thread per pixel, 2 = lane-sorting workgroups (experimental).  ldsScene: 1 = stage sphere records and materials in LDS (default
- * when they fit), 0 = read them from global memory, -1 = auto.  All variants produce identical bits. */
+/* hitSpheres: 0 = two-phase (default: a conservative filter + the reference's exact test for what passes.  The filter runs
+ * on the matrix cores for scenes of <= 64 spheres that binary16 operands can carry, as packed FP32 on the VALU otherwise;
+ * scenes of 256 spheres or more are traversed through compact groups of <= 16 spheres with bounding spheres -- same hits,
+ * same tie-break, ~4x faster on the 4096-sphere scene), 1 = simple loop (exact test for every sphere), 2 = two-phase
+ * without grouping (brute force over all spheres, the reference's cost model), 3 = two-phase with the packed VALU filter
+ * everywhere (no matrix-core table).  persistent: 3 = path queues in LDS (default; per-pixel seeds, recursive fold, two-phase
+ * only -- anything else falls back to 1), 1 = persistent waves with lane refill (any other value selects 3).  ldsScene:
+ * 1 = stage sphere records and materials in LDS (default when they fit), 0 = read them from global memory, -1 = auto.
+ * All variants produce identical bits. */
 int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene);
 /* device math unit tests: op 0 sqrt 1 div 2 sin 3 cos 4 pow5 5 rnd01^16 6 schlick 7 normalize.x; host arrays */
 int tptTestMath(int op, const float* a, const float* b, float* out, int n);

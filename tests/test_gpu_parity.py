@@ -37,15 +37,37 @@ def test_row_serial_reproduces_reference_golden_hashes(tpt_defaults, case):
     assert float(np.abs(bb[..., 3]).max()) == 0.0
 
 
+@pytest.mark.parametrize("case", [c for c in goldens() if c["flags"] == FLAG_PROGRESSIVE and c["frames"] >= 2],
+                         ids=lambda c: "%dx%dx%d_f%d" % (c["width"], c["height"], c["spp"], c["frames"]))
+def test_row_serial_batched_launch_reproduces_reference_golden_hashes(tpt_defaults, case):
+    """The reference's image at GPU speed: in its own seed mode every (frame, row) is an independent RNG stream (Test.cpp:280),
+    so tptDrawDeviceBatch traces all frames of a golden case in ONE launch of the lane-refill kernel -- frames x rows lanes
+    instead of rows -- and blends them in frame order.  Same FNV hashes as the reference's CPU build (BASELINE.md section 2:
+    609aacda for F = 2, 16cce49a for F = 3, 46afd557 for F = 10 at 1280x720x4), same ray totals."""
+    import torch
+    tpt = tpt_defaults
+    tpt.set_seed_mode(SEED_ROW_SERIAL)
+    tpt.set_samples_per_pixel(case["spp"])
+    w, h, frames = case["width"], case["height"], case["frames"]
+    tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+    r0 = tpt.ray_counter_read()
+    tpt.UpdateTest(0.0, 0, w, h, FLAG_PROGRESSIVE)
+    tpt.draw_device_batch(0.0, 0, frames, w, h, tile.data_ptr(), FLAG_PROGRESSIVE)
+    rays = tpt.ray_counter_read() - r0
+    bb = tile.cpu().numpy()
+    assert rays == case["rays"]
+    assert "%08x" % fnv1a(bb) == case["fnv"]
+
+
 # ---- 2. production mode (per-pixel seeds) against the oracle, every kernel variant
-@pytest.mark.parametrize("persist", [3, 2, 1, 0], ids=["path_queues", "sorted", "persistent", "static"])
+@pytest.mark.parametrize("persist", [3, 1], ids=["path_queues", "lane_refill"])
 @pytest.mark.parametrize("hs", [0, 1], ids=["two_phase", "simple"])
 @pytest.mark.parametrize("fold", [FOLD_RECURSIVE, FOLD_FORWARD], ids=["recursive", "forward"])
 def test_per_pixel_bit_exact_all_variants(tpt_defaults, oracle, persist, hs, fold):
     tpt = tpt_defaults
     w, h, spp, frames = 320, 184, 4, 3
-    if persist >= 2 and hs == 1:
-        pytest.skip("the lane-sorting / path-queue kernels always use the two-phase HitSpheres")
+    if persist == 3 and hs == 1:
+        pytest.skip("the path-queue kernel always uses the two-phase HitSpheres")
     if persist == 3 and fold == FOLD_FORWARD:
         pytest.skip("the path-queue kernel implements the recursive (reference-order) fold only")
     tpt.set_kernel_variant(hs, persist, -1)
@@ -231,8 +253,8 @@ def test_config3_3840x2160_16spp_full_parity(tpt_defaults, oracle):
     s, m = oracle.default_scene()
     ro, bo = oracle.render(s, m, oracle.default_camera(w, h), w, h, spp, 0, seed_mode=SEED_PER_PIXEL)
     assert r1 == ro and b1.tobytes() == bo.tobytes()
-    # static thread-per-pixel variant gives the same frame
-    tpt.set_kernel_variant(0, 0, -1)
+    # the packed VALU filter instead of the matrix-core one gives the same frame
+    tpt.set_kernel_variant(3, 3, -1)
     r3, b3, _ = gpu_frames(tpt, w, h, 1)
     assert r3 == r1 and b3.tobytes() == b1.tobytes()
 
@@ -472,10 +494,10 @@ def test_animated_scene_async_upload_ring(tpt_defaults, oracle, overlap):
     tpt.set_frame_overlap(16)
 
 
-@pytest.mark.parametrize("variant,fold", [(2, FOLD_RECURSIVE), (2, FOLD_FORWARD), (3, FOLD_RECURSIVE)],
-                         ids=["sorted-recursive", "sorted-forward", "path_queues-recursive"])
-def test_experimental_kernels_full_size_and_stress(tpt_defaults, oracle, variant, fold):
-    """Lane-sorting and path-queue kernels: configs[1] in full, ragged size, and the 4096-sphere scene."""
+@pytest.mark.parametrize("variant,fold", [(1, FOLD_RECURSIVE), (1, FOLD_FORWARD), (3, FOLD_RECURSIVE)],
+                         ids=["lane_refill-recursive", "lane_refill-forward", "path_queues-recursive"])
+def test_both_kernels_full_size_and_stress(tpt_defaults, oracle, variant, fold):
+    """Lane-refill and path-queue kernels: configs[1] in full, ragged size, and the 4096-sphere scene."""
     from toypathtracer_amd.scenes import STRESS_CAMERA, stress_scene
     tpt = tpt_defaults
     tpt.set_kernel_variant(0, variant, -1)

@@ -5,9 +5,6 @@
 #ifndef TPT_BLOCK
 #define TPT_BLOCK 64         // threads per workgroup: one wave, so a finished wave frees its LDS/VGPRs at once
 #endif
-#ifndef TPT_SORT_WAVES
-#define TPT_SORT_WAVES 4     // waves per workgroup of the lane-sorting kernel (lanes are regrouped across these)
-#endif
 #define TPT_CHUNK_PIXELS 256 // pixels a persistent wave pulls per atomic (4 tiles of 8x8)
 
 namespace tpt {
@@ -29,7 +26,6 @@ struct KernelArgs {
     unsigned totalWaves;
     // FOLD_RECURSIVE bounce stack: the first ldsStackLevels levels live in LDS (per thread), deeper ones in
     // stackBuf [TPT_MAX_DEPTH - ldsStackLevels][stackStride] (global, one column per thread of the launch).
-    // The lane-sorting kernel uses ldsStackLevels = 0: a path keeps its column while it moves between lanes.
     f4* stackBuf;
     int stackStride;
     int ldsStackLevels;
@@ -46,11 +42,8 @@ struct KernelArgs {
 } // namespace tpt
 
 size_t tptLdsBytes(const tpt::KernelArgs& a, int fold, bool ldsScene); // uses a.ldsStackLevels
-hipError_t tptLaunchTrace(const tpt::KernelArgs& a, int hs, int fold, bool persist, bool ldsScene, int blocks, size_t lds, hipStream_t stream);
-int tptTraceOccupancy(int hs, int fold, bool persist, bool ldsScene, size_t lds);
-size_t tptSortedLdsBytes(const tpt::KernelArgs& a, int fold, bool ldsScene);
-hipError_t tptLaunchTraceSorted(const tpt::KernelArgs& a, int fold, bool ldsScene, int blocks, size_t lds, hipStream_t stream);
-int tptTraceSortedOccupancy(int fold, bool ldsScene, size_t lds);
+hipError_t tptLaunchTrace(const tpt::KernelArgs& a, int hs, int fold, bool ldsScene, int blocks, size_t lds, hipStream_t stream);
+int tptTraceOccupancy(int hs, int fold, bool ldsScene, size_t lds);
 size_t tptQueueLdsBytes(const tpt::KernelArgs& a, bool ldsScene);
 hipError_t tptLaunchTraceQueue(const tpt::KernelArgs& a, bool ldsScene, int blocks, size_t lds, hipStream_t stream);
 int tptQueuePathsPerBlock();

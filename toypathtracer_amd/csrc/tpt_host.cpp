@@ -718,7 +718,7 @@ int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene)
         g.useMatrix = matrix;
         g.sceneDirty = true; // the staged scene set carries (or not) the grouped arrays / the matrix table
     }
-    g.persist = persistent < 0 ? 0 : (persistent > 3 ? 3 : persistent);
+    g.persist = persistent == 1 ? 1 : 3; // 3 = path queues (default), 1 = lane-refill kernel; the experimental variants 0 and 2 are gone
     g.configEpoch++;
     g.ldsScene = ldsScene < 0 ? -1 : (ldsScene ? 1 : 0);
     return 0;
@@ -811,7 +811,7 @@ namespace {
 // Everything decided about a frame before anything is enqueued.
 struct FramePlan {
     KernelArgs a;
-    bool rowSerial = false, sorted = false, queued = false, ldsScene = false, useOrder = false;
+    bool rowSerial = false, queued = false, ldsScene = false, useOrder = false;
     size_t lds = 0;
     int occ = 0, threadsPerBlock = 0, blocks = 0;
     int nOverlap = 1;           // launches that may run side by side (trace streams in use)
@@ -828,12 +828,39 @@ struct FramePlan {
 int syncAllStreams();
 int reserveSlotBuffers(int nSlots, size_t colourBytes, size_t stackBytes, size_t pathBytes)
 { // (stack / path buffers are used while the kernel runs only: indexed by stream, allocated for the first kMaxOverlap slots)
-    if (nSlots <= g.slotsReserved && colourBytes <= g.colourCap && stackBytes <= g.stackCap && pathBytes <= g.pathCap) return 0;
+    // Memory that a large batched frame pinned is given back when the caller returns to frames a quarter of that size and more
+    // than 1 GiB of colour slots is held (one drain, like a growth); anything smaller stays (no churn between similar shapes).
+    const bool shrink = colourBytes * 4 <= g.colourCap && g.colourCap * (size_t)g.slotsReserved > (1ull << 30);
+    if (!shrink && nSlots <= g.slotsReserved && colourBytes <= g.colourCap && stackBytes <= g.stackCap && pathBytes <= g.pathCap) return 0;
     int rc = syncAllStreams();
     if (rc) return rc;
+    if (shrink) {
+        for (int k = 0; k < g.slotsReserved; ++k) {
+            if (g.dColour[k]) HIPCHK(hipFree(g.dColour[k]));
+            g.dColour[k] = nullptr;
+        }
+        g.colourCap = 0;
+    }
     const size_t cb = colourBytes > g.colourCap ? colourBytes : g.colourCap, sb = stackBytes > g.stackCap ? stackBytes : g.stackCap,
                  pb = pathBytes > g.pathCap ? pathBytes : g.pathCap;
     const int n = nSlots > g.slotsReserved ? nSlots : g.slotsReserved;
+    {
+        // refuse BEFORE anything is freed when the device cannot hold the request (a failed hipMalloc half-way would leave the
+        // context without its buffers)
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+            size_t need = 0;
+            for (int k = 0; k < n; ++k) {
+                const bool fresh = k >= g.slotsReserved;
+                if (fresh || cb > g.colourCap) need += cb;
+                if ((fresh || sb > g.stackCap) && k < Context::kMaxOverlap) need += sb;
+            }
+            const size_t held = (cb > g.colourCap ? g.colourCap * (size_t)g.slotsReserved : 0);
+            if (need > freeB + held)
+                return fail("frame buffers: " + std::to_string(need >> 20) + " MiB needed for " + std::to_string(n) + " frame slots, " +
+                            std::to_string((freeB + held) >> 20) + " MiB available on the device (smaller batch / frame, or fewer frames in flight: tptSetFrameOverlap)");
+        }
+    }
     for (int k = 0; k < n; ++k) {
         const bool fresh = k >= g.slotsReserved;
         if (fresh || cb > g.colourCap) {
@@ -867,21 +894,18 @@ int chooseKernel(FramePlan& P)
     const int nPad = a.scene.nPairs * 2;
     P.ldsScene = g.ldsScene < 0 ? ((size_t)nPad * 20 + (size_t)a.scene.nSpheres * 48 <= 40960) : (g.ldsScene != 0);
     if (a.scene.nGroups > 0) P.ldsScene = false; // the LDS-staging kernels are built without the grouped traversal
-    // bounce stack: the lane-refill kernel keeps the first levels in LDS and spills the rare deep ones to global memory;
-    // the thread-per-pixel kernel (huge grids) keeps all of it in LDS
-    a.ldsStackLevels = (g.persist && g.foldMode == FOLD_RECURSIVE) ? g.ldsStackLevels : TPT_MAX_DEPTH;
+    // bounce stack: the lane-refill kernel keeps the first levels in LDS and spills the rare deep ones to global memory
+    a.ldsStackLevels = g.foldMode == FOLD_RECURSIVE ? g.ldsStackLevels : TPT_MAX_DEPTH;
     const size_t ldsV1 = tptLdsBytes(a, g.foldMode, P.ldsScene);
-    P.sorted = g.persist == 2 && !P.rowSerial && g.hs == HS_TWO_PHASE; // lane-sorting kernel (PER_PIXEL seeds only)
     // path-queue kernel: PER_PIXEL seeds, recursive fold, two-phase HitSpheres
     // (it packs a pixel as x | y << 16 and a path id as 16 bits: larger frames take the lane-refill kernel)
     // (so does its 64-B path record: 11 bits of sample index, 16 of sphere id)
     P.queued = g.persist == 3 && !P.rowSerial && g.hs == HS_TWO_PHASE && g.foldMode == FOLD_RECURSIVE && a.fc.width <= 65535 &&
                a.fc.height <= 65535 && g.spp <= 2047 && a.scene.nSpheres <= 65534;
-    P.lds = P.queued ? tptQueueLdsBytes(a, P.ldsScene) : P.sorted ? tptSortedLdsBytes(a, g.foldMode, P.ldsScene) : ldsV1;
+    P.lds = P.queued ? tptQueueLdsBytes(a, P.ldsScene) : ldsV1;
     if ((size_t)a.scene.nLights * 32 > 96 * 1024)
         return fail("tptDrawDevice: too many emissive spheres for the LDS light table (3072 at most)");
     if (P.lds > 160 * 1024) return fail("tptDrawDevice: scene too large for LDS staging; use tptSetKernelVariant(.., .., 0)");
-    if (P.sorted) a.ldsStackLevels = 0;
     if (P.queued) {
         a.ldsStackLevels = 1; // level 0 of the bounce stack sits in the path record (LDS), levels 1-9 in global memory
         // two workgroups per CU are worth more than the scene in LDS: a scene that costs the second workgroup its place
@@ -891,18 +915,15 @@ int chooseKernel(FramePlan& P)
             P.lds = tptQueueLdsBytes(a, false);
         }
     }
-    const int key = (P.queued ? (1 << 30) : 0) | (P.sorted ? 16 : 0) | (g.hs ? 8 : 0) | (g.foldMode ? 4 : 0) | (g.persist ? 2 : 0) |
-                    (P.ldsScene ? 1 : 0) | ((int)(P.lds / 256) << 5);
+    const int key = (P.queued ? (1 << 30) : 0) | (g.hs ? 8 : 0) | (g.foldMode ? 4 : 0) | (P.ldsScene ? 1 : 0) | ((int)(P.lds / 256) << 5);
     auto it = g.occCache.find(key);
     if (it == g.occCache.end()) {
-        P.occ = P.queued   ? (int)(160 * 1024 / (P.lds + 256))
-                : P.sorted ? tptTraceSortedOccupancy(g.foldMode, P.ldsScene, P.lds)
-                           : tptTraceOccupancy(g.hs, g.foldMode, g.persist != 0, P.ldsScene, P.lds);
+        P.occ = P.queued ? (int)(160 * 1024 / (P.lds + 256)) : tptTraceOccupancy(g.hs, g.foldMode, P.ldsScene, P.lds);
         g.occCache[key] = P.occ;
     } else {
         P.occ = it->second;
     }
-    P.threadsPerBlock = P.queued ? tptQueueThreadsPerBlock() : P.sorted ? 64 * TPT_SORT_WAVES : TPT_BLOCK;
+    P.threadsPerBlock = P.queued ? tptQueueThreadsPerBlock() : TPT_BLOCK;
     return 0;
 }
 
@@ -912,13 +933,6 @@ const int kBurstFrames = 24; // frames after an idle pipeline that are launched 
 void sizeGrid(FramePlan& P)
 {
     KernelArgs& a = P.a;
-    if (!g.persist) { // one thread per pixel
-        a.chunkSize = 0;
-        a.numChunks = 0;
-        P.blocks = (a.numItems + TPT_BLOCK - 1) / TPT_BLOCK;
-        a.totalWaves = 0;
-        return;
-    }
     int occUse = P.occ;
     if (g.maxBlocksPerCU > 0 && g.maxBlocksPerCU < occUse) occUse = g.maxBlocksPerCU;
     const int resident = g.numCUs * occUse; // workgroups that can be co-resident
@@ -977,7 +991,6 @@ void sizeGrid(FramePlan& P)
 int maxGridBlocks(const FramePlan& P)
 {
     const KernelArgs& a = P.a;
-    if (!g.persist) return (a.numItems + TPT_BLOCK - 1) / TPT_BLOCK;
     const int wavesPerBlock = P.threadsPerBlock / 64;
     const int resident = g.numCUs * P.occ;
     const int minChunk = P.rowSerial ? 1 : 64;
@@ -992,7 +1005,7 @@ int ensureFrameBuffers(FramePlan& P, int w)
     KernelArgs& a = P.a;
     const int slot = P.slot;
     const int maxBlocks = maxGridBlocks(P);
-    const bool needStack = g.persist && g.foldMode == FOLD_RECURSIVE && a.ldsStackLevels < TPT_MAX_DEPTH;
+    const bool needStack = g.foldMode == FOLD_RECURSIVE && a.ldsStackLevels < TPT_MAX_DEPTH;
     const size_t maxColumns = (size_t)maxBlocks * (size_t)(P.queued ? tptQueuePathsPerBlock() : P.threadsPerBlock);
     const size_t stackBytes = needStack ? maxColumns * (size_t)(TPT_MAX_DEPTH - a.ldsStackLevels) * sizeof(f4) : 0;
     const size_t pathBytes = 0; // (the path-queue kernel's per-path colour sums moved into LDS)
@@ -1025,7 +1038,7 @@ int prepareChunkOrder(FramePlan& P)
     a.chunkOrder = nullptr;
     a.chunkCost = nullptr;
     a.chunkShift = 6;
-    P.useOrder = g.costOrder && g.persist == 1 && !P.rowSerial && !P.sorted && !P.queued && a.numChunks > 1 &&
+    P.useOrder = g.costOrder && !P.rowSerial && !P.queued && a.numChunks > 1 &&
                  (a.chunkSize & (a.chunkSize - 1)) == 0;
     if (!P.useOrder) return 0;
     int sh = 0;
@@ -1135,14 +1148,25 @@ int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long
     // full either way), and -4 % at C3, where 16 launches of 190 ms running at once only crowd the caches: large frames
     // keep one slot per stream (profiles/r02/r02_run42.log, r02_evidence2.log).
     P.nSlots = P.nOverlap;
-    if (P.nOverlap > 1 && g.slotFactor > 1 && (size_t)a.nLocalRows * (size_t)w * sizeof(f4) * (size_t)batch <= (32ull << 20)) P.nSlots = 2 * P.nOverlap;
+    const size_t colourBytesPerSlot = (size_t)a.nLocalRows * (size_t)w * sizeof(f4) * (size_t)batch;
+    if (P.nOverlap > 1 && g.slotFactor > 1 && colourBytesPerSlot <= (32ull << 20)) P.nSlots = 2 * P.nOverlap;
+    // Every slot is sized for the largest frame seen, so the number of slots bounds the memory a large (batched) frame pins:
+    // all colour slots together stay under 8 GiB (1280x720 x 32 frames per launch: 16 slots x 472 MB = 7.5 GB; a 4K x 8-frame
+    // batch: 4 slots instead of 16), never fewer than 2 (one being traced, one being blended); a single slot above 4 GiB is
+    // refused here, before anything is drained or freed.
+    if (colourBytesPerSlot > (4ull << 30))
+        return fail("tptDrawDeviceBatch: " + std::to_string(colourBytesPerSlot >> 20) + " MiB of frame colour per launch (rows x width x 16 B x frames): over the 4096 MiB limit, use a smaller batch");
+    while (P.nSlots > 2 && colourBytesPerSlot * (size_t)P.nSlots > (8ull << 30)) P.nSlots /= 2;
+    if (P.nOverlap > P.nSlots) P.nOverlap = P.nSlots;
     P.slot = (int)(g.frameSeq % (unsigned long long)P.nSlots);
     g.frameSeq++;
 
     int rc = chooseKernel(P);
     if (rc) return rc;
-    if (batch > 1 && (!P.queued || w > 8192 || h > 8192 || (long long)a.nLocalRows * w * batch > (1ll << 30)))
-        return fail("tptDrawDeviceBatch: needs the path-queue kernel (per-pixel seeds, recursive fold, two-phase HitSpheres) and a frame of at most 8192 x 8192 (2^30 pixels per batch)");
+    // a batch is traced by the path-queue kernel (per-pixel seeds) or, in the reference's own seed mode, by the lane-refill
+    // kernel: one lane per (frame, row) -- rows AND frames are independent RNG streams there (Test.cpp:280)
+    if (batch > 1 && (!(P.queued || P.rowSerial) || w > 8192 || h > 8192 || (long long)a.nLocalRows * w * batch > (1ll << 30)))
+        return fail("tptDrawDeviceBatch: needs the path-queue kernel (per-pixel seeds, recursive fold, two-phase HitSpheres) or row-serial seeds, and a frame of at most 8192 x 8192 (2^30 pixels per batch)");
     sizeGrid(P);
     if ((rc = ensureFrameBuffers(P, w))) return rc;
     if (frameRays) a.rayCounter = frameRays;
@@ -1181,10 +1205,8 @@ int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long
     if (timeIt) HIPCHK(hipEventRecord(g.ktStart[g.ktUsed], ts));
     if (P.queued)
         HIPCHK(tptLaunchTraceQueue(a, P.ldsScene, P.blocks, P.lds, ts));
-    else if (P.sorted)
-        HIPCHK(tptLaunchTraceSorted(a, g.foldMode, P.ldsScene, P.blocks, P.lds, ts));
     else
-        HIPCHK(tptLaunchTrace(a, g.hs, g.foldMode, g.persist != 0, P.ldsScene, P.blocks, P.lds, ts));
+        HIPCHK(tptLaunchTrace(a, g.hs, g.foldMode, P.ldsScene, P.blocks, P.lds, ts));
     if (timeIt) {
         HIPCHK(hipEventRecord(g.ktStop[g.ktUsed], ts));
         g.ktUsed++;

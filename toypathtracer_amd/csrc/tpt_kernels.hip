@@ -7,10 +7,9 @@
 //   * tptTraceQueueKernel   (default)  workgroups of 8 waves own 1024 paths whose state lives in LDS; waves pop
 //                                      batches of paths that need the SAME code from per-class rings, so Scatter and the
 //                                      intersections run at (nearly) full lane utilisation;
-//   * tptTraceKernel        PERSIST    one-wave workgroups pull 8x8-pixel chunks from a global counter and re-fill idle
+//   * tptTraceKernel                   one-wave workgroups pull 8x8-pixel chunks from a global counter and re-fill idle
 //                                      lanes with the next pixel (fallback for row-serial seeds / forward fold / simple
-//                                      HitSpheres; cost-ordered chunks);  !PERSIST: one thread per pixel;
-//   * tptTraceSortedKernel             4 waves regroup their lanes by class through LDS after every intersection.
+//                                      HitSpheres; cost-ordered chunks).
 //
 //   * work item  = one pixel (PER_PIXEL seed mode) or one row (ROW_SERIAL, the reference's Test.cpp:280 RNG stream;
 //     bit-for-bit reproduction of the CPU image);
@@ -219,7 +218,7 @@ __global__ void __launch_bounds__(256) tptDisplayKernel(const f4* __restrict__ t
     rgba[i] = to8(c.x) | (to8(c.y) << 8) | (to8(c.z) << 16) | 0xff000000u;
 }
 
-template <int HS, int FOLD, bool PERSIST, bool LDS_SCENE>
+template <int HS, int FOLD, bool LDS_SCENE>
 // 112 VGPRs x 4 waves/SIMD leaves 64 registers per SIMD lane for the resolve kernel's waves (see tptTraceQueueKernel;
 // amdgpu_num_vgpr counts half of the unified file on gfx90a+, so 56 means 112)
 __global__ void __launch_bounds__(TPT_BLOCK, TPT_MIN_WAVES_PER_SIMD) __attribute__((amdgpu_num_vgpr(56)))
@@ -270,28 +269,11 @@ tptTraceKernel(const KernelArgs a)
     L.active = false;
     L.rays = 0;
 
-    if (!PERSIST) {
-        // ---- static mapping: one work item per thread
-        int idx = blockIdx.x * TPT_BLOCK + threadIdx.x;
-        int x, ly;
-        if (idx < a.numItems && mapItem(a, idx, x, ly)) {
-            laneBeginPixel(L, fc, x, localRowToGlobal(a, ly), ly * fc.width + x, true);
-        }
-        while (L.active) {
-            if (laneStep<HSX, FOLD>(L, sv, fc, stack)) {
-                storeColour(a, L);
-                if (rowSerial && L.x + 1 < fc.width) {
-                    laneBeginPixel(L, fc, L.x + 1, L.y, L.pix + 1, false);
-                        } else {
-                    L.active = false;
-                }
-            }
-        }
-    } else {
+    {
         // ---- persistent waves with per-lane refill
         const int lane = threadIdx.x & 63;
         const unsigned long long laneBelow = (1ull << lane) - 1ull;
-        int chunkNext = 0, chunkEnd = 0;
+        int chunkNext = 0, chunkEnd = 0, chunkFrame = 0;
         bool noMoreWork = false;
         for (;;) {
             bool need = !L.active;
@@ -310,6 +292,11 @@ tptTraceKernel(const KernelArgs a)
                         break;
                     }
                     if (a.chunkOrder) c = (int)a.chunkOrder[c]; // expensive chunks first (statistics of previous frames)
+                    chunkFrame = 0;
+                    if (a.batchFrames > 1) { // batched launch (row-serial seeds): chunk c belongs to frame c / chunksPerFrame of the batch
+                        chunkFrame = c / a.chunksPerFrame;
+                        c -= chunkFrame * a.chunksPerFrame;
+                    }
                     chunkNext = c * a.chunkSize;
                     chunkEnd = chunkNext + a.chunkSize;
                     if (chunkEnd > a.numItems) chunkEnd = a.numItems;
@@ -321,7 +308,8 @@ tptTraceKernel(const KernelArgs a)
                 if (need && rank < take) {
                     int x, ly;
                     if (mapItem(a, chunkNext + rank, x, ly)) {
-                        laneBeginPixel(L, fc, x, localRowToGlobal(a, ly), ly * fc.width + x, true);
+                        laneBeginPixel(L, fc, x, localRowToGlobal(a, ly), chunkFrame * a.framePlane + ly * fc.width + x, true);
+                        if (a.batchFrames > 1) L.rng = pixelSeed(fc.seedMode, L.x, L.y, fc.frame + chunkFrame);
                         L.item = chunkNext + rank;
                         L.rays0 = L.rays;
                         need = false;
@@ -361,7 +349,7 @@ tptTraceKernel(const KernelArgs a)
 #endif
     if ((threadIdx.x & 63) == 0) {
         atomicAdd(a.rayCounter, (unsigned long long)waveRays);
-        if (PERSIST) {
+        {
             // last wave to finish re-arms the work counter for the next launch on this stream
             unsigned done = atomicAdd(&a.work[1], 1u) + 1u;
             if (done == a.totalWaves) {
@@ -372,227 +360,11 @@ tptTraceKernel(const KernelArgs a)
     }
 }
 
-// ---------------------------------------------------------------- lane-sorting variant
-// Same lane logic, same results; what changes is WHICH lane holds which path.  After the (wave-uniform)
-// intersection every lane classifies its path by the block it needs next (end-of-path / dielectric / metal /
-// Lambert hit / shadow-ray return), the 4 waves of the workgroup agree on a class-sorted order through 10-bit
-// packed per-wave counters in LDS, and the whole path state (9 or 11 float4) is permuted through LDS.  Each wave
-// then executes one or two post-intersection blocks at (nearly) full lane utilisation instead of all of them at
-// ~25 % (profiles/r01/block_stats_megakernel_v1.txt).  Two workgroup barriers per step.  The FOLD_RECURSIVE bounce
-// stack moves to global memory (column = L.slot, travels with the path).
-#define TPT_SORT_T (64 * TPT_SORT_WAVES)
-static_assert(TPT_SORT_T < 1024, "per-class counters are 10-bit fields: a workgroup of 1024 lanes would overflow them");
-template <int FOLD>
-struct SortPack {
-    static constexpr int N = FOLD == FOLD_FORWARD ? 11 : 9;
-};
 __device__ __forceinline__ f4 mk4(float x, float y, float z, float w)
 {
     f4 v;
     v.x = x; v.y = y; v.z = z; v.w = w;
     return v;
-}
-template <int FOLD>
-__device__ __forceinline__ void packLane(const Lane& L, int id, float t, f4* xch, int dest)
-{
-    const uint32_t flags = ((uint32_t)L.sample & 0xffffu) | (((uint32_t)L.depth & 15u) << 16) | ((uint32_t)(L.kind & 1) << 20) |
-                           (((uint32_t)L.hitType & 3u) << 21) | ((uint32_t)L.active << 23) | ((uint32_t)L.needCamera << 24) |
-                           ((uint32_t)L.doMatE << 25) | (((uint32_t)L.sp & 15u) << 26);
-    xch[0 * TPT_SORT_T + dest] = mk4(L.orig.x, L.orig.y, L.orig.z, u2f(L.rng));
-    xch[1 * TPT_SORT_T + dest] = mk4(L.dir.x, L.dir.y, L.dir.z, t);
-    xch[2 * TPT_SORT_T + dest] = mk4(L.sdir.x, L.sdir.y, L.sdir.z, u2f((uint32_t)id));
-    xch[3 * TPT_SORT_T + dest] = mk4(L.nl.x, L.nl.y, L.nl.z, L.cosAMax);
-    xch[4 * TPT_SORT_T + dest] = mk4(L.albedo.x, L.albedo.y, L.albedo.z, u2f(flags));
-    xch[5 * TPT_SORT_T + dest] = mk4(L.lightE.x, L.lightE.y, L.lightE.z, u2f((uint32_t)L.pix));
-    xch[6 * TPT_SORT_T + dest] = mk4(L.col.x, L.col.y, L.col.z, u2f((uint32_t)L.x | ((uint32_t)L.y << 16)));
-    xch[7 * TPT_SORT_T + dest] = mk4(L.matE.x, L.matE.y, L.matE.z, u2f((uint32_t)L.hitId));
-    xch[8 * TPT_SORT_T + dest] = mk4(u2f((uint32_t)L.slot), u2f(L.rays), u2f((uint32_t)L.j), 0.0f);
-    if (FOLD == FOLD_FORWARD) {
-        xch[9 * TPT_SORT_T + dest] = mk4(L.radiance.x, L.radiance.y, L.radiance.z, L.throughput.x);
-        xch[10 * TPT_SORT_T + dest] = mk4(L.throughput.y, L.throughput.z, 0.0f, 0.0f);
-    }
-}
-template <int FOLD>
-__device__ __forceinline__ void unpackLane(Lane& L, int& id, float& t, const f4* xch, int src)
-{
-    f4 v = xch[0 * TPT_SORT_T + src];
-    L.orig = mk3(v.x, v.y, v.z); L.rng = f2u(v.w);
-    v = xch[1 * TPT_SORT_T + src];
-    L.dir = mk3(v.x, v.y, v.z); t = v.w;
-    v = xch[2 * TPT_SORT_T + src];
-    L.sdir = mk3(v.x, v.y, v.z); id = (int)f2u(v.w);
-    v = xch[3 * TPT_SORT_T + src];
-    L.nl = mk3(v.x, v.y, v.z); L.cosAMax = v.w;
-    v = xch[4 * TPT_SORT_T + src];
-    L.albedo = mk3(v.x, v.y, v.z);
-    const uint32_t flags = f2u(v.w);
-    L.sample = (int)(flags & 0xffffu);
-    L.depth = (int)((flags >> 16) & 15u);
-    L.kind = (int)((flags >> 20) & 1u);
-    L.hitType = (int)((flags >> 21) & 3u);
-    L.active = ((flags >> 23) & 1u) != 0;
-    L.needCamera = ((flags >> 24) & 1u) != 0;
-    L.doMatE = ((flags >> 25) & 1u) != 0;
-    L.sp = (int)((flags >> 26) & 15u);
-    v = xch[5 * TPT_SORT_T + src];
-    L.lightE = mk3(v.x, v.y, v.z); L.pix = (int)f2u(v.w);
-    v = xch[6 * TPT_SORT_T + src];
-    L.col = mk3(v.x, v.y, v.z);
-    L.x = (int)(f2u(v.w) & 0xffffu); L.y = (int)(f2u(v.w) >> 16);
-    v = xch[7 * TPT_SORT_T + src];
-    L.matE = mk3(v.x, v.y, v.z); L.hitId = (int)f2u(v.w);
-    v = xch[8 * TPT_SORT_T + src];
-    L.slot = (int)f2u(v.x); L.rays = f2u(v.y); L.j = (int)f2u(v.z);
-    if (FOLD == FOLD_FORWARD) {
-        v = xch[9 * TPT_SORT_T + src];
-        L.radiance = mk3(v.x, v.y, v.z);
-        float tx = v.w;
-        v = xch[10 * TPT_SORT_T + src];
-        L.throughput = mk3(tx, v.x, v.y);
-    }
-}
-
-template <int FOLD, bool LDS_SCENE>
-__global__ void __launch_bounds__(TPT_SORT_T) tptTraceSortedKernel(const KernelArgs a)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int nPad = a.scene.nPairs * 2;
-    f4* ldsSph = reinterpret_cast<f4*>(smem);
-    int off = LDS_SCENE ? nPad * 16 : 0;
-    float* ldsInvR = reinterpret_cast<float*>(smem + off);
-    off += LDS_SCENE ? ((nPad * 4 + 15) & ~15) : 0;
-    f4* ldsLights = reinterpret_cast<f4*>(smem + off);
-    off += a.scene.nLights * 32;
-    f4* ldsMats = reinterpret_cast<f4*>(smem + off);
-    off += LDS_SCENE ? a.scene.nSpheres * 48 : 0;
-    f4* xch = reinterpret_cast<f4*>(smem + off);
-    off += SortPack<FOLD>::N * TPT_SORT_T * 16;
-    unsigned long long* cnt = reinterpret_cast<unsigned long long*>(smem + off);
-
-    SceneView sv = a.scene;
-    if (LDS_SCENE) {
-        for (int i = threadIdx.x; i < nPad; i += TPT_SORT_T) {
-            ldsSph[i] = a.scene.sph4[i];
-            ldsInvR[i] = a.scene.invR[i];
-        }
-        for (int i = threadIdx.x; i < a.scene.nSpheres * 3; i += TPT_SORT_T) ldsMats[i] = a.scene.mats[i];
-        sv.sph4 = ldsSph;
-        sv.invR = ldsInvR;
-        sv.mats = ldsMats;
-    }
-    for (int i = threadIdx.x; i < a.scene.nLights * 2; i += TPT_SORT_T) ldsLights[i] = a.scene.lights[i];
-    sv.lights = ldsLights;
-    __syncthreads();
-
-    const FrameConsts& fc = a.fc;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const unsigned long long laneBelow = (1ull << lane) - 1ull;
-    Lane L;
-    L.rng = 0; L.x = 0; L.y = 0; L.pix = 0; L.sample = 0; L.depth = 0; L.kind = KIND_MAIN; L.j = 0; L.hitId = 0; L.hitType = 0;
-    L.active = false; L.needCamera = false; L.doMatE = true;
-    L.orig = L.dir = L.sdir = L.nl = L.albedo = L.lightE = L.matE = L.col = L.radiance = L.throughput = mk3(0, 0, 0);
-    L.cosAMax = 0; L.sp = 0; L.rays = 0;
-    L.slot = blockIdx.x * TPT_SORT_T + tid;
-
-    int chunkNext = 0, chunkEnd = 0;
-    bool noMoreWork = false;
-    for (;;) {
-        // ---- (1) refill idle lanes from this wave's chunk pool (as in tptTraceKernel)
-        bool need = !L.active;
-        for (;;) {
-            unsigned long long needMask = __ballot(need);
-            if (needMask == 0ull) break;
-            TPT_STAT(ST_REFILL);
-            if (chunkNext >= chunkEnd) {
-                if (noMoreWork) break;
-                TPT_STAT(ST_CHUNK);
-                int c = 0;
-                if (lane == 0) c = (int)atomicAdd(&a.work[0], 1u);
-                c = __builtin_amdgcn_readfirstlane(c);
-                if (c >= a.numChunks) {
-                    noMoreWork = true;
-                    break;
-                }
-                chunkNext = c * a.chunkSize;
-                chunkEnd = chunkNext + a.chunkSize;
-                if (chunkEnd > a.numItems) chunkEnd = a.numItems;
-            }
-            int rank = __popcll(needMask & laneBelow);
-            int want = __popcll(needMask);
-            int avail = chunkEnd - chunkNext;
-            int take = want < avail ? want : avail;
-            if (need && rank < take) {
-                int x, ly;
-                if (mapItem(a, chunkNext + rank, x, ly)) {
-                    laneBeginPixel(L, fc, x, localRowToGlobal(a, ly), ly * fc.width + x, true);
-                    need = false;
-                }
-            }
-            chunkNext += take;
-        }
-        // ---- (2) camera ray for lanes starting a sample, (3) HitWorld for every live lane
-        int id = -1;
-        float t = 0.0f;
-        if (L.active) {
-            TPT_STAT(ST_STEP);
-            if (L.needCamera) laneCamera<FOLD>(L, fc);
-            id = hitSpheres<LDS_SCENE ? HS_TWO_PHASE : HS_TWO_PHASE_GROUPS>(sv, L.orig, L.dir, TPT_MIN_T, TPT_MAX_T, t);
-            L.rays++;
-        }
-        // ---- (4) classify; per-wave class histogram, 10 bits per class, one LDS word per wave
-        const int cls = laneClassify(L, id, sv);
-        unsigned long long mine = 0ull, packed = 0ull;
-#pragma unroll
-        for (int c = 0; c < CLS_COUNT; ++c) {
-            unsigned long long m = __ballot(cls == c);
-            if (cls == c) mine = m;
-            packed |= (unsigned long long)__popcll(m) << (10 * c);
-        }
-        const int rank = __popcll(mine & laneBelow);
-        if (lane == 0) cnt[wave] = packed;
-        __syncthreads(); // A: all histograms visible; every wave finished reading xch of the previous step
-        // ---- (5) destination slot in class-sorted order
-        unsigned long long total = 0ull, before = 0ull;
-#pragma unroll
-        for (int w = 0; w < TPT_SORT_WAVES; ++w) {
-            unsigned long long c = cnt[w];
-            if (w < wave) before += c;
-            total += c;
-        }
-        if ((int)((total >> (10 * CLS_IDLE)) & 1023ull) == TPT_SORT_T) break; // every lane of the workgroup is idle (uniform)
-        int base = 0;
-#pragma unroll
-        for (int c = 0; c < CLS_COUNT; ++c)
-            if (c < cls) base += (int)((total >> (10 * c)) & 1023ull);
-        const int dest = base + (int)((before >> (10 * cls)) & 1023ull) + rank;
-        // ---- (6) permute the path state through LDS, (7) read back the slot of this thread
-        packLane<FOLD>(L, id, t, xch, dest);
-        __syncthreads(); // B
-        unpackLane<FOLD>(L, id, t, xch, tid);
-        // ---- (8) post-intersection work; lanes of a wave now mostly need the same block
-        if (L.active) {
-            BounceStack stack;
-            stack.base = nullptr;
-            stack.stride = 0;
-            stack.fastLevels = 0;
-            stack.spill = a.stackBuf + L.slot;
-            stack.spillStride = a.stackStride;
-            if (lanePost<FOLD>(L, id, t, sv, fc, stack)) {
-                storeColour(a, L);
-                L.active = false;
-            }
-        }
-    }
-
-    unsigned waveRays = waveReduceAdd(L.rays);
-    if (lane == 0) {
-        atomicAdd(a.rayCounter, (unsigned long long)waveRays);
-        unsigned done = atomicAdd(&a.work[1], 1u) + 1u;
-        if (done == a.totalWaves) {
-            a.work[0] = 0u;
-            a.work[1] = 0u;
-        }
-    }
 }
 
 // ---------------------------------------------------------------- path-queue variant
@@ -1262,10 +1034,10 @@ size_t tptLdsBytes(const KernelArgs& a, int fold, bool ldsScene)
     return bytes;
 }
 
-template <int HS, int FOLD, bool PERSIST, bool LDS_SCENE>
+template <int HS, int FOLD, bool LDS_SCENE>
 static hipError_t launchOne(const KernelArgs& a, int blocks, size_t lds, hipStream_t stream)
 {
-    auto k = tptTraceKernel<HS, FOLD, PERSIST, LDS_SCENE>;
+    auto k = tptTraceKernel<HS, FOLD, LDS_SCENE>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
@@ -1274,87 +1046,37 @@ static hipError_t launchOne(const KernelArgs& a, int blocks, size_t lds, hipStre
     return hipGetLastError();
 }
 
-template <int HS, int FOLD, bool PERSIST, bool LDS_SCENE>
+template <int HS, int FOLD, bool LDS_SCENE>
 static int occupancyOne(size_t lds)
 {
     int nb = 0;
-    auto k = tptTraceKernel<HS, FOLD, PERSIST, LDS_SCENE>;
+    auto k = tptTraceKernel<HS, FOLD, LDS_SCENE>;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), TPT_BLOCK, lds) != hipSuccess) nb = 1;
     return nb < 1 ? 1 : nb;
 }
 
-#define TPT_DISPATCH(FN, ...)                                                                                      \
-    do {                                                                                                           \
-        const int key = (hs ? 8 : 0) | (fold ? 4 : 0) | (persist ? 2 : 0) | (ldsScene ? 1 : 0);                    \
-        switch (key) {                                                                                             \
-        case 0: return FN<HS_TWO_PHASE, FOLD_RECURSIVE, false, false>(__VA_ARGS__);                                \
-        case 1: return FN<HS_TWO_PHASE, FOLD_RECURSIVE, false, true>(__VA_ARGS__);                                 \
-        case 2: return FN<HS_TWO_PHASE, FOLD_RECURSIVE, true, false>(__VA_ARGS__);                                 \
-        case 3: return FN<HS_TWO_PHASE, FOLD_RECURSIVE, true, true>(__VA_ARGS__);                                  \
-        case 4: return FN<HS_TWO_PHASE, FOLD_FORWARD, false, false>(__VA_ARGS__);                                  \
-        case 5: return FN<HS_TWO_PHASE, FOLD_FORWARD, false, true>(__VA_ARGS__);                                   \
-        case 6: return FN<HS_TWO_PHASE, FOLD_FORWARD, true, false>(__VA_ARGS__);                                   \
-        case 7: return FN<HS_TWO_PHASE, FOLD_FORWARD, true, true>(__VA_ARGS__);                                    \
-        case 8: return FN<HS_SIMPLE, FOLD_RECURSIVE, false, false>(__VA_ARGS__);                                   \
-        case 9: return FN<HS_SIMPLE, FOLD_RECURSIVE, false, true>(__VA_ARGS__);                                    \
-        case 10: return FN<HS_SIMPLE, FOLD_RECURSIVE, true, false>(__VA_ARGS__);                                   \
-        case 11: return FN<HS_SIMPLE, FOLD_RECURSIVE, true, true>(__VA_ARGS__);                                    \
-        case 12: return FN<HS_SIMPLE, FOLD_FORWARD, false, false>(__VA_ARGS__);                                    \
-        case 13: return FN<HS_SIMPLE, FOLD_FORWARD, false, true>(__VA_ARGS__);                                     \
-        case 14: return FN<HS_SIMPLE, FOLD_FORWARD, true, false>(__VA_ARGS__);                                     \
-        default: return FN<HS_SIMPLE, FOLD_FORWARD, true, true>(__VA_ARGS__);                                      \
-        }                                                                                                          \
+#define TPT_DISPATCH(FN, ...)                                                                  \
+    do {                                                                                       \
+        const int key = (hs ? 4 : 0) | (fold ? 2 : 0) | (ldsScene ? 1 : 0);                    \
+        switch (key) {                                                                         \
+        case 0: return FN<HS_TWO_PHASE, FOLD_RECURSIVE, false>(__VA_ARGS__);                   \
+        case 1: return FN<HS_TWO_PHASE, FOLD_RECURSIVE, true>(__VA_ARGS__);                    \
+        case 2: return FN<HS_TWO_PHASE, FOLD_FORWARD, false>(__VA_ARGS__);                     \
+        case 3: return FN<HS_TWO_PHASE, FOLD_FORWARD, true>(__VA_ARGS__);                      \
+        case 4: return FN<HS_SIMPLE, FOLD_RECURSIVE, false>(__VA_ARGS__);                      \
+        case 5: return FN<HS_SIMPLE, FOLD_RECURSIVE, true>(__VA_ARGS__);                       \
+        case 6: return FN<HS_SIMPLE, FOLD_FORWARD, false>(__VA_ARGS__);                        \
+        default: return FN<HS_SIMPLE, FOLD_FORWARD, true>(__VA_ARGS__);                        \
+        }                                                                                      \
     } while (0)
 
-hipError_t tptLaunchTrace(const KernelArgs& a, int hs, int fold, bool persist, bool ldsScene, int blocks, size_t lds, hipStream_t stream)
+hipError_t tptLaunchTrace(const KernelArgs& a, int hs, int fold, bool ldsScene, int blocks, size_t lds, hipStream_t stream)
 {
     TPT_DISPATCH(launchOne, a, blocks, lds, stream);
 }
-int tptTraceOccupancy(int hs, int fold, bool persist, bool ldsScene, size_t lds)
+int tptTraceOccupancy(int hs, int fold, bool ldsScene, size_t lds)
 {
     TPT_DISPATCH(occupancyOne, lds);
-}
-
-size_t tptSortedLdsBytes(const KernelArgs& a, int fold, bool ldsScene)
-{
-    const int nPad = a.scene.nPairs * 2;
-    size_t bytes = 0;
-    if (ldsScene) bytes += (size_t)nPad * 16 + (((size_t)nPad * 4 + 15) & ~(size_t)15);
-    bytes += (size_t)a.scene.nLights * 32;
-    if (ldsScene) bytes += (size_t)a.scene.nSpheres * 48;
-    bytes += (size_t)(fold == FOLD_FORWARD ? 11 : 9) * TPT_SORT_T * 16;
-    bytes += 64;
-    return bytes;
-}
-template <int FOLD, bool LDS_SCENE>
-static hipError_t launchSortedOne(const KernelArgs& a, int blocks, size_t lds, hipStream_t stream)
-{
-    auto k = tptTraceSortedKernel<FOLD, LDS_SCENE>;
-    if (lds > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(k, dim3(blocks), dim3(TPT_SORT_T), lds, stream, a);
-    return hipGetLastError();
-}
-template <int FOLD, bool LDS_SCENE>
-static int occupancySortedOne(size_t lds)
-{
-    int nb = 0;
-    auto k = tptTraceSortedKernel<FOLD, LDS_SCENE>;
-    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(k), TPT_SORT_T, lds) != hipSuccess) nb = 1;
-    return nb < 1 ? 1 : nb;
-}
-hipError_t tptLaunchTraceSorted(const KernelArgs& a, int fold, bool ldsScene, int blocks, size_t lds, hipStream_t stream)
-{
-    if (fold == FOLD_FORWARD) return ldsScene ? launchSortedOne<FOLD_FORWARD, true>(a, blocks, lds, stream) : launchSortedOne<FOLD_FORWARD, false>(a, blocks, lds, stream);
-    return ldsScene ? launchSortedOne<FOLD_RECURSIVE, true>(a, blocks, lds, stream) : launchSortedOne<FOLD_RECURSIVE, false>(a, blocks, lds, stream);
-}
-int tptTraceSortedOccupancy(int fold, bool ldsScene, size_t lds)
-{
-    if (fold == FOLD_FORWARD) return ldsScene ? occupancySortedOne<FOLD_FORWARD, true>(lds) : occupancySortedOne<FOLD_FORWARD, false>(lds);
-    return ldsScene ? occupancySortedOne<FOLD_RECURSIVE, true>(lds) : occupancySortedOne<FOLD_RECURSIVE, false>(lds);
 }
 
 size_t tptQueueLdsBytes(const KernelArgs& a, bool ldsScene)

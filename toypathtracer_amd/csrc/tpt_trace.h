@@ -741,7 +741,6 @@ struct Lane {
     f3 col;                                    // sum over samples (Test.cpp:283-290)
     f3 radiance, throughput;                   // FOLD_FORWARD
     int sp;                                    // FOLD_RECURSIVE: entries on the bounce stack
-    int slot;                                  // sorted kernel: which bounce-stack column this path owns (travels with the path)
     int item;                                  // persistent kernel: work-item index of the current pixel (for the chunk cost statistics)
     uint32_t rays0;                            //   and the lane's ray count when the pixel started
     uint32_t rays;
@@ -808,19 +807,6 @@ TPT_HD void laneCamera(Lane& L, const FrameConsts& fc)
     } else {
         L.sp = 0;
     }
-}
-
-// Which post-intersection block a lane needs next (used by the sorted kernel to regroup lanes so that a wave
-// executes one or two blocks at full lane utilisation instead of all of them at ~25 %).  Order chosen so that
-// classes sharing code sit next to each other (LAMBERT and SHADOW both run the light-sampling block).
-enum { CLS_END = 0, CLS_DIEL = 1, CLS_METAL = 2, CLS_LAMBERT = 3, CLS_SHADOW = 4, CLS_IDLE = 5, CLS_COUNT = 6 };
-TPT_HD int laneClassify(const Lane& L, int id, const SceneView& sv)
-{
-    if (!L.active) return CLS_IDLE;
-    if (L.kind == KIND_SHADOW) return CLS_SHADOW;
-    if (id < 0 || L.depth >= TPT_MAX_DEPTH) return CLS_END;
-    int type = (int)f2u(sv.mats[id * 3].w);
-    return type == MAT_LAMBERT ? CLS_LAMBERT : type == MAT_METAL ? CLS_METAL : type == MAT_DIELECTRIC ? CLS_DIEL : CLS_END;
 }
 
 // Everything after HitWorld for one ray of this lane: Scatter / light sampling / bounce / fold.

@@ -209,7 +209,7 @@ def row_serial_rate(api, width, height, frames=3):
     return dt / frames * 1e3, rays / dt / 1e6
 
 
-def row_serial_batched_rate(api, torch, width, height, per_launch=32, launches=3):
+def row_serial_batched_rate(api, torch, width, height, per_launch=32, launches=8):
     """ROW_SERIAL seeds through tptDrawDeviceBatch: per_launch frames x rows lanes per launch (rows AND frames are independent
     RNG streams in the reference, Test.cpp:280) -- the reference's exact image, bit for bit, at GPU speed."""
     api.set_seed_mode(0)

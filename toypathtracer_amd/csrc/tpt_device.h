@@ -24,6 +24,7 @@ struct KernelArgs {
     // after the other into frameColour (framePlane pixels apart).  1 = a single frame (chunksPerFrame == numChunks).
     int batchFrames, chunksPerFrame, framePlane;
     unsigned totalWaves;
+    int laneCap;    // lane-refill kernel: lanes of a wave that take work items (64; fewer for row-serial seeds, whose items are whole rows)
     // FOLD_RECURSIVE bounce stack: the first ldsStackLevels levels live in LDS (per thread), deeper ones in
     // stackBuf [TPT_MAX_DEPTH - ldsStackLevels][stackStride] (global, one column per thread of the launch).
     f4* stackBuf;

@@ -947,6 +947,19 @@ void sizeGrid(FramePlan& P)
     a.chunksPerFrame = a.numChunks;
     a.numChunks *= P.batch; // a batched launch hands out the chunks of all its frames, frame after frame
     int blocks = (a.numChunks + wavesPerBlock - 1) / wavesPerBlock;
+    a.laneCap = 64;
+    if (P.rowSerial && !P.queued) {
+        // Row-serial seeds: a work item is a whole image row (thousands of sequential rays), and there are few of them -- rows x
+        // frames of the batch.  A wave that fills all 64 lanes leaves most SIMDs idle; a SIMD runs one wave's instructions at
+        // the same rate whether 8 or 64 of its lanes are alive, so the items are dealt out over as many waves as there are
+        // SIMDs (4 per CU), at least 4 lanes each.
+        // (k launches in flight -- the deepest pipeline this caller has built so far -- share the SIMDs: k times the lanes)
+        const int simds = g.numCUs * 4, k = g.streamDepth > 1 ? g.streamDepth : 1;
+        int cap = (int)(((long long)a.numChunks * k + simds - 1) / simds);
+        cap = cap < 4 ? 4 : (cap > 64 ? 64 : cap);
+        a.laneCap = cap;
+        blocks = (a.numChunks + cap - 1) / cap;
+    }
     // Frames in flight share the machine: with k trace kernels side by side each one gets fill / k of the resident
     // workgroups -- its pools then stay in steady state longer before they drain, and the launches behind it fill the
     // gaps.  fill = 200 % on a single GPU (measured best), 100 % when the frame is sharded over ranks (oversubscription
@@ -980,6 +993,7 @@ void sizeGrid(FramePlan& P)
         const int floorBlocks = resident / (2 * (P.nOverlap > 1 ? P.nOverlap : 1));
         if (cap < floorBlocks) cap = floorBlocks;
     }
+    if (P.rowSerial && !P.queued) cap = resident; // (row-serial launches are latency-bound: one short wave per SIMD, whatever else is in flight)
     if (cap < 1) cap = 1;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;

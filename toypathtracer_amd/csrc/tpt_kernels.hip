@@ -276,7 +276,7 @@ tptTraceKernel(const KernelArgs a)
         int chunkNext = 0, chunkEnd = 0, chunkFrame = 0;
         bool noMoreWork = false;
         for (;;) {
-            bool need = !L.active;
+            bool need = !L.active && lane < a.laneCap; // (laneCap < 64: few, long work items -- spread them over more waves)
             for (;;) {
                 unsigned long long needMask = __ballot(need);
                 if (needMask == 0ull) break;

@@ -954,7 +954,7 @@ void sizeGrid(FramePlan& P)
         // the same rate whether 8 or 64 of its lanes are alive, so the items are dealt out over as many waves as there are
         // SIMDs (4 per CU), at least 4 lanes each.
         // (k launches in flight -- the deepest pipeline this caller has built so far -- share the SIMDs: k times the lanes)
-        const int simds = g.numCUs * 4, k = g.streamDepth > 1 ? g.streamDepth : 1;
+        const int simds = g.numCUs * 4, k = g.depthOverride > 0 ? g.depthOverride : (g.streamDepth > 1 ? g.streamDepth : 1);
         int cap = (int)(((long long)a.numChunks * k + simds - 1) / simds);
         cap = cap < 4 ? 4 : (cap > 64 ? 64 : cap);
         a.laneCap = cap;

@@ -194,8 +194,9 @@ def sync_caller_rate(api, torch, width, height, frames=60):
     return dt / frames * 1e3, rays / dt / 1e6
 
 
-def row_serial_rate(api, width, height, frames=3):
-    """ROW_SERIAL seeds: the reference's exact image (one RNG stream per row: one lane per row)."""
+def row_serial_rate(api, width, height, frames=96):
+    """ROW_SERIAL seeds through the reference's own contract: synchronous DrawTest(host buffer), frame by frame, the reference's
+    exact image (one RNG stream per row; the library traces the next 32 frames of a static scene ahead as one launch)."""
     api.set_seed_mode(0)
     bb = np.zeros((height, width, 4), np.float32)
     api.UpdateTest(0.0, 0, width, height, FLAG_PROGRESSIVE)
@@ -509,7 +510,8 @@ def main():
             if scene == "default" and width * height <= 1280 * 720:
                 ms, mr = row_serial_rate(api, width, height)
                 out["row_serial_ms"], out["row_serial_Mray_s"] = ms, mr
-                out["row_serial_note"] = "seed mode 0: the reference's per-row RNG streams (bit-identical CPU image), one lane per image row, frame by frame through DrawTest(host buffer)"
+                out["row_serial_note"] = ("seed mode 0: the reference's per-row RNG streams (bit-identical CPU image) through synchronous DrawTest(host buffer), frame by "
+                                          "frame; the library traces the next 32 frames of the static scene ahead as one launch (rows x frames lanes)")
                 ms, mr = row_serial_batched_rate(api, torch, width, height)
                 out["row_serial_batched_32_ms_per_frame"], out["row_serial_batched_32_Mray_s"] = ms, mr
                 out["row_serial_batched_note"] = ("seed mode 0 through tptDrawDeviceBatch: 32 frames x rows lanes per launch on a device tile -- the reference's exact "

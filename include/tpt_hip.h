@@ -61,6 +61,8 @@ int tptDraw(float time, int frameCount, int screenWidth, int screenHeight, float
  *    blends and downloads.  A frame alone on the GPU is bound by its longest paths (1.0 ms at 1280x720x4); with three in
  *    flight the pipeline delivers one every 0.55 ms.  A wrong guess (other frame number, size, flags, scene, spp, ...) only
  *    costs GPU time: the frames traced ahead are dropped and the frame is traced again.  Never used with kFlagAnimate.
+ *    In seed mode 0 (the reference's own pixels) any n > 0 means: this frame and the 31 after it as one batched launch, the
+ *    batch after that as soon as this one is being served.
  *    The same look-ahead serves tptDrawDevice for a SYNCHRONOUS caller -- one whose previous frame has already been blended
  *    when its next call arrives, twice in a row, for consecutive frames of one configuration (a caller that streams frames
  *    never meets that and is unaffected): 0.98 -> ~0.55 ms per 1280x720x4 frame for a host that waits for every frame. */
@@ -83,7 +85,10 @@ int tptSetSamplesPerPixel(int spp);
  * roughness 0, constant sky (0.15, 0.21, 0.3), aperture 0 (takes effect at the next tptUpdate). */
 int tptSetConfig(int lightSampling, float animateSmoothing, int mitsubaCompare);
 /* RNG seeding.  0 = ROW_SERIAL: one XorShift stream per image row carried along x (Test.cpp:280);
- * bit-identical to the reference CPU image, parallel over rows only (debug / verification).
+ * bit-identical to the reference CPU image.  A frame alone is parallel over rows only (720 lanes of work), but rows AND
+ * frames are independent streams: for a static scene DrawTest / tptDraw trace the next 32 frames ahead as ONE launch (rows x
+ * frames lanes) and serve them one by one (3.7 ms instead of 60-90 ms per 1280x720x4 frame), and tptDrawDeviceBatch takes up
+ * to 32 frames per call (8-10 Gray/s).
  * 1 = PER_PIXEL (default): one stream per pixel, the reference's own GPU formula
  * (Cpp/Windows/ComputeShader.hlsl:380); parallel over pixels. */
 int tptSetSeedMode(int mode);

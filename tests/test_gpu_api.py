@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from oracle_lib import ROOT, FLAG_PROGRESSIVE, SEED_PER_PIXEL, fnv1a
+from oracle_lib import ROOT, FLAG_PROGRESSIVE, SEED_PER_PIXEL, SEED_ROW_SERIAL, fnv1a
 
 pytestmark = pytest.mark.gpu
 
@@ -173,6 +173,36 @@ def test_drawtest_lookahead_changes_nothing(tpt_defaults, oracle, lookahead):
     assert per1 + per3 == pero and bb1.tobytes() == bo.tobytes()
     ro2, bo2, pero2 = oracle_frames(oracle, 96, 64, 4, 3, seed_mode=SEED_PER_PIXEL)
     assert per2 == pero2 and bb2.tobytes() == bo2.tobytes()
+
+
+def test_drawtest_in_the_reference_seed_mode_is_served_from_batched_lookahead(tpt_defaults, oracle):
+    """tptSetSeedMode(0) + plain synchronous DrawTest calls -- the literal drop-in with the reference's own pixels: the library
+    traces this frame and the 31 after it as ONE launch (rows x frames lanes, a ray counter per frame) and the batch after
+    that as soon as the first is being served.  Every frame's bytes and ray count equal the oracle's ROW_SERIAL render, across
+    the batch boundary (frames 31 -> 32 -> 33), after a jump in frameCount, a restart at 0 and a different size in between."""
+    from common import oracle_frames
+    tpt = tpt_defaults
+    tpt.set_seed_mode(SEED_ROW_SERIAL)
+    tpt.set_samples_per_pixel(2)
+    w, h = 160, 96
+    s, m = oracle.default_scene()
+    cam = oracle.default_camera(w, h)
+    hits0 = tpt.lookahead_hits()
+    seq = list(range(36)) + [40, 41, 0, 1]
+    per, bb = _draw_seq(tpt, seq, w, h)
+    ob = np.zeros((h, w, 4), np.float32)
+    want = []
+    for f in seq:
+        r, _ = oracle.render(s, m, cam, w, h, 2, f, seed_mode=SEED_ROW_SERIAL, backbuffer=ob)
+        want.append(r)
+    assert per == want and bb.tobytes() == ob.tobytes()
+    assert tpt.lookahead_hits() - hits0 >= 35  # frames 1..35 (and 41, 1) were already traced when their call arrived
+    per2, bb2 = _draw_seq(tpt, [0, 1, 2], 96, 64)
+    ro2, bo2, pero2 = oracle_frames(oracle, 96, 64, 2, 3, seed_mode=SEED_ROW_SERIAL)
+    assert per2 == pero2 and bb2.tobytes() == bo2.tobytes()
+    tpt.set_host_lookahead(0)  # look-ahead off: frame by frame, same bits
+    per3, bb3 = _draw_seq(tpt, [0, 1, 2], 96, 64)
+    assert per3 == pero2 and bb3.tobytes() == bo2.tobytes()
 
 
 def test_drawtest_lookahead_is_dropped_by_every_state_change(tpt_defaults, oracle):

@@ -38,6 +38,7 @@ struct KernelArgs {
     int chunkShift;                  // log2(chunkSize)
     unsigned* work;                  // [0] next chunk, [1] finished waves (persistent variants)
     unsigned long long* rayCounter;  // monotonic total of rays traced by this context
+    int rayCounterStride;            // batched row-serial launch: frame j of the batch counts into rayCounter[j * stride] (0: one counter)
 };
 
 } // namespace tpt

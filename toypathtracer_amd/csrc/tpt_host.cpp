@@ -139,6 +139,18 @@ struct Context {
     };
     Ahead ahead[4];
     TraceTicket aheadTicket[4];
+    // The same in the reference's own seed mode (one RNG stream per row, Test.cpp:280): a frame alone offers `rows` lanes of
+    // work, so the frames ahead are traced as ONE batched launch (rows x frames lanes, tptDrawDeviceBatch's kernel path) with a
+    // ray counter per frame, and served one by one; [0] is being served, [1] is the batch after it, launched when [0] starts.
+    struct RowSerialBatch {
+        bool used = false;
+        int firstFrame = 0, n = 0, next = 0, w = 0, h = 0;
+        unsigned flags = 0;
+        unsigned long long key = 0;
+        TraceTicket T;
+        int counterBase = 0;
+    } rsb[2];
+    unsigned long long* dRaysBatch = nullptr; // [2][kMaxBatch] per-frame ray counters of those two batches
     // tptDrawDevice: is the caller synchronous (the previous frame's blend has completed by the time the next call arrives)
     // and are its calls consecutive frames of one configuration?  Then the next frames are traced ahead for it too.
     struct DeviceCaller {
@@ -519,6 +531,9 @@ int tptInitialize(void)
     HIPCHK(hipEventCreateWithFlags(&g.evBandEnd, kOrderingEvent));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dRaysAhead), sizeof(unsigned long long) * Context::kMaxSlots));
     HIPCHK(hipMemsetAsync(g.dRaysAhead, 0, sizeof(unsigned long long) * Context::kMaxSlots, g.stream));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dRaysBatch), sizeof(unsigned long long) * 2 * kMaxBatch));
+    HIPCHK(hipMemsetAsync(g.dRaysBatch, 0, sizeof(unsigned long long) * 2 * kMaxBatch, g.stream));
+    g.rsb[0].used = g.rsb[1].used = false;
     for (int k = 0; k < 4; ++k) g.ahead[k].used = false;
     if (const char* e9 = getenv("TPT_HOST_LOOKAHEAD")) g.lookahead = atoi(e9) < 0 ? 0 : (atoi(e9) > 3 ? 3 : atoi(e9));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dRaysOwn), 64));
@@ -599,6 +614,8 @@ int tptShutdown(void)
     g.tileSrc = nullptr; g.tileW = g.tileH = 0;
     for (int k = 0; k < 4; ++k) g.ahead[k].used = false;
     (void)hipFree(g.dRaysAhead); g.dRaysAhead = nullptr;
+    (void)hipFree(g.dRaysBatch); g.dRaysBatch = nullptr;
+    g.rsb[0].used = g.rsb[1].used = false;
     g.orderDone = true; g.orderStream = nullptr; g.oldestPending = 0; g.frameSeq = 0;
     g.streamDepth = 1; g.prevInFlight = -1;
     return 0;
@@ -1125,7 +1142,7 @@ namespace {
 
 // First half of a frame: plan, buffers, trace kernel on the slot's stream.  `frameRays`: where the kernel adds its ray
 // count (the context's counter, or a per-slot one for frames that are traced ahead of their DrawTest call).
-int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long long* frameRays, TraceTicket& T, int batch = 1)
+int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long long* frameRays, TraceTicket& T, int batch = 1, int rayStride = 0)
 {
     if (g.sceneDirty || (g.curSet < 0 && g.pendingSet < 0)) { // tptSetScene after the last tptUpdate
         int rc = stageScene();
@@ -1171,6 +1188,7 @@ int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long
     if (colourBytesPerSlot > (4ull << 30))
         return fail("tptDrawDeviceBatch: " + std::to_string(colourBytesPerSlot >> 20) + " MiB of frame colour per launch (rows x width x 16 B x frames): over the 4096 MiB limit, use a smaller batch");
     while (P.nSlots > 2 && colourBytesPerSlot * (size_t)P.nSlots > (8ull << 30)) P.nSlots /= 2;
+    if (rayStride > 0 && P.nSlots > 4) P.nSlots = 4; // (the host path's row-serial batches: two alive at a time)
     if (P.nOverlap > P.nSlots) P.nOverlap = P.nSlots;
     P.slot = (int)(g.frameSeq % (unsigned long long)P.nSlots);
     g.frameSeq++;
@@ -1184,6 +1202,7 @@ int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long
     sizeGrid(P);
     if ((rc = ensureFrameBuffers(P, w))) return rc;
     if (frameRays) a.rayCounter = frameRays;
+    a.rayCounterStride = rayStride; // (batched row-serial launch for the host path: one counter per frame of the batch)
     if ((rc = prepareChunkOrder(P))) return rc;
     g.lastBlocksPerCU = P.occ;
     g.lastLds = (int)P.lds;
@@ -1214,7 +1233,7 @@ int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long
     }
     if ((rc = enqueueSceneUpload(ts))) return rc; // behind the wait above: nobody reads the set being replaced any more
     if ((rc = enqueueChunkOrder(P, ts))) return rc;
-    if (frameRays && frameRays != g.dRays) HIPCHK(hipMemsetAsync(frameRays, 0, sizeof(unsigned long long), ts));
+    if (frameRays && frameRays != g.dRays) HIPCHK(hipMemsetAsync(frameRays, 0, sizeof(unsigned long long) * (size_t)(rayStride > 0 ? batch : 1), ts));
     const bool timeIt = g.kernelTiming && g.ktUsed < g.ktStart.size();
     if (timeIt) HIPCHK(hipEventRecord(g.ktStart[g.ktUsed], ts));
     if (P.queued)
@@ -1402,11 +1421,12 @@ namespace {
 // to be used): let them finish and forget them.  Their colour buffers were never blended into anything.
 int discardLookahead()
 {
-    bool any = false;
+    bool any = g.rsb[0].used || g.rsb[1].used;
     for (int k = 0; k < 4; ++k) any = any || g.ahead[k].used;
     if (!any) return 0;
     for (int k = 0; k < Context::kMaxOverlap; ++k) HIPCHK(hipStreamSynchronize(g.traceStream[k]));
     for (int k = 0; k < 4; ++k) g.ahead[k].used = false;
+    g.rsb[0].used = g.rsb[1].used = false;
     return 0;
 }
 
@@ -1503,8 +1523,56 @@ int tptDraw(float time, int frameCount, int w, int h, float* backbuffer, int* ou
     } depthScope(pipelined && stable ? 1 + (g.lookahead < 3 ? g.lookahead : 3) : 1);
     TraceTicket T;
     int raySlot = -1;
+    const unsigned long long* rayPtr = nullptr;
+    bool servedFromBatch = false;
+    if (g.seedMode == SEED_ROW_SERIAL && stable && pipelined && !sharded && g.lookahead > 0 && rows > 0 && !g.mirror) {
+        // ---- 1r. the reference's own seed mode: this frame and the 31 after it as ONE launch (rows x frames lanes), the batch
+        //          after that one launched as soon as this one starts being served (a wrong guess costs GPU time only)
+        auto matches = [&](const Context::RowSerialBatch& B) {
+            return B.used && B.w == w && B.h == h && B.flags == testFlags && B.key == key && frameCount == B.firstFrame + B.next;
+        };
+        auto launch = [&](int which, int firstFrame) -> int {
+            Context::RowSerialBatch& B = g.rsb[which];
+            B.used = false;
+            B.firstFrame = firstFrame; B.n = kMaxBatch; B.next = 0; B.w = w; B.h = h; B.flags = testFlags; B.key = key;
+            // (two banks of per-frame counters; the batch being served keeps its bank when it moves from [1] to [0])
+            B.counterBase = (which == 1 && g.rsb[0].used && g.rsb[0].counterBase == 0) ? kMaxBatch : 0;
+            int rc = enqueueTrace(firstFrame, w, h, testFlags, g.dRaysBatch + B.counterBase, B.T, B.n, 1);
+            if (rc) return rc;
+            B.used = B.T.valid;
+            return 0;
+        };
+        if (!matches(g.rsb[0])) {
+            int rc = discardLookahead();
+            if (rc) return rc;
+            if ((rc = launch(0, frameCount))) return rc;
+        } else {
+            g.aheadHits++;
+        }
+        Context::RowSerialBatch& B = g.rsb[0];
+        if (B.used) {
+            if (B.next == 0 && !g.rsb[1].used) {
+                int rc = launch(1, B.firstFrame + B.n);
+                if (rc) return rc;
+            }
+            const int j = B.next;
+            T = B.T;
+            T.colour = B.T.colour + (size_t)j * (size_t)B.T.nPixels;
+            T.lerpFac = B.T.lerp.v[j];
+            T.batch = 1;
+            rayPtr = g.dRaysBatch + B.counterBase + j;
+            servedFromBatch = true;
+            if (++B.next == B.n) { // the batch is used up with this frame: the one after it becomes current
+                g.rsb[0] = g.rsb[1];
+                g.rsb[0].counterBase = g.rsb[1].counterBase;
+                g.rsb[1].used = false;
+            }
+        }
+    }
     Context::Ahead& front = g.ahead[0];
-    if (front.used && front.frameCount == frameCount && front.w == w && front.h == h && front.flags == testFlags && front.configKey == key && stable) {
+    if (servedFromBatch) {
+        // (nothing more to trace)
+    } else if (front.used && front.frameCount == frameCount && front.w == w && front.h == h && front.flags == testFlags && front.configKey == key && stable) {
         int rc = takeAhead(T, raySlot);
         if (rc) return rc;
     } else {
@@ -1514,16 +1582,16 @@ int tptDraw(float time, int frameCount, int w, int h, float* backbuffer, int* ou
         if ((rc = enqueueTrace(frameCount, w, h, testFlags, g.dRaysAhead + raySlot, T))) return rc;
     }
     // ---- 2. trace the next frames ahead (a wrong guess costs GPU time only)
-    if (pipelined && stable && T.valid) {
+    if (pipelined && stable && T.valid && !servedFromBatch) {
         int rc = traceAhead(frameCount, w, h, testFlags, key, g.lookahead);
         if (rc) return rc;
     }
+    if (!servedFromBatch) rayPtr = T.valid ? g.dRaysAhead + raySlot : nullptr;
     // ---- 3. the previous image: the host buffer is the source of truth (previous frame's RGB, caller-owned alpha) unless
     //         the caller has promised that only DrawTest writes it (tptSetHostBufferMode): then the device tile is, and the
     //         upload happens once per buffer.  Then blend and download.
     const bool upload = rows > 0 && !(g.hostTrust && g.tileSrc == backbuffer && g.tileW == w && g.tileH == h && frameCount != 0);
     if (upload) { g.tileSrc = backbuffer; g.tileW = w; g.tileH = h; }
-    const unsigned long long* rayPtr = T.valid ? g.dRaysAhead + raySlot : nullptr;
     if (upload && !sharded && T.valid && T.pipelined && rows >= 64 && !g.mirror) {
         // Banded: rows in four bands, alternating between two streams, each band upload -> blend -> download.  PCIe is
         // full duplex: one band's download crosses while the next band's upload does (0.57 + 0.27 ms of copies become
@@ -1583,7 +1651,7 @@ int tptDraw(float time, int frameCount, int w, int h, float* backbuffer, int* ou
         }
     }
     unsigned long long frameRays = 0;
-    if (T.valid) HIPCHK(hipMemcpyAsync(&frameRays, g.dRaysAhead + raySlot, sizeof(frameRays), hipMemcpyDeviceToHost, g.stream));
+    if (T.valid) HIPCHK(hipMemcpyAsync(&frameRays, rayPtr, sizeof(frameRays), hipMemcpyDeviceToHost, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     if (outRayCount) *outRayCount = (int)frameRays;
     return 0;

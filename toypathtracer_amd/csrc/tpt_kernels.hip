@@ -310,6 +310,7 @@ tptTraceKernel(const KernelArgs a)
                     if (mapItem(a, chunkNext + rank, x, ly)) {
                         laneBeginPixel(L, fc, x, localRowToGlobal(a, ly), chunkFrame * a.framePlane + ly * fc.width + x, true);
                         if (a.batchFrames > 1) L.rng = pixelSeed(fc.seedMode, L.x, L.y, fc.frame + chunkFrame);
+                        L.frameIdx = chunkFrame;
                         L.item = chunkNext + rank;
                         L.rays0 = L.rays;
                         need = false;
@@ -328,6 +329,12 @@ tptTraceKernel(const KernelArgs a)
                         // (and 90 % fewer atomics than counting every pixel)
                         if (a.chunkCost && L.rays - L.rays0 > (uint32_t)(8 * fc.spp))
                             atomicAdd(&a.chunkCost[L.item >> a.chunkShift], L.rays - L.rays0);
+                        if (rowSerial && a.batchFrames > 1) {
+                            // batched row-serial launch: the row's rays go to its frame's own counter (a host that is served
+                            // the frames one by one returns each frame's count, Test.cpp:366) -- one atomic per row
+                            atomicAdd(a.rayCounter + (size_t)L.frameIdx * a.rayCounterStride, (unsigned long long)(L.rays - L.rays0));
+                            L.rays = L.rays0; // (not again in the wave's total below)
+                        }
                         L.active = false;
                     }
                 }

@@ -742,6 +742,7 @@ struct Lane {
     f3 radiance, throughput;                   // FOLD_FORWARD
     int sp;                                    // FOLD_RECURSIVE: entries on the bounce stack
     int item;                                  // persistent kernel: work-item index of the current pixel (for the chunk cost statistics)
+    int frameIdx;                              //   batched row-serial launch: which frame of the batch the lane's row belongs to
     uint32_t rays0;                            //   and the lane's ray count when the pixel started
     uint32_t rays;
 };

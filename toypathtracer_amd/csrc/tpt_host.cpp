@@ -498,16 +498,7 @@ int tptInitialize(void)
     g.device = dev;
     g.numCUs = prop.multiProcessorCount;
     g.deviceName = std::string(prop.name) + " (" + prop.gcnArchName + ")";
-    {
-        // the context's own stream carries the ordered blend chain (and the exchange kernels of a sharded frame): short
-        // kernels that every following frame waits for.  env TPT_RESOLVE_PRIO=1 (experiment): a high-priority queue.
-        int lo = 0, hi = 0;
-        const char* pe = getenv("TPT_RESOLVE_PRIO");
-        if (pe && atoi(pe) > 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi < lo)
-            HIPCHK(hipStreamCreateWithPriority(&g.ownStream, hipStreamNonBlocking, hi));
-        else
-            HIPCHK(hipStreamCreateWithFlags(&g.ownStream, hipStreamNonBlocking));
-    }
+    HIPCHK(hipStreamCreateWithFlags(&g.ownStream, hipStreamNonBlocking));
     g.stream = g.ownStream;
     HIPCHK(hipEventCreateWithFlags(&g.evOrder, kOrderingEvent));
     g.orderDone = true;

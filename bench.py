@@ -393,6 +393,7 @@ def main():
     dt = time.perf_counter() - t0
     launch_ms_sum, launches = api.kernel_timing_end()
     kernel_ms = launch_ms_sum / max(launches, 1) * args.steps  # = steps x average duration of one trace launch (a launch of --batch frames counts once per frame: trace_launch_ms_avg is per LAUNCH)
+    frames_per_launch = args.steps / max(launches, 1)          # measured: --batch, or the library's stream batching of small frames (tptSetStreamBatching)
     rays_end = rays_so_far()
     rays_local = rays_end - rays0
     if exchange == "cabi":
@@ -426,9 +427,9 @@ def main():
         #                                                    frame overlap two launches share the GPU, so k_ms ~ 2 x the
         #                                                    pipeline time per frame (p_ms)
         p_ms = pipeline_ms / args.steps
-        pl_ms = p_ms * args.batch                          # pipeline time per LAUNCH (= per frame unless --batch)
-        px = width * height / world * args.batch            # pixels one launch of one rank covers (all frames of a batched launch)
-        rays_per_launch = rays_total / args.steps / world * args.batch
+        pl_ms = p_ms * frames_per_launch                   # pipeline time per LAUNCH (= per frame unless several frames share a launch)
+        px = width * height / world * frames_per_launch     # pixels one launch of one rank covers (all frames of a batched launch)
+        rays_per_launch = rays_total / args.steps / world * frames_per_launch
         hbm_write_gbs = px * 16 / (k_ms * 1e-3) / 1e9      # 16 B written per pixel
         valu_tflops = rays_per_launch * FLOP_PER_SPHERE_TEST * n_spheres / (k_ms * 1e-3) / 1e12
         # HBM traffic per trace launch: counter passes serialise kernels and cannot run inside the timed region, so the
@@ -436,7 +437,7 @@ def main():
         # very launch geometry (workgroups per launch); no entry -> null, never a neighbour's number.
         traffic, traffic_src = None, "profiles/pmc_traffic.json has no entry for (%s, %d workgroups per launch)" % (args.workload, info["grid_blocks"])
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(tpath) and args.persistent == 3 and args.batch == 1 and world == 1:
+        if os.path.exists(tpath) and args.persistent == 3 and frames_per_launch == 1 and world == 1:
             ent = json.load(open(tpath)).get("by_workload_and_grid", {}).get(args.workload, {}).get(str(info["grid_blocks"]))
             if ent:
                 traffic, traffic_src = ent["bytes_per_launch"], ent["source"]
@@ -447,7 +448,7 @@ def main():
             "exchange": exchange, "rccl_ranks": world if exchange != "none" else 0,
             "config": {"workload": label, "width": width, "height": height, "spp": spp, "spheres": n_spheres,
                        "seed_mode": "per_pixel", "fold": "forward" if args.fold else "recursive",
-                       "hit_spheres": ["two_phase" + ("+groups" if n_spheres >= 256 else "+matrix_core_filter" if n_spheres <= 64 else ""), "simple", "two_phase_brute_force", "two_phase_valu_filter"][args.hit_spheres], "kernel": {1: "persistent_waves", 3: "path_queues"}[args.persistent], "frame_overlap": args.overlap, "frames_per_launch": args.batch,
+                       "hit_spheres": ["two_phase" + ("+groups" if n_spheres >= 256 else "+matrix_core_filter" if n_spheres <= 64 else ""), "simple", "two_phase_brute_force", "two_phase_valu_filter"][args.hit_spheres], "kernel": {1: "persistent_waves", 3: "path_queues"}[args.persistent], "frame_overlap": args.overlap, "frames_per_launch": frames_per_launch,
                        "untimed_priming_frames": args.prime,
                        "flags": "progressive|animate" if args.animate else "progressive",
                        "sharding": "none" if world == 1 else "row stripes of %d, round-robin over %d ranks, pipelined gather to rank 0" % (args.stripe_rows, world),
@@ -456,7 +457,7 @@ def main():
             "rays_per_step": rays_total / args.steps,
             "trace_launch_ms_avg": k_ms,
             "pipeline_ms_per_step": p_ms,
-            "pipeline_Mray_s": rays_per_launch / args.batch * world / (p_ms * 1e-3) / 1e6,
+            "pipeline_Mray_s": rays_per_launch / frames_per_launch * world / (p_ms * 1e-3) / 1e6,
             # roofline.frac is the chip-level figure: the frame's algorithmic bytes over the time a frame occupies the
             # pipeline (ms_per_step measured by HIP events on the render stream) -- up to `frame_overlap` launches share
             # the GPU, so bytes / one launch's own duration (frac_per_launch) understates the chip by that factor

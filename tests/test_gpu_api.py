@@ -125,10 +125,11 @@ def test_pipeline_info_with_queues_set_early(tpt_defaults):
     assert info["hw_queues"] == 16 and info["overlap_effective"] == 16, info
     w, h = 320, 200
     tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
-    tpt.UpdateTest(0.0, 0, w, h, FLAG_PROGRESSIVE)
-    tpt.draw_device(0.0, 0, w, h, tile.data_ptr(), FLAG_PROGRESSIVE)
+    for f in range(0, 4):  # (a streaming caller with frames this small gets several frames per launch from its third call on:
+        tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)  #  the slots are re-reserved once for the batched colour planes)
+        tpt.draw_device(0.0, f, w, h, tile.data_ptr(), FLAG_PROGRESSIVE)
     r0 = tpt.pipeline_info()["slot_reservations"]
-    for f in range(1, 40):
+    for f in range(4, 40):
         tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
         tpt.draw_device(0.0, f, w, h, tile.data_ptr(), FLAG_PROGRESSIVE)
     tpt.synchronize()
@@ -203,6 +204,69 @@ def test_drawtest_in_the_reference_seed_mode_is_served_from_batched_lookahead(tp
     tpt.set_host_lookahead(0)  # look-ahead off: frame by frame, same bits
     per3, bb3 = _draw_seq(tpt, [0, 1, 2], 96, 64)
     assert per3 == pero2 and bb3.tobytes() == bo2.tobytes()
+
+
+def test_stream_batching_delivers_every_frame_with_its_own_ray_count(tpt_defaults, oracle):
+    """A caller that streams consecutive small frames gets several frames per launch behind its back (tptSetStreamBatching): the
+    tile after EVERY frame equals the oracle's -- checked by snapshotting the tile and the ray counter with stream-ordered copies
+    (no synchronise, so the caller keeps looking like a streaming one) -- across batch boundaries, a jump in frameCount and a
+    change of spp in the middle; the final ray total is exact; and while only batches are in flight the running total behind
+    every frame is exact too (frames served from a batch fold their rays in at their own blend, in frame order).  The same
+    sequences with batching switched off give the same tiles and totals."""
+    import torch
+    tpt = tpt_defaults
+    w, h = 256, 144  # 147 K samples at 4 spp: 8 frames per launch
+    s, m = oracle.default_scene()
+    cam = oracle.default_camera(w, h)
+
+    def run(seq):
+        stream = torch.cuda.Stream()
+        tpt.set_stream(stream.cuda_stream)
+        counter = torch.zeros(1, dtype=torch.int64, device="cuda")
+        tpt.set_ray_counter(counter.data_ptr())
+        tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        snaps, counts = [], []
+        torch.cuda.synchronize()
+        try:
+            with torch.cuda.stream(stream):
+                for f, spp in seq:
+                    tpt.set_samples_per_pixel(spp)
+                    tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+                    tpt.draw_device(0.0, f, w, h, tile.data_ptr(), FLAG_PROGRESSIVE)
+                    snaps.append(tile.clone())      # stream-ordered behind this frame's blend
+                    counts.append(counter.clone())
+            stream.synchronize()
+        finally:
+            tpt.set_stream(None)
+            tpt.set_ray_counter(None)
+        return [t.cpu().numpy() for t in snaps], [int(c.item()) for c in counts]
+
+    def want(seq):
+        ob = np.zeros((h, w, 4), np.float32)
+        tiles, totals, total = [], [], 0
+        for f, spp in seq:
+            r, _ = oracle.render(s, m, cam, w, h, spp, f, seed_mode=SEED_PER_PIXEL, backbuffer=ob)
+            total += r
+            tiles.append(ob.copy())
+            totals.append(total)
+        return tiles, totals
+
+    steady = [(f, 4) for f in range(21)]                                                    # two plain calls, then batches of 8
+    bumpy = [(f, 4) for f in range(5)] + [(30, 4), (31, 4), (32, 4)] + [(33, 2), (34, 2), (35, 2), (36, 2)]
+    for batching in (True, False):
+        tpt.set_stream_batching(batching)
+        for seq in (steady, bumpy):
+            tpt.set_samples_per_pixel(4)
+            tiles, totals = want(seq)
+            snaps, counts = run(seq)
+            for k in range(len(seq)):
+                assert snaps[k].tobytes() == tiles[k].tobytes(), (batching, k, seq[k])
+            assert counts[-1] == totals[-1] and all(a <= b for a, b in zip(counts, counts[1:]))
+            if batching and seq is steady:
+                # calls 0 and 1 are plain launches (their kernels add their rays whenever they end, both before the third blend);
+                # everything after them is served from batches
+                assert counts[2:] == totals[2:], (counts, totals)
+    tpt.set_stream_batching(True)
 
 
 def test_drawtest_lookahead_is_dropped_by_every_state_change(tpt_defaults, oracle):

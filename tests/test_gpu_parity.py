@@ -364,7 +364,7 @@ def test_sharded_frame_exchange_on_device(tpt_defaults, oracle, world, stripe):
             image, total = img.cpu().numpy(), tot
     tpt.set_row_shard(0, 1, 0)
     ro, bo, _ = oracle_frames(oracle, w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
-    assert total == ro
+    assert total == ro, (total, ro, tpt.pipeline_info())
     bad = np.argwhere((image.view(np.uint32) != bo.view(np.uint32)).any(axis=2))
     assert len(bad) == 0, "%d pixels differ, first rows %s" % (len(bad), sorted(set(bad[:, 0].tolist()))[:12])
 
@@ -419,7 +419,7 @@ def test_frame_overlap_is_bit_identical(tpt_defaults, oracle, overlap):
         tpt.draw_device(0.0, f, w, h, tile.data_ptr(), FLAG_PROGRESSIVE)
     ms, n = tpt.kernel_timing_end()
     rays = tpt.ray_counter_read() - r0
-    assert n == frames and ms > 0
+    assert 1 <= n <= frames and ms > 0  # (launches: fewer than frames when the library batches a streaming caller's small frames)
     ro, bo, _ = oracle_frames(oracle, w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
     assert rays == ro and tile.cpu().numpy().tobytes() == bo.tobytes()
     tpt.set_frame_overlap(16)
@@ -455,7 +455,7 @@ def test_frame_overlap_stress_300_repetitions(tpt_defaults, oracle):
                 tpt.draw_device(0.0, f, w, h, tile.data_ptr(), FLAG_PROGRESSIVE)
             if timing:
                 ms, n = tpt.kernel_timing_end()
-                assert n == frames and ms > 0
+                assert 1 <= n <= frames and ms > 0  # (launches: fewer than frames when small frames are batched for a streaming caller)
             rays = tpt.ray_counter_read() - r0
             assert rays == want[frames][0], (it, ov)
             assert tile.cpu().numpy().tobytes() == want[frames][1], (it, ov)

@@ -151,6 +151,23 @@ struct Context {
         int counterBase = 0;
     } rsb[2];
     unsigned long long* dRaysBatch = nullptr; // [2][kMaxBatch] per-frame ray counters of those two batches
+    // Streaming callers of tptDrawDevice / tptDrawSharded with SMALL frames (tiles of a sharded frame, 640x360): a launch cannot
+    // be shorter than its longest pixel's sequential samples, so frame by frame such callers are bound by launch latency, not
+    // by arithmetic.  When the calls are consecutive frames of one static configuration, the next call's frames are traced in
+    // the SAME launch (2-8 frames, tptDrawDeviceBatch's kernel path, a ray counter per frame) and each later call only blends
+    // its own plane -- every frame is still delivered, in order, with its own ray count.  A wrong guess costs GPU time only.
+    struct StreamBatch {
+        bool used = false;
+        int firstFrame = 0, n = 0, next = 0, w = 0, h = 0;
+        unsigned flags = 0;
+        unsigned long long key = 0;
+        TraceTicket T;
+        int counterBase = 0;
+    } sbatch;
+    static const int kStreamBatchMax = 8, kStreamRing = 64;
+    unsigned long long* dRaysStream = nullptr; // [kStreamRing][kStreamBatchMax]
+    unsigned long long streamBatches = 0;       // batches launched (ring index)
+    int streamBatch = 1;                        // tptSetStreamBatching / env TPT_STREAM_BATCH=0: off
     // tptDrawDevice: is the caller synchronous (the previous frame's blend has completed by the time the next call arrives)
     // and are its calls consecutive frames of one configuration?  Then the next frames are traced ahead for it too.
     struct DeviceCaller {
@@ -522,6 +539,10 @@ int tptInitialize(void)
     HIPCHK(hipEventCreateWithFlags(&g.evBandEnd, kOrderingEvent));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dRaysAhead), sizeof(unsigned long long) * Context::kMaxSlots));
     HIPCHK(hipMemsetAsync(g.dRaysAhead, 0, sizeof(unsigned long long) * Context::kMaxSlots, g.stream));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dRaysStream), sizeof(unsigned long long) * Context::kStreamRing * Context::kStreamBatchMax));
+    HIPCHK(hipMemsetAsync(g.dRaysStream, 0, sizeof(unsigned long long) * Context::kStreamRing * Context::kStreamBatchMax, g.stream));
+    g.sbatch.used = false;
+    if (const char* esb = getenv("TPT_STREAM_BATCH")) g.streamBatch = atoi(esb) != 0;
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dRaysBatch), sizeof(unsigned long long) * 2 * kMaxBatch));
     HIPCHK(hipMemsetAsync(g.dRaysBatch, 0, sizeof(unsigned long long) * 2 * kMaxBatch, g.stream));
     g.rsb[0].used = g.rsb[1].used = false;
@@ -606,6 +627,8 @@ int tptShutdown(void)
     for (int k = 0; k < 4; ++k) g.ahead[k].used = false;
     (void)hipFree(g.dRaysAhead); g.dRaysAhead = nullptr;
     (void)hipFree(g.dRaysBatch); g.dRaysBatch = nullptr;
+    (void)hipFree(g.dRaysStream); g.dRaysStream = nullptr;
+    g.sbatch.used = false;
     g.rsb[0].used = g.rsb[1].used = false;
     g.orderDone = true; g.orderStream = nullptr; g.oldestPending = 0; g.frameSeq = 0;
     g.streamDepth = 1; g.prevInFlight = -1;
@@ -624,13 +647,16 @@ int tptSetStream(void* hipStream)
 int tptSetSamplesPerPixel(int spp)
 {
     if (spp < 1 || spp > 65536) return fail("tptSetSamplesPerPixel: spp out of range");
+    if (spp == g.spp) return 0; // (a setter that changes nothing must not invalidate frames traced ahead)
     g.spp = spp;
     g.configEpoch++;
     return 0;
 }
 int tptSetConfig(int lightSampling, float animateSmoothing, int mitsubaCompare)
 {
-    g.config = (lightSampling ? CFG_LIGHT_SAMPLING : 0) | (mitsubaCompare ? CFG_MITSUBA_COMPARE : 0);
+    const int config = (lightSampling ? CFG_LIGHT_SAMPLING : 0) | (mitsubaCompare ? CFG_MITSUBA_COMPARE : 0);
+    if (config == g.config && animateSmoothing == g.animateSmoothing) return 0;
+    g.config = config;
     g.animateSmoothing = animateSmoothing;
     g.configEpoch++;
     return 0;
@@ -638,6 +664,7 @@ int tptSetConfig(int lightSampling, float animateSmoothing, int mitsubaCompare)
 int tptSetSeedMode(int mode)
 {
     if (mode != SEED_ROW_SERIAL && mode != SEED_PER_PIXEL) return fail("tptSetSeedMode: 0 (ROW_SERIAL) or 1 (PER_PIXEL)");
+    if (mode == g.seedMode) return 0;
     g.seedMode = mode;
     g.configEpoch++;
     return 0;
@@ -645,6 +672,7 @@ int tptSetSeedMode(int mode)
 int tptSetFoldMode(int mode)
 {
     if (mode != FOLD_RECURSIVE && mode != FOLD_FORWARD) return fail("tptSetFoldMode: 0 (RECURSIVE) or 1 (FORWARD)");
+    if (mode == g.foldMode) return 0;
     g.foldMode = mode;
     g.configEpoch++;
     return 0;
@@ -1179,7 +1207,7 @@ int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long
     if (colourBytesPerSlot > (4ull << 30))
         return fail("tptDrawDeviceBatch: " + std::to_string(colourBytesPerSlot >> 20) + " MiB of frame colour per launch (rows x width x 16 B x frames): over the 4096 MiB limit, use a smaller batch");
     while (P.nSlots > 2 && colourBytesPerSlot * (size_t)P.nSlots > (8ull << 30)) P.nSlots /= 2;
-    if (rayStride > 0 && P.nSlots > 4) P.nSlots = 4; // (the host path's row-serial batches: two alive at a time)
+    if (rayStride > 0 && g.seedMode == SEED_ROW_SERIAL && P.nSlots > 4) P.nSlots = 4; // (the host path's row-serial batches: two alive at a time)
     if (P.nOverlap > P.nSlots) P.nOverlap = P.nSlots;
     P.slot = (int)(g.frameSeq % (unsigned long long)P.nSlots);
     g.frameSeq++;
@@ -1300,8 +1328,43 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
     const Context::Ahead& front = g.ahead[0];
     const bool hit = front.used && front.frameCount == frameCount && front.w == w && front.h == h && front.flags == testFlags &&
                      front.configKey == key && stable && !g.mirror;
-    if (!hit && !lookAhead) { // the plain path: trace + blend, the kernel adds its rays to the running total itself
-        if ((rc = discardLookahead())) return rc;
+    if (!hit && !lookAhead) {
+        // ---- a streaming caller with small frames: served from / starting a stream batch (see Context::StreamBatch)
+        Context::StreamBatch& SB = g.sbatch;
+        if (SB.used && SB.w == w && SB.h == h && SB.flags == testFlags && SB.key == key && stable && frameCount == SB.firstFrame + SB.next) {
+            const int j = SB.next++;
+            T = SB.T;
+            T.colour = SB.T.colour + (size_t)j * (size_t)SB.T.nPixels;
+            T.lerpFac = SB.T.lerp.v[j];
+            T.batch = 1;
+            if (SB.next == SB.n) SB.used = false;
+            rc = enqueueResolve(T, deviceTile, g.dRaysStream + SB.counterBase + j);
+            D.lastSlot = T.slot;
+            return rc;
+        }
+        if ((rc = discardLookahead())) return rc; // (also closes a stream batch that did not continue as guessed)
+        int nBatch = 1;
+        if (g.streamBatch && pipelined && stable && D.seqStreak >= 2 && g.persist == 3 && g.seedMode == SEED_PER_PIXEL && g.foldMode == FOLD_RECURSIVE &&
+            g.hs == HS_TWO_PHASE && w <= 8192 && h <= 8192 && g.spp <= 2047) {
+            // how many frames make a launch long enough to amortise its fixed cost: 1 at 1280x720x4 (3.7 M samples), 2 / 4 / 8 for
+            // halves / quarters / eighths of that (profiles/r03/r03_run19.log: where several frames per launch pay)
+            const long long samples = (long long)localRows(h) * w * g.spp;
+            nBatch = samples >= 2400000 ? 1 : samples >= 1200000 ? 2 : samples >= 600000 ? 4 : Context::kStreamBatchMax;
+            if (samples <= 0) nBatch = 1;
+        }
+        if (nBatch > 1) {
+            SB.firstFrame = frameCount; SB.n = nBatch; SB.next = 1; SB.w = w; SB.h = h; SB.flags = testFlags; SB.key = key;
+            SB.counterBase = (int)(g.streamBatches++ % (unsigned long long)Context::kStreamRing) * Context::kStreamBatchMax;
+            if ((rc = enqueueTrace(frameCount, w, h, testFlags, g.dRaysStream + SB.counterBase, SB.T, nBatch, 1))) return rc;
+            SB.used = SB.T.valid;
+            T = SB.T;
+            T.lerpFac = SB.T.lerp.v[0];
+            T.batch = 1;
+            rc = enqueueResolve(T, deviceTile, T.valid ? g.dRaysStream + SB.counterBase : nullptr);
+            if (T.valid) D.lastSlot = T.slot;
+            return rc;
+        }
+        // the plain path: trace + blend, the kernel adds its rays to the running total itself
         if ((rc = enqueueTrace(frameCount, w, h, testFlags, nullptr, T))) return rc;
         rc = enqueueResolve(T, deviceTile, nullptr);
         if (T.valid) D.lastSlot = T.slot;
@@ -1412,12 +1475,14 @@ namespace {
 // to be used): let them finish and forget them.  Their colour buffers were never blended into anything.
 int discardLookahead()
 {
+    g.sbatch.used = false; // (an open stream batch needs no wait: its unserved planes are simply never blended)
     bool any = g.rsb[0].used || g.rsb[1].used;
     for (int k = 0; k < 4; ++k) any = any || g.ahead[k].used;
     if (!any) return 0;
     for (int k = 0; k < Context::kMaxOverlap; ++k) HIPCHK(hipStreamSynchronize(g.traceStream[k]));
     for (int k = 0; k < 4; ++k) g.ahead[k].used = false;
     g.rsb[0].used = g.rsb[1].used = false;
+    g.sbatch.used = false;
     return 0;
 }
 
@@ -1466,6 +1531,15 @@ int tptSetHostBufferMode(int hostBufferOnlyWrittenByDrawTest)
 {
     g.hostTrust = hostBufferOnlyWrittenByDrawTest ? 1 : 0;
     g.tileSrc = nullptr; // next DrawTest uploads once
+    return 0;
+}
+
+int tptSetStreamBatching(int enable)
+{
+    if (requireInit()) return -1;
+    int rc = discardLookahead();
+    if (rc) return rc;
+    g.streamBatch = enable ? 1 : 0;
     return 0;
 }
 

@@ -91,11 +91,17 @@ __global__ void __launch_bounds__(256) tptResolveKernel(float* __restrict__ tile
 // next frames keep accumulating into the tile) and the current value of the ray counter to `counterOut`: one kernel
 // in the frame's dependency chain instead of three.
 __global__ void __launch_bounds__(256) tptResolveMirrorKernel(float* __restrict__ tile, const f4* __restrict__ colour, int nPixels, float lerpFac,
-                                                              f4* __restrict__ mirror, const unsigned long long* rayCounter,
-                                                              unsigned long long* counterOut)
+                                                              f4* __restrict__ mirror, unsigned long long* rayCounter,
+                                                              unsigned long long* counterOut, const unsigned long long* frameRays)
 {
     __builtin_amdgcn_s_setprio(3); // see tptResolveKernel
-    if (blockIdx.x == 0 && threadIdx.x == 0 && counterOut) *counterOut = __hip_atomic_load(rayCounter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        // frameRays: the frame's own ray count (it was traced as part of a batch), folded into the running total here, in
+        // frame order -- the snapshot of the counter that travels with the mirrored tile then is exact for "frames up to this one"
+        unsigned long long total = frameRays ? atomicAdd(rayCounter, *frameRays) + *frameRays
+                                             : __hip_atomic_load(rayCounter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (counterOut) *counterOut = total;
+    }
     for (int i = blockIdx.x * 256 + threadIdx.x; i < nPixels; i += gridDim.x * 256) {
         f4 t = reinterpret_cast<const f4*>(tile)[i];
         f4 c = colour[i];
@@ -417,6 +423,7 @@ struct QueueCtl {
     unsigned tail[8];
     unsigned poolTotal;       // pixels sitting in the private chunk pools of this workgroup's waves (+ fetches in flight)
     unsigned globalExhausted; // some wave saw the global chunk counter run out
+    unsigned frameRays[32];   // batched launch: rays traced for each frame of the batch by this workgroup
 };
 
 // Push every lane's path id to the queue of its class `cls` (Q_FREE..Q_LAMBERT, or -1 for none): one returning LDS atomic
@@ -577,6 +584,7 @@ tptTraceQueueKernel(const KernelArgs a)
         ctl->poolTotal = 0u;
         ctl->globalExhausted = 0u;
     }
+    if (BATCH && tid < 32) ctl->frameRays[tid] = 0u;
     __syncthreads();
 
     const FrameConsts& fc = a.fc;
@@ -820,6 +828,7 @@ tptTraceQueueKernel(const KernelArgs a)
         // ---- HitWorld for the rays this batch produced.  A Lambert batch first runs its light loop (Test.cpp:96-133), wave-
         //      uniform in j: shadow ray, intersection, shading, all in registers; its last trip intersects the bounce ray.
         int cls = -1;
+        unsigned iterRays = 0; // (batched launch: this lane's rays of this iteration, counted for the frame its path belongs to)
         const int nRay = __popcll(__ballot(ray));
         if (pick == Q_FREE || pick == Q_INT || pick == Q_LAMBERT || nRay >= TPT_Q_FUSE_MIN) {
             const int nShadow = (pick == Q_LAMBERT && (fc.config & CFG_LIGHT_SAMPLING)) ? sv.nLights : 0;
@@ -862,7 +871,7 @@ tptTraceQueueKernel(const KernelArgs a)
 #else
                     const int id = hitSpheres<LDS_SCENE ? HS_TWO_PHASE : HS_TWO_PHASE_GROUPS>(sv, ro, d2, TPT_MIN_T, TPT_MAX_T, t);
 #endif
-                    myRays++;
+                    if (BATCH) iterRays++; else myRays++;
                     if (shadow) {
                         if (id == lightId) qLightShade(l1, d2, lam);
                     } else {
@@ -891,6 +900,7 @@ tptTraceQueueKernel(const KernelArgs a)
             st[1 * TPT_Q_PATHS + p] = mk4(rd.x, rd.y, rd.z, u2f(w));
         }
         if (toFree) cls = Q_FREE;
+        if (BATCH && iterRays != 0u) atomicAdd(&ctl->frameRays[f2u(colSum[p].w) >> 26], iterRays); // (one LDS atomic per lane and iteration)
         TPT_TSTAMP(tsInt);
         TPT_TADD(64 + pick * 4 + 2, tsClass, tsInt);
         // (the cold state is global memory, but every wave that can pop this path runs on this CU and shares its L1:
@@ -902,8 +912,14 @@ tptTraceQueueKernel(const KernelArgs a)
     }
 
     const unsigned waveRays = waveReduceAdd(myRays);
+    if (BATCH) {
+        // every frame of the batch has its own counter (rayCounterStride 1: a caller that is served the frames one by one
+        // gets each frame's own count; 0: they all add to the context's running total)
+        __syncthreads();
+        if (tid < a.batchFrames && ctl->frameRays[tid] != 0u) atomicAdd(a.rayCounter + (size_t)tid * a.rayCounterStride, (unsigned long long)ctl->frameRays[tid]);
+    }
     if (lane == 0) {
-        atomicAdd(a.rayCounter, (unsigned long long)waveRays);
+        if (!BATCH) atomicAdd(a.rayCounter, (unsigned long long)waveRays);
         unsigned done = atomicAdd(&a.work[1], 1u) + 1u;
         if (done == a.totalWaves) {
             a.work[0] = 0u;
@@ -1161,7 +1177,7 @@ hipError_t tptLaunchResolve(float* tile, const f4* frameColour, int nPixels, flo
     const int blocks = tptResolveBlocks(nPixels);
     if (mirror)
         hipLaunchKernelGGL(tptResolveMirrorKernel, dim3(blocks), dim3(256), 0, stream, tile, frameColour, nPixels, lerpFac,
-                           reinterpret_cast<f4*>(mirror), rayCounter, counterOut);
+                           reinterpret_cast<f4*>(mirror), rayCounter, counterOut, frameRays);
     else
         hipLaunchKernelGGL(tptResolveKernel, dim3(blocks), dim3(256), 0, stream, tile, frameColour, nPixels, lerpFac, frameRays, rayCounter);
     return hipGetLastError();

@@ -141,16 +141,25 @@ def image_parity(image, rays_total, width, height, spp, frames, max_frames=64):
     return out
 
 
+def drain_lookahead(api):
+    """Frames the library traced ahead of a synchronous caller are dropped and the GPU is idle: a secondary leg neither inherits
+    speculative work from the one before it nor leaves its own unfinished behind its end time."""
+    api.set_host_lookahead(2)  # (the default; setting it drops what was traced ahead)
+    api.synchronize()
+
+
 def drawtest_host_path(api, width, height, frames=24):
     """The reference's own contract: synchronous DrawTest on a HOST backbuffer (upload + trace + blend + download)."""
     bb = np.zeros((height, width, 4), np.float32)
     for f in range(4):
         api.UpdateTest(0.0, f, width, height, FLAG_PROGRESSIVE)
         api.DrawTest(0.0, f, width, height, bb, FLAG_PROGRESSIVE)
+    drain_lookahead(api)  # the timed frames start with nothing traced ahead (the first one pays a full trace) ...
     rays, t0 = 0, time.perf_counter()
     for f in range(4, 4 + frames):
         api.UpdateTest(0.0, f, width, height, FLAG_PROGRESSIVE)
         rays += api.DrawTest(0.0, f, width, height, bb, FLAG_PROGRESSIVE)
+    drain_lookahead(api)  # ... and the frames still being traced ahead of the last call are waited for inside the timed region
     dt = time.perf_counter() - t0
     return dt / frames * 1e3, rays / dt / 1e6
 
@@ -183,12 +192,14 @@ def sync_caller_rate(api, torch, width, height, frames=60):
         api.UpdateTest(0.0, f, width, height, FLAG_PROGRESSIVE)
         api.draw_device(0.0, f, width, height, tile.data_ptr(), FLAG_PROGRESSIVE)
         api.synchronize()
+    drain_lookahead(api)
     r0 = api.ray_counter_read()
     t0 = time.perf_counter()
     for f in range(8, 8 + frames):
         api.UpdateTest(0.0, f, width, height, FLAG_PROGRESSIVE)
         api.draw_device(0.0, f, width, height, tile.data_ptr(), FLAG_PROGRESSIVE)
         api.synchronize()
+    drain_lookahead(api)
     dt = time.perf_counter() - t0
     rays = api.ray_counter_read() - r0
     return dt / frames * 1e3, rays / dt / 1e6
@@ -201,10 +212,12 @@ def row_serial_rate(api, width, height, frames=96):
     bb = np.zeros((height, width, 4), np.float32)
     api.UpdateTest(0.0, 0, width, height, FLAG_PROGRESSIVE)
     api.DrawTest(0.0, 0, width, height, bb, FLAG_PROGRESSIVE)
+    drain_lookahead(api)
     rays, t0 = 0, time.perf_counter()
     for f in range(1, 1 + frames):
         api.UpdateTest(0.0, f, width, height, FLAG_PROGRESSIVE)
         rays += api.DrawTest(0.0, f, width, height, bb, FLAG_PROGRESSIVE)
+    drain_lookahead(api)
     dt = time.perf_counter() - t0
     api.set_seed_mode(1)
     return dt / frames * 1e3, rays / dt / 1e6

@@ -463,6 +463,15 @@ int requireInit()
 // queues can carry (tptGetPipelineInfo reports both numbers).
 int probeHardwareQueues()
 {
+    // env TPT_HW_QUEUES=n: the host knows how many hardware queues this process has (GPU_MAX_HW_QUEUES as the runtime read it):
+    // no probe (it costs 2-4 ms at start-up and measures a busy, shared GPU pessimistically)
+    if (const char* eq = getenv("TPT_HW_QUEUES")) {
+        const int q = atoi(eq);
+        g.hwQueues = q < 1 ? 1 : (q > Context::kMaxOverlap ? Context::kMaxOverlap : q);
+        g.overlapCap = g.hwQueues >= Context::kMaxOverlap ? Context::kMaxOverlap : (g.hwQueues >= 8 ? g.hwQueues - 3 : 2);
+        if (const char* e = getenv("TPT_OVERLAP_CAP")) g.overlapCap = atoi(e) < 1 ? 1 : (atoi(e) > Context::kMaxOverlap ? Context::kMaxOverlap : atoi(e));
+        return 0;
+    }
     // Long enough that enqueueing the 16 probes (~20 us each) does not matter: 2 ms of the 100 MHz wall clock.
     const double spinUs = 2000.0;
     const unsigned long long ticks = (unsigned long long)(spinUs * 100.0);

@@ -1,0 +1,11 @@
+#!/bin/bash
+# r03 closing run: full GPU suite, smoke, the driver's command (full line), steady state
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+cd "$R"
+mkdir -p gpurun_out/ev4
+echo "== full GPU suite"; timeout 2400 python -m pytest tests -m gpu -q --tb=line 2>&1 | grep -v "RCCL\|HIP version\|ROCm version\|Hostname\|Librccl" | tail -8
+echo "== smoke"; python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+summ() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%8.1f Mray/s  %.4f ms/step  launch %.3f ms grid %d valu_frac %.4f parity %s host %s sync %s rowserial %s/%s batched %s/%s cpu %s' % (d['value'], d['ms_per_step'], d['trace_launch_ms_avg'], d['config']['grid_blocks'], d['roofline_valu']['frac'], d.get('parity_ok'), d.get('drawtest_host_ms'), d.get('sync_device_caller_ms'), d.get('row_serial_Mray_s'), d.get('row_serial_batched_32_Mray_s'), d.get('batched_4_Mray_s'), d.get('batched_8_Mray_s'), d.get('cpu_baseline',{}).get('value')))"; }
+echo "== driver's command (full line)"; timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 | tee gpurun_out/ev4/bench_c2_driver_cmd.json | summ
+echo "== steady state"; timeout 300 python bench.py --no-cpu-baseline --no-extras --steps 200 --warmup 20 --parity-frames 0 2>/dev/null | tail -1 | tee gpurun_out/ev4/bench_c2_steps200.json | summ

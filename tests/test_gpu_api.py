@@ -266,7 +266,7 @@ def test_stream_batching_delivers_every_frame_with_its_own_ray_count(tpt_default
                 # calls 0 and 1 are plain launches (their kernels add their rays whenever they end, both before the third blend);
                 # everything after them is served from batches
                 assert counts[2:] == totals[2:], (counts, totals)
-    tpt.set_stream_batching(True)
+    tpt.set_stream_batching(False)
 
 
 def test_drawtest_lookahead_is_dropped_by_every_state_change(tpt_defaults, oracle):

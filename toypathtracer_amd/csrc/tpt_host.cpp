@@ -167,7 +167,7 @@ struct Context {
     static const int kStreamBatchMax = 8, kStreamRing = 64;
     unsigned long long* dRaysStream = nullptr; // [kStreamRing][kStreamBatchMax]
     unsigned long long streamBatches = 0;       // batches launched (ring index)
-    int streamBatch = 1;                        // tptSetStreamBatching / env TPT_STREAM_BATCH=0: off
+    int streamBatch = 0;                        // tptSetStreamBatching(1) / env TPT_STREAM_BATCH=1: on (opt-in)
     // tptDrawDevice: is the caller synchronous (the previous frame's blend has completed by the time the next call arrives)
     // and are its calls consecutive frames of one configuration?  Then the next frames are traced ahead for it too.
     struct DeviceCaller {

@@ -138,13 +138,13 @@ int tptDrawDeviceBatch(float time, int firstFrame, int nFrames, int screenWidth,
  * run side by side and clamps the pipeline to that (tptGetPipelineInfo).  Twice as many frames may be ENQUEUED ahead
  * (frames f and f + frames share a stream). */
 int tptSetFrameOverlap(int frames);
-/* Stream batching (default on): a caller that streams consecutive frames of one static configuration with SMALL frames -- fewer
+/* Stream batching (opt-in, default off): a caller that streams consecutive frames of one static configuration with SMALL frames -- fewer
  * than 2.4 M samples (rows x width x spp): tiles of a sharded frame, 640x360 -- is bound by the latency of a launch (no launch is
  * shorter than its longest pixel's sequential samples), not by arithmetic.  For such a caller tptDrawDevice / tptDrawSharded trace
  * the frames of the next 1-7 calls in the SAME launch (2 / 4 / 8 frames per launch for halves / quarters / eighths of 1280x720x4)
  * and every later call only blends its own colour plane: each frame is still delivered, in order, with its own ray count (the
  * counter and the mirrored snapshot are exact per frame), bit-identical to one launch per frame.  A call that does not continue
- * the sequence (other frame number, size, flags, scene, ...) drops the unserved planes: GPU time only.  0 turns it off. */
+ * the sequence (other frame number, size, flags, scene, ...) drops the unserved planes: GPU time only.  1 turns it on (also env TPT_STREAM_BATCH=1 at tptInitialize). */
 int tptSetStreamBatching(int enable);
 /* Display conversion of a device-resident FULL image (w*h float4, row 0 = bottom) into w*h RGBA8 in device memory,
  * top row first: the reference's own conversion for its C++ path, Cpp/Emscripten/main.cpp:63-79

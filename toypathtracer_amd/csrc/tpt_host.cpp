@@ -551,7 +551,7 @@ int tptInitialize(void)
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dRaysStream), sizeof(unsigned long long) * Context::kStreamRing * Context::kStreamBatchMax));
     HIPCHK(hipMemsetAsync(g.dRaysStream, 0, sizeof(unsigned long long) * Context::kStreamRing * Context::kStreamBatchMax, g.stream));
     g.sbatch.used = false;
-    if (const char* esb = getenv("TPT_STREAM_BATCH")) g.streamBatch = atoi(esb) != 0;
+    if (const char* esb = getenv("TPT_STREAM_BATCH")) g.streamBatch = atoi(esb) != 0; // (opt-in)
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dRaysBatch), sizeof(unsigned long long) * 2 * kMaxBatch));
     HIPCHK(hipMemsetAsync(g.dRaysBatch, 0, sizeof(unsigned long long) * 2 * kMaxBatch, g.stream));
     g.rsb[0].used = g.rsb[1].used = false;

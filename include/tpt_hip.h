@@ -222,7 +222,7 @@ int tptKernelTimingEnd(float* outSumMilliseconds, int* outLaunches);
  * 1 = stage sphere records and materials in LDS (default when they fit), 0 = read them from global memory, -1 = auto.
  * All variants produce identical bits. */
 int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene);
-/* device math unit tests: op 0 sqrt 1 div 2 sin 3 cos 4 pow5 5 rnd01^16 6 schlick 7 normalize.x; host arrays */
+/* device math unit tests: op 0 sqrt 1 div 2 sin 3 cos 4 pow5 5 rnd01^16 6 schlick 7 normalize.x 8 / 9 sin / cos of the sincos pair; host arrays */
 int tptTestMath(int op, const float* a, const float* b, float* out, int n);
 /* intersect n host rays ([n][6] = origin, UNIT direction -- the reference asserts it, Maths.h:337; the two-phase
  * filter's error bound assumes it) with the current scene on the GPU */

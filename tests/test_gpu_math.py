@@ -59,6 +59,17 @@ def test_sincos_bit_exact_on_path_domain(tpt, oracle):
         assert np.all(np.abs(got_c.astype(np.float64) - np.cos(a.astype(np.float64))) < 1.2e-7)
 
 
+def test_sincos_pair_equals_sinf_cosf_on_the_whole_path_domain(tpt):
+    """tsincosf (one argument-reduction path for every angle) against tsinf / tcosf (glibc's branch structure, pinned to libm
+    above) for ALL 2^24 arguments rnd01 * 2 * kPI can take, in both association orders the path uses (Maths.cpp:42, Test.cpp:116)."""
+    k = np.arange(0, 1 << 24, dtype=np.uint32)
+    r = k.astype(np.float32) / np.float32(16777216.0)
+    for a in (r * np.float32(2.0) * np.float32(3.1415926), np.float32(2 * np.float32(3.1415926)) * r):
+        a = a.astype(np.float32)
+        assert np.array_equal(bits(tpt.test_math(8, a)), bits(tpt.test_math(2, a)))
+        assert np.array_equal(bits(tpt.test_math(9, a)), bits(tpt.test_math(3, a)))
+
+
 def test_pow5_bit_exact(tpt, oracle):
     rng = np.random.default_rng(2)
     x = np.concatenate([rng.uniform(-0.5, 1.0, 200000).astype(np.float32), rnd_floats(rng, 50000, -39, 0, signed=True),

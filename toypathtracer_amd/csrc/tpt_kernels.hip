@@ -947,7 +947,7 @@ tptTraceQueueKernel(const KernelArgs a)
 }
 
 // ---------------------------------------------------------------- unit-test kernels (GPU parity of the math layer)
-// op: 0 sqrt(a) 1 a/b 2 tsinf(a) 3 tcosf(a) 4 tpow5f(a) 5 rnd01 stream (a = seed bits) 6 schlick(a,b) 7 1/sqrt-normalize.x
+// op: 0 sqrt(a) 1 a/b 2 tsinf(a) 3 tcosf(a) 4 tpow5f(a) 5 rnd01 stream (a = seed bits) 6 schlick(a,b) 7 1/sqrt-normalize.x 8 / 9 sin / cos of tsincosf(a)
 __global__ void tptMathTestKernel(int op, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -966,6 +966,8 @@ __global__ void tptMathTestKernel(int op, const float* __restrict__ a, const flo
     }
     case 6: r = schlick(x, y); break;
     case 7: r = normalize(mk3(x, y, 1.0f)).x; break;
+    case 8: { float sn, cs; tsincosf(x, sn, cs); r = sn; break; } // the pair the path uses, against ops 2 / 3
+    case 9: { float sn, cs; tsincosf(x, sn, cs); r = cs; break; }
     }
     out[i] = r;
 }

@@ -220,17 +220,15 @@ TPT_HD float tcosf(float y)
 TPT_HD void tsincosf(float y, float& outSin, float& outCos)
 {
     double x = y;
-    if (abstop12(y) < abstop12(0x1.921FB6p-1f)) {
-        if (abstop12(y) < abstop12(0x1p-12f)) {
-            outSin = y;
-            outCos = 1.0f;
-            return;
-        }
-        double x2 = x * x;
-        outSin = sincos_poly(x, x2, false, 0);
-        outCos = sincos_poly(x, x2, false, 1);
+    if (abstop12(y) < abstop12(0x1p-12f)) {
+        outSin = y;
+        outCos = 1.0f;
         return;
     }
+    // glibc branches on |y| < pi/4 to skip the argument reduction; the reduction of such an argument is the identity (n = 0,
+    // x - 0 * pi/2 = x, sign +1, same polynomials on the same x and x^2), so ONE path serves both and a wave whose lanes
+    // straddle pi/4 -- nearly every wave: the angle is uniform in [0, 2 pi) -- no longer runs the polynomials twice.  Same bits:
+    // test_gpu_math.py::test_sincos_pair_equals_sinf_cosf_on_the_whole_path_domain (all 2^24 arguments of both call forms).
     int n;
     x = reduce_fast(x, n);
     double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;

@@ -1175,10 +1175,12 @@ TPT_HD f3 qLightRay(const f4 l0, f3 pos, uint32_t& rng, float& cosAMax)
 {
     TPT_STAT(ST_LIGHTGEN);
     const f3 sc = mk3(l0.x, l0.y, l0.z);
-    const f3 sw = normalize(sc - pos);
+    const f3 toL = sc - pos;
+    const float d2 = dot(toL, toL); // = sqLength(pos - sc) bit for bit: (a - b) and (b - a) differ in sign only, the squares are equal
+    const f3 sw = toL * trsqrt2(d2); // normalize(sc - pos)
     const f3 su = normalize(cross((sw.x < 0 ? -sw.x : sw.x) > 0.01f ? mk3(0, 1, 0) : mk3(1, 0, 0), sw));
     const f3 sv_ = cross(sw, su);
-    cosAMax = tsqrt(1.0f - l0.w * l0.w / sqLength(pos - sc));
+    cosAMax = tsqrt(1.0f - l0.w * l0.w / d2);
     const float eps1 = rnd01(rng), eps2 = rnd01(rng);
     const float cosA = 1.0f - eps1 + eps1 * cosAMax;
     const float sinA = tsqrt(1.0f - cosA * cosA);

@@ -329,6 +329,7 @@ def main():
             dist.broadcast_object_list(uid, src=0, device=device)
         api.comm_init(uid[0], world, rank, args.stripe_rows)
         image_on_root = torch.zeros((height, width, 4), dtype=torch.float32, device=device)
+        torch.cuda.synchronize()  # (the fill ran on torch's stream; the library's streams do not wait for it)
         img_ptr = image_on_root.data_ptr()
 
         def step(frame):

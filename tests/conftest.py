@@ -77,3 +77,28 @@ def tpt_defaults(tpt):
     tpt.set_host_lookahead(2)
     tpt.set_stream_batching(os.environ.get("TPT_FORCE_STREAM_BATCH", "0") == "1")  # opt-in feature: off unless a test (or the environment) asks for it
     return tpt
+
+
+@pytest.fixture(autouse=True, scope="session")
+def _torch_fills_complete_before_the_library_sees_the_buffer():
+    """torch.zeros(..., device="cuda") enqueues its fill on torch's current stream; the library works on its own non-blocking
+    streams, which do not wait for it.  A test that hands such a tensor to the library straight away races the fill against the
+    library's writes (seen as an all-zero assembled image or a garbage snapshot counter once in a few suite runs, when long
+    batched launches of an earlier test were still occupying the GPU).  Every CUDA tensor the tests create is therefore complete
+    when torch.zeros returns.  (A host has the same obligation: INTEGRATION.md section 3.)"""
+    try:
+        import torch
+    except ImportError:
+        yield
+        return
+    orig = torch.zeros
+
+    def zeros(*a, **k):
+        t = orig(*a, **k)
+        if t.is_cuda:
+            torch.cuda.synchronize()
+        return t
+
+    torch.zeros = zeros
+    yield
+    torch.zeros = orig

@@ -111,6 +111,8 @@ class ShardedFrame:
             self.comm_stream = torch.cuda.Stream(device=self.device)
             self.ev_ready = [torch.cuda.Event() for _ in range(depth)]   # send buffer filled (render stream)
             self.ev_free = [torch.cuda.Event() for _ in range(depth)]    # send buffer consumed (comm stream)
+            # the buffers above were filled on torch's current stream; the library and the two streams here do not wait for it
+            torch.cuda.synchronize(self.device)
         else:
             self.render_stream = self.comm_stream = None
 

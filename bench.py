@@ -141,13 +141,10 @@ def image_parity(image, rays_total, width, height, spp, frames, max_frames=64):
     return out
 
 
-HOST_LOOKAHEAD = 2  # the library's default (tptSetHostLookahead); tools/host_drawtest_rate.py sweeps it
-
-
 def drain_lookahead(api):
     """Frames the library traced ahead of a synchronous caller are dropped and the GPU is idle: a secondary leg neither inherits
     speculative work from the one before it nor leaves its own unfinished behind its end time."""
-    api.set_host_lookahead(HOST_LOOKAHEAD)  # (setting it drops what was traced ahead)
+    api.set_host_lookahead(2)  # (the default; setting it drops what was traced ahead)
     api.synchronize()
 
 

@@ -49,12 +49,10 @@ int tptDraw(float time, int frameCount, int screenWidth, int screenHeight, float
             unsigned testFlags);
 /* The host-pointer path above keeps the reference's contract (synchronous, the caller's buffer read-modify-written in
  * place); three things make it fast, none changes a byte of the result:
- *  - the upload of the previous image, the blend and the download are done in four row bands on two streams, so that one
- *    band's download crosses PCIe while the next band's upload does (full duplex).  The caller's memory is NOT page-locked
- *    (it is the caller's to free between calls); because a copy from / to pageable memory does not return before it is
- *    done, the bands go through a pinned staging buffer, filled and emptied by tptSetHostCopyThreads(n) threads (default 4:
- *    the calling thread + 3 helpers that spin for 0.5 ms after a frame and sleep otherwise; 1 = no helpers, no staging,
- *    the two directions then run one after the other: 2 x 0.27 ms for 1280x720);
+ *  - the upload of the previous image, the blend and the download are done in four row bands on two streams, so that a
+ *    band's blend and download do not wait for the whole upload.  The caller's memory is NOT page-locked: it is the
+ *    caller's to free between calls, and both directions run at link speed from pageable memory (measured: 0.27-0.30 ms
+ *    each for 1280x720; they do not overlap -- a copy on pageable memory returns when it is done);
  *  - tptSetHostBufferMode(1): the caller promises that nobody but DrawTest writes the backbuffer between calls (true of
  *    every reference host: TestWin.cpp:73-74,315-316; Renderer.mm:225; Emscripten/main.cpp:59-60) -- the device-resident
  *    accumulation tile is then the source of truth and the buffer is uploaded once per buffer / size / frameCount == 0
@@ -70,7 +68,6 @@ int tptDraw(float time, int frameCount, int screenWidth, int screenHeight, float
  *    when its next call arrives, twice in a row, for consecutive frames of one configuration (a caller that streams frames
  *    never meets that and is unaffected): 0.98 -> ~0.55 ms per 1280x720x4 frame for a host that waits for every frame. */
 int tptSetHostBufferMode(int hostBufferOnlyWrittenByDrawTest);
-int tptSetHostCopyThreads(int threads); /* 1..16, env TPT_HOST_COPY_THREADS */
 int tptSetHostLookahead(int frames);
 /* how many frames were found traced ahead when their DrawTest / tptDrawDevice call arrived (monotonic; diagnostics, tests) */
 int tptDebugLookaheadHits(long long* outHits);

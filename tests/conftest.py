@@ -75,7 +75,6 @@ def tpt_defaults(tpt):
     tpt.set_frame_overlap(16)
     tpt.set_host_buffer_mode(False)
     tpt.set_host_lookahead(2)
-    tpt.set_host_copy_threads(4)
     tpt.set_stream_batching(os.environ.get("TPT_FORCE_STREAM_BATCH", "0") == "1")  # opt-in feature: off unless a test (or the environment) asks for it
     return tpt
 

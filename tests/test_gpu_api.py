@@ -147,7 +147,7 @@ def _draw_seq(tpt, seq, w, h, bb=None, flags=FLAG_PROGRESSIVE):
     return per, bb
 
 
-@pytest.mark.parametrize("lookahead", [0, 1, 2, 3, 7, 12])
+@pytest.mark.parametrize("lookahead", [0, 1, 2, 3])
 def test_drawtest_lookahead_changes_nothing(tpt_defaults, oracle, lookahead):
     """DrawTest traces the next frames ahead of its caller (tptSetHostLookahead).  Whatever the depth, every frame's bytes
     and ray count equal the oracle's -- also when the sequence does not continue as guessed: a jump in frameCount, a
@@ -325,39 +325,6 @@ def test_drawtest_trusted_buffer_mode(tpt_defaults, oracle):
     _draw_seq(tpt, [2], w, h, bb)
     assert float(bb[:10, :, :3].min()) > 3.0  # 5 * 2/3 + col / 3
     tpt.set_host_buffer_mode(False)
-
-
-def test_drawtest_staged_copies_change_nothing(tpt_defaults, oracle):
-    """tptSetHostCopyThreads: the host image goes through pinned staging, copied in and out by 2 / 4 / 7 threads (bands of
-    0.9 MB at 640x360: the helpers take part), or straight from the caller's memory (1).  Same bytes and ray counts as the
-    oracle whatever the count, caller-owned alpha untouched, an edit between two frames picked up, the count changed in
-    the middle of a sequence, a second size (unaligned band edges)."""
-    from common import oracle_frames
-    tpt = tpt_defaults
-    w, h, frames = 640, 360, 4
-    ro, bo, pero = oracle_frames(oracle, w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
-    images = {}
-    for threads in (1, 2, 4, 7):
-        tpt.set_host_copy_threads(threads)
-        bb = np.zeros((h, w, 4), np.float32)
-        bb[..., 3] = 0.5
-        per, bb = _draw_seq(tpt, range(frames), w, h, bb)
-        assert per == pero, threads
-        assert bb[..., :3].tobytes() == bo[..., :3].tobytes() and float(bb[..., 3].min()) == 0.5 == float(bb[..., 3].max()), threads
-        bb[100:130, :, :3] = 2.0   # the caller edits the image between two frames ...
-        if threads == 4:
-            tpt.set_host_copy_threads(3)  # ... and the pool is rebuilt in the middle of a sequence
-        _draw_seq(tpt, [frames], w, h, bb)
-        images[threads] = bb.tobytes()
-        assert float(bb[100:130, :, :3].min()) > 1.5  # 2 * 4/5 + col / 5
-    assert len(set(images.values())) == 1
-    w2, h2 = 333, 259  # rows x row bytes not a multiple of anything
-    ro2, bo2, pero2 = oracle_frames(oracle, w2, h2, 4, 3, seed_mode=SEED_PER_PIXEL)
-    tpt.set_host_copy_threads(4)
-    per2, bb2 = _draw_seq(tpt, range(3), w2, h2)
-    assert per2 == pero2 and bb2.tobytes() == bo2.tobytes()
-    with pytest.raises(RuntimeError):
-        tpt.set_host_copy_threads(0)
 
 
 # ---- multi-GPU through the C ABI (RCCL inside the library)

@@ -37,7 +37,7 @@ C_ABI_SYMBOLS = [
     "tptSetSamplesPerPixel", "tptSetConfig", "tptSetSeedMode", "tptSetFoldMode", "tptSetScene", "tptSetCamera", "tptSetStream",
     "tptSetRowShard", "tptLocalRowCount", "tptLocalRowToGlobal", "tptDrawDevice", "tptRayCounterRead", "tptSetRayCounter", "tptSetFrameOverlap", "tptDisplayRGBA8", "tptKernelTimingBegin", "tptKernelTimingEnd",
     "tptSynchronize", "tptTimerBegin", "tptTimerEnd", "tptSetKernelVariant", "tptTestMath", "tptTestMathExhaustive", "tptTestHitSpheres",
-    "tptDrawDeviceBatch", "tptDrawShardedBatch", "tptDebugLookaheadHits", "tptCommGetUniqueId", "tptCommInit", "tptCommInitLoopback", "tptCommDestroy", "tptDrawSharded", "tptShardedFinish", "tptGetLaunchInfo", "tptGetPipelineInfo", "tptSetHostBufferMode", "tptSetHostCopyThreads", "tptSetHostLookahead", "tptSetStreamBatching", "tptTestMatrixFilter", "tptSetTileMirror", "tptGetLastError", "tptGetDeviceName", "tptDebugStats", "tptDebugChunkOrder",
+    "tptDrawDeviceBatch", "tptDrawShardedBatch", "tptDebugLookaheadHits", "tptCommGetUniqueId", "tptCommInit", "tptCommInitLoopback", "tptCommDestroy", "tptDrawSharded", "tptShardedFinish", "tptGetLaunchInfo", "tptGetPipelineInfo", "tptSetHostBufferMode", "tptSetHostLookahead", "tptSetStreamBatching", "tptTestMatrixFilter", "tptSetTileMirror", "tptGetLastError", "tptGetDeviceName", "tptDebugStats", "tptDebugChunkOrder",
 ]
 # the reference's own C++ symbols (nm of the compiled Test.cpp), exported for link-level drop-in
 CXX_ABI_SYMBOLS = [
@@ -79,7 +79,7 @@ def load_library():
         "tptSetRayCounter": [p], "tptSetTileMirror": [p, p], "tptSetFrameOverlap": [i], "tptDisplayRGBA8": [p, i, i, p], "tptKernelTimingBegin": [i],
         "tptKernelTimingEnd": [C.POINTER(f), C.POINTER(i)],
         "tptSynchronize": [], "tptTimerBegin": [], "tptTimerEnd": [C.POINTER(f)], "tptSetKernelVariant": [i, i, i],
-        "tptDebugStats": [p, i], "tptDebugChunkOrder": [p, p, i], "tptTestMath": [i, p, p, p, i], "tptTestMathExhaustive": [i, u, u, p, p], "tptTestHitSpheres": [i, p, p, p, i], "tptTestMatrixFilter": [p, p, p, p, i], "tptGetLaunchInfo": [C.POINTER(i)] * 4, "tptGetPipelineInfo": [C.POINTER(i)] * 4, "tptCommGetUniqueId": [p], "tptCommInit": [p, i, i, i], "tptCommInitLoopback": [i, i], "tptCommDestroy": [], "tptDrawSharded": [f, i, i, i, p, u], "tptDrawShardedBatch": [f, i, i, i, i, p, u], "tptDrawDeviceBatch": [f, i, i, i, i, p, u], "tptShardedFinish": [C.POINTER(C.c_int64)], "tptSetHostBufferMode": [i], "tptSetHostCopyThreads": [i], "tptDebugLookaheadHits": [C.POINTER(C.c_longlong)], "tptSetHostLookahead": [i], "tptSetStreamBatching": [i],
+        "tptDebugStats": [p, i], "tptDebugChunkOrder": [p, p, i], "tptTestMath": [i, p, p, p, i], "tptTestMathExhaustive": [i, u, u, p, p], "tptTestHitSpheres": [i, p, p, p, i], "tptTestMatrixFilter": [p, p, p, p, i], "tptGetLaunchInfo": [C.POINTER(i)] * 4, "tptGetPipelineInfo": [C.POINTER(i)] * 4, "tptCommGetUniqueId": [p], "tptCommInit": [p, i, i, i], "tptCommInitLoopback": [i, i], "tptCommDestroy": [], "tptDrawSharded": [f, i, i, i, p, u], "tptDrawShardedBatch": [f, i, i, i, i, p, u], "tptDrawDeviceBatch": [f, i, i, i, i, p, u], "tptShardedFinish": [C.POINTER(C.c_int64)], "tptSetHostBufferMode": [i], "tptDebugLookaheadHits": [C.POINTER(C.c_longlong)], "tptSetHostLookahead": [i], "tptSetStreamBatching": [i],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)
@@ -310,11 +310,6 @@ def sharded_finish():
 
 def set_host_buffer_mode(only_written_by_drawtest):
     _chk(load_library().tptSetHostBufferMode(1 if only_written_by_drawtest else 0), "tptSetHostBufferMode")
-
-
-def set_host_copy_threads(threads):
-    """Threads that copy between the caller's pageable image and the pinned staging buffer (1 = none, copies on the caller's memory)."""
-    _chk(load_library().tptSetHostCopyThreads(threads), "tptSetHostCopyThreads")
 
 
 def set_host_lookahead(frames):

@@ -12,7 +12,6 @@
 #include "../../include/tpt_test_api.h"
 #include "tpt_device.h"
 #include "tpt_scene.h"
-#include "tpt_hostcopy.h"
 #include <hip/hip_runtime.h>
 #include <thread>
 #include <rccl/rccl.h> // types and prototypes only: the library is dlopen()ed when tptCommInit is called
@@ -127,14 +126,6 @@ struct Context {
     // ---- host-pointer path (tptDraw / DrawTest)
     hipStream_t hostStream2 = nullptr;  // second stream of the banded upload / blend / download (full-duplex PCIe)
     hipEvent_t evBand = nullptr, evBandEnd = nullptr;
-    static const int kHostBands = 4;
-    hipEvent_t evBandDone[kHostBands] = {}; // band b's download has reached the staging buffer
-    // Staged copies (tpt_hostcopy.h): the caller's pageable image <-> hostStage (pinned) by hostCopyThreads threads, so that the
-    // upload and the download overlap on the link.  hostCopyThreads <= 1: hipMemcpyAsync on the caller's memory (one after the other).
-    int hostCopyThreads = 4;            // tptSetHostCopyThreads / env TPT_HOST_COPY_THREADS (the calling thread counts)
-    HostCopyPool* copyPool = nullptr;   // created by the first staged DrawTest, deleted by tptShutdown (raw: no destructor at exit)
-    char* hostStage = nullptr;
-    size_t hostStageCap = 0;
     int hostTrust = 0;                  // tptSetHostBufferMode(1): only DrawTest writes the backbuffer -> never re-upload it
     const float* tileSrc = nullptr;     // which host buffer (and size) the device tile g.dFrame currently mirrors
     int tileW = 0, tileH = 0;
@@ -146,9 +137,8 @@ struct Context {
         int raySlot;
         bool used;
     };
-    static const int kMaxAhead = 12;    // deepest look-ahead (tptSetHostLookahead); + this frame = 13 of the 16 trace streams
-    Ahead ahead[kMaxAhead + 1];
-    TraceTicket aheadTicket[kMaxAhead + 1];
+    Ahead ahead[4];
+    TraceTicket aheadTicket[4];
     // The same in the reference's own seed mode (one RNG stream per row, Test.cpp:280): a frame alone offers `rows` lanes of
     // work, so the frames ahead are traced as ONE batched launch (rows x frames lanes, tptDrawDeviceBatch's kernel path) with a
     // ray counter per frame, and served one by one; [0] is being served, [1] is the batch after it, launched when [0] starts.
@@ -435,25 +425,6 @@ int framesInFlight(int nOverlap) // nOverlap: frame slots in use
     return (int)(cur - g.oldestPending);
 }
 
-// Pinned staging buffer + helper threads of the staged host path; false (nothing changed) when staging is off or the pinned
-// allocation fails -- the caller then copies from / to the pageable buffer directly.
-bool ensureHostStage(size_t bytes)
-{
-    if (g.hostCopyThreads <= 1) return false;
-    if (g.hostStageCap < bytes) {
-        (void)hipStreamSynchronize(g.stream);
-        (void)hipStreamSynchronize(g.hostStream2);
-        if (g.hostStage) (void)hipHostFree(g.hostStage);
-        g.hostStage = nullptr; g.hostStageCap = 0;
-        void* p = nullptr;
-        if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return false; }
-        g.hostStage = static_cast<char*>(p); g.hostStageCap = bytes;
-    }
-    if (g.copyPool && g.copyPool->threads() != g.hostCopyThreads) { delete g.copyPool; g.copyPool = nullptr; }
-    if (!g.copyPool) g.copyPool = new HostCopyPool(g.hostCopyThreads);
-    return true;
-}
-
 // tptDraw's upload of the caller's backbuffer (previous frame's RGB, caller-owned alpha) into g.dFrame, this rank's rows
 int uploadBackbuffer(const float* backbuffer, int w, int h)
 {
@@ -575,8 +546,6 @@ int tptInitialize(void)
     HIPCHK(hipStreamCreateWithFlags(&g.hostStream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&g.evBand, kOrderingEvent));
     HIPCHK(hipEventCreateWithFlags(&g.evBandEnd, kOrderingEvent));
-    for (int b = 0; b < Context::kHostBands; ++b) HIPCHK(hipEventCreateWithFlags(&g.evBandDone[b], kOrderingEvent));
-    if (const char* ehc = getenv("TPT_HOST_COPY_THREADS")) g.hostCopyThreads = atoi(ehc) < 1 ? 1 : (atoi(ehc) > 16 ? 16 : atoi(ehc));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dRaysAhead), sizeof(unsigned long long) * Context::kMaxSlots));
     HIPCHK(hipMemsetAsync(g.dRaysAhead, 0, sizeof(unsigned long long) * Context::kMaxSlots, g.stream));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dRaysStream), sizeof(unsigned long long) * Context::kStreamRing * Context::kStreamBatchMax));
@@ -586,8 +555,8 @@ int tptInitialize(void)
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dRaysBatch), sizeof(unsigned long long) * 2 * kMaxBatch));
     HIPCHK(hipMemsetAsync(g.dRaysBatch, 0, sizeof(unsigned long long) * 2 * kMaxBatch, g.stream));
     g.rsb[0].used = g.rsb[1].used = false;
-    for (int k = 0; k <= Context::kMaxAhead; ++k) g.ahead[k].used = false;
-    if (const char* e9 = getenv("TPT_HOST_LOOKAHEAD")) g.lookahead = atoi(e9) < 0 ? 0 : (atoi(e9) > Context::kMaxAhead ? Context::kMaxAhead : atoi(e9));
+    for (int k = 0; k < 4; ++k) g.ahead[k].used = false;
+    if (const char* e9 = getenv("TPT_HOST_LOOKAHEAD")) g.lookahead = atoi(e9) < 0 ? 0 : (atoi(e9) > 3 ? 3 : atoi(e9));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dRaysOwn), 64));
     HIPCHK(hipMemsetAsync(g.dRaysOwn, 0, 64, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -663,12 +632,8 @@ int tptShutdown(void)
     if (g.hostStream2) { (void)hipStreamSynchronize(g.hostStream2); (void)hipStreamDestroy(g.hostStream2); g.hostStream2 = nullptr; }
     if (g.evBand) { (void)hipEventDestroy(g.evBand); g.evBand = nullptr; }
     if (g.evBandEnd) { (void)hipEventDestroy(g.evBandEnd); g.evBandEnd = nullptr; }
-    for (int b = 0; b < Context::kHostBands; ++b)
-        if (g.evBandDone[b]) { (void)hipEventDestroy(g.evBandDone[b]); g.evBandDone[b] = nullptr; }
-    delete g.copyPool; g.copyPool = nullptr;
-    if (g.hostStage) { (void)hipHostFree(g.hostStage); g.hostStage = nullptr; g.hostStageCap = 0; }
     g.tileSrc = nullptr; g.tileW = g.tileH = 0;
-    for (int k = 0; k <= Context::kMaxAhead; ++k) g.ahead[k].used = false;
+    for (int k = 0; k < 4; ++k) g.ahead[k].used = false;
     (void)hipFree(g.dRaysAhead); g.dRaysAhead = nullptr;
     (void)hipFree(g.dRaysBatch); g.dRaysBatch = nullptr;
     (void)hipFree(g.dRaysStream); g.dRaysStream = nullptr;
@@ -1205,7 +1170,7 @@ namespace {
 
 // First half of a frame: plan, buffers, trace kernel on the slot's stream.  `frameRays`: where the kernel adds its ray
 // count (the context's counter, or a per-slot one for frames that are traced ahead of their DrawTest call).
-int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long long* frameRays, TraceTicket& T, int batch = 1, int rayStride = 0, int slotCap = 0)
+int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long long* frameRays, TraceTicket& T, int batch = 1, int rayStride = 0)
 {
     if (g.sceneDirty || (g.curSet < 0 && g.pendingSet < 0)) { // tptSetScene after the last tptUpdate
         int rc = stageScene();
@@ -1251,7 +1216,7 @@ int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long
     if (colourBytesPerSlot > (4ull << 30))
         return fail("tptDrawDeviceBatch: " + std::to_string(colourBytesPerSlot >> 20) + " MiB of frame colour per launch (rows x width x 16 B x frames): over the 4096 MiB limit, use a smaller batch");
     while (P.nSlots > 2 && colourBytesPerSlot * (size_t)P.nSlots > (8ull << 30)) P.nSlots /= 2;
-    if (slotCap > 0 && P.nSlots > slotCap) P.nSlots = slotCap; // (the host path's look-ahead batches: two alive at a time, four slots)
+    if (rayStride > 0 && g.seedMode == SEED_ROW_SERIAL && P.nSlots > 4) P.nSlots = 4; // (the host path's row-serial batches: two alive at a time)
     if (P.nOverlap > P.nSlots) P.nOverlap = P.nSlots;
     P.slot = (int)(g.frameSeq % (unsigned long long)P.nSlots);
     g.frameSeq++;
@@ -1416,7 +1381,7 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
     }
     // one frame more than the host-pointer path looks ahead: there the PCIe copies fill the caller's time (2 ahead: 0.88 ms
     // per frame, 3: 0.92), here nothing does (2: 0.598 ms, 3: 0.561; profiles/r02/r02_run50.log)
-    const int devAhead = g.lookahead + 1 < Context::kMaxAhead ? g.lookahead + 1 : Context::kMaxAhead;
+    const int devAhead = g.lookahead + 1 < 3 ? g.lookahead + 1 : 3;
     struct DepthScope { // launches made from here share the machine with the frames traced ahead, not with a deep pipeline
         explicit DepthScope(int d) { g.depthOverride = d; }
         ~DepthScope() { g.depthOverride = 0; }
@@ -1521,10 +1486,10 @@ int discardLookahead()
 {
     g.sbatch.used = false; // (an open stream batch needs no wait: its unserved planes are simply never blended)
     bool any = g.rsb[0].used || g.rsb[1].used;
-    for (int k = 0; k <= Context::kMaxAhead; ++k) any = any || g.ahead[k].used;
+    for (int k = 0; k < 4; ++k) any = any || g.ahead[k].used;
     if (!any) return 0;
     for (int k = 0; k < Context::kMaxOverlap; ++k) HIPCHK(hipStreamSynchronize(g.traceStream[k]));
-    for (int k = 0; k <= Context::kMaxAhead; ++k) g.ahead[k].used = false;
+    for (int k = 0; k < 4; ++k) g.ahead[k].used = false;
     g.rsb[0].used = g.rsb[1].used = false;
     g.sbatch.used = false;
     return 0;
@@ -1536,8 +1501,8 @@ int takeAhead(TraceTicket& T, int& raySlot)
     g.aheadHits++;
     T = g.aheadTicket[0];
     raySlot = g.ahead[0].raySlot;
-    for (int k = 0; k < Context::kMaxAhead; ++k) { g.ahead[k] = g.ahead[k + 1]; g.aheadTicket[k] = g.aheadTicket[k + 1]; }
-    g.ahead[Context::kMaxAhead].used = false;
+    for (int k = 0; k + 1 < 4; ++k) { g.ahead[k] = g.ahead[k + 1]; g.aheadTicket[k] = g.aheadTicket[k + 1]; }
+    g.ahead[3].used = false;
     return 0;
 }
 
@@ -1547,7 +1512,7 @@ int takeAhead(TraceTicket& T, int& raySlot)
 int traceAhead(int frameCount, int w, int h, unsigned testFlags, unsigned long long key, int want)
 {
     int have = 0;
-    while (have < Context::kMaxAhead && g.ahead[have].used) ++have;
+    while (have < 4 && g.ahead[have].used) ++have;
     int nextFrame = have ? g.ahead[have - 1].frameCount + 1 : frameCount + 1;
     // every frame traced but not yet blended holds a slot (its colour buffer): this one plus the ones ahead must leave one
     // slot spare, whatever the hardware-queue probe clamped the pipeline to
@@ -1571,13 +1536,6 @@ int traceAhead(int frameCount, int w, int h, unsigned testFlags, unsigned long l
 
 extern "C" {
 
-int tptSetHostCopyThreads(int threads)
-{
-    if (threads < 1 || threads > 16) return fail("tptSetHostCopyThreads: 1 (no helper threads, no staging) .. 16");
-    g.hostCopyThreads = threads; // (the pool is rebuilt by the next staged DrawTest)
-    return 0;
-}
-
 int tptSetHostBufferMode(int hostBufferOnlyWrittenByDrawTest)
 {
     g.hostTrust = hostBufferOnlyWrittenByDrawTest ? 1 : 0;
@@ -1596,7 +1554,7 @@ int tptSetStreamBatching(int enable)
 
 int tptSetHostLookahead(int frames)
 {
-    if (frames < 0 || frames > Context::kMaxAhead) return fail("tptSetHostLookahead: 0..12");
+    if (frames < 0 || frames > 3) return fail("tptSetHostLookahead: 0..3");
     if (g.inited) {
         int rc = discardLookahead();
         if (rc) return rc;
@@ -1636,51 +1594,39 @@ int tptDraw(float time, int frameCount, int w, int h, float* backbuffer, int* ou
     struct DepthScope { // launches made from here share the machine with the frames traced ahead, not with a deep device-path pipeline
         explicit DepthScope(int d) { g.depthOverride = d; }
         ~DepthScope() { g.depthOverride = 0; }
-    } depthScope(pipelined && stable ? 1 + g.lookahead : 1);
+    } depthScope(pipelined && stable ? 1 + (g.lookahead < 3 ? g.lookahead : 3) : 1);
     TraceTicket T;
     int raySlot = -1;
     const unsigned long long* rayPtr = nullptr;
     bool servedFromBatch = false;
-    // ---- 1b. look-ahead in BATCHES: this frame and the ones after it as one launch, served one by one; the batch after that
-    //          one is launched as soon as this one starts being served (a wrong guess costs GPU time only).
-    //          Row-serial seeds (the reference's own) only: 32 frames per launch -- a frame alone offers `rows` lanes of work.
-    //          (Per-pixel seeds were tried the same way, 4 frames per launch at 1280x720x4: a lone launch, however large, runs at
-    //          half the streaming rate -- 0.60 ms per frame against 0.51 for single frames three deep; the path-queue kernel needs
-    //          MANY launches side by side, so those frames are traced ahead one launch each, deeper: tptSetHostLookahead.
-    //          profiles/r03/r03_hostbatch.log)
-    int batchN = 0;
-    const bool rowSerialBatches = g.seedMode == SEED_ROW_SERIAL;
-    if (stable && pipelined && !sharded && g.lookahead > 0 && rows > 0 && !g.mirror) {
-        if (rowSerialBatches) {
-            batchN = kMaxBatch;
-        }
-    }
-    auto batchMatches = [&](const Context::RowSerialBatch& B) {
-        return B.used && B.n == batchN && B.w == w && B.h == h && B.flags == testFlags && B.key == key && frameCount == B.firstFrame + B.next;
-    };
-    auto launchBatch = [&](int which, int firstFrame) -> int {
-        Context::RowSerialBatch& B = g.rsb[which];
-        B.used = false;
-        B.firstFrame = firstFrame; B.n = batchN; B.next = 0; B.w = w; B.h = h; B.flags = testFlags; B.key = key;
-        // (two banks of per-frame counters; the batch being served keeps its bank when it moves from [1] to [0])
-        B.counterBase = (which == 1 && g.rsb[0].used && g.rsb[0].counterBase == 0) ? kMaxBatch : 0;
-        int rc = enqueueTrace(firstFrame, w, h, testFlags, g.dRaysBatch + B.counterBase, B.T, B.n, 1, 4);
-        if (rc) return rc;
-        B.used = B.T.valid;
-        return 0;
-    };
-    if (batchN) {
-        if (!batchMatches(g.rsb[0])) {
+    if (g.seedMode == SEED_ROW_SERIAL && stable && pipelined && !sharded && g.lookahead > 0 && rows > 0 && !g.mirror) {
+        // ---- 1r. the reference's own seed mode: this frame and the 31 after it as ONE launch (rows x frames lanes), the batch
+        //          after that one launched as soon as this one starts being served (a wrong guess costs GPU time only)
+        auto matches = [&](const Context::RowSerialBatch& B) {
+            return B.used && B.w == w && B.h == h && B.flags == testFlags && B.key == key && frameCount == B.firstFrame + B.next;
+        };
+        auto launch = [&](int which, int firstFrame) -> int {
+            Context::RowSerialBatch& B = g.rsb[which];
+            B.used = false;
+            B.firstFrame = firstFrame; B.n = kMaxBatch; B.next = 0; B.w = w; B.h = h; B.flags = testFlags; B.key = key;
+            // (two banks of per-frame counters; the batch being served keeps its bank when it moves from [1] to [0])
+            B.counterBase = (which == 1 && g.rsb[0].used && g.rsb[0].counterBase == 0) ? kMaxBatch : 0;
+            int rc = enqueueTrace(firstFrame, w, h, testFlags, g.dRaysBatch + B.counterBase, B.T, B.n, 1);
+            if (rc) return rc;
+            B.used = B.T.valid;
+            return 0;
+        };
+        if (!matches(g.rsb[0])) {
             int rc = discardLookahead();
             if (rc) return rc;
-            if ((rc = launchBatch(0, frameCount))) return rc;
+            if ((rc = launch(0, frameCount))) return rc;
         } else {
             g.aheadHits++;
         }
         Context::RowSerialBatch& B = g.rsb[0];
         if (B.used) {
             if (B.next == 0 && !g.rsb[1].used) {
-                int rc = launchBatch(1, B.firstFrame + B.n);
+                int rc = launch(1, B.firstFrame + B.n);
                 if (rc) return rc;
             }
             const int j = B.next;
@@ -1721,14 +1667,14 @@ int tptDraw(float time, int frameCount, int w, int h, float* backbuffer, int* ou
     const bool upload = rows > 0 && !(g.hostTrust && g.tileSrc == backbuffer && g.tileW == w && g.tileH == h && frameCount != 0);
     if (upload) { g.tileSrc = backbuffer; g.tileW = w; g.tileH = h; }
     if (upload && !sharded && T.valid && T.pipelined && rows >= 64 && !g.mirror) {
-        // Banded: rows in four bands, alternating between two streams, each band upload -> blend -> download.  PCIe is
-        // full duplex, but a copy from / to PAGEABLE memory does not return before it is done, so on the caller's buffer the
-        // copies run one after the other (2 x 0.27 ms for C2).  Staged (default): helper threads copy each band into pinned
-        // memory, the DMA engines take it from there, and one band's download crosses while the next band's upload does;
-        // the bands are copied out to the caller's buffer as they land.  (Page-locking the CALLER's memory is not ours to
-        // do -- it may be freed between calls.)
-        const int kBands = Context::kHostBands;
-        const bool staged = ensureHostStage(rowBytes * (size_t)rows);
+        // Banded: rows in four bands, alternating between two streams, each band upload -> blend -> download, so that a
+        // band's blend and download do not wait for the whole upload.  The caller's buffer is pageable (page-locking the
+        // CALLER's memory is not ours to do -- it may be freed between calls), and a copy on pageable memory does not return
+        // before it is done: the two directions do NOT overlap on the link (profiles/r03/r03_h2d_probe.log: 0.27-0.30 ms each
+        // way at 50-55 GB/s, 0.28 ms for half up + half down "at once").  Going through a pinned staging buffer filled and
+        // emptied by helper threads does overlap them and was tried in round 3: 0.74-0.78 instead of 0.80 ms per frame in a
+        // plain process, 0.97-1.07 instead of 0.81 in one whose HIP context torch had initialised -- dropped.
+        const int kBands = 4;
         HIPCHK(hipEventRecord(g.evBand, g.stream)); // (orders stream 2 behind everything earlier on g.stream)
         HIPCHK(hipStreamWaitEvent(g.hostStream2, g.evBand, 0));
         // Trace still running (nothing was traced ahead)?  Then all uploads go first, beside it; otherwise they are interleaved
@@ -1743,19 +1689,13 @@ int tptDraw(float time, int frameCount, int w, int h, float* backbuffer, int* ou
         for (int pass = 0; pass < 2; ++pass) {
             for (int b = 0; b < kBands; ++b) {
                 const int r0 = (int)((long long)rows * b / kBands), r1 = (int)((long long)rows * (b + 1) / kBands);
-                const size_t bandBytes = rowBytes * (size_t)(r1 - r0);
                 hipStream_t st = (b & 1) ? g.hostStream2 : g.stream;
                 char* hb = reinterpret_cast<char*>(backbuffer) + rowBytes * r0;
-                char* sb = staged ? g.hostStage + rowBytes * r0 : hb; // what the DMA engines read and write
                 float* db = g.dFrame + (size_t)r0 * w * 4;
-                if (pass == 0) {
-                    if (staged) g.copyPool->copy(sb, hb, bandBytes);
-                    HIPCHK(hipMemcpyAsync(db, sb, bandBytes, hipMemcpyHostToDevice, st));
-                }
+                if (pass == 0) HIPCHK(hipMemcpyAsync(db, hb, rowBytes * (size_t)(r1 - r0), hipMemcpyHostToDevice, st));
                 if (pass == 0 && !traceDone) continue;
                 HIPCHK(tptLaunchResolve(db, T.colour + (size_t)r0 * w, (r1 - r0) * w, T.lerpFac, nullptr, g.dRays, nullptr, b == 0 ? rayPtr : nullptr, st));
-                HIPCHK(hipMemcpyAsync(sb, db, bandBytes, hipMemcpyDeviceToHost, st)); // (same stream as the band's upload: the staging rows are free)
-                if (staged) HIPCHK(hipEventRecord(g.evBandDone[b], st));
+                HIPCHK(hipMemcpyAsync(hb, db, rowBytes * (size_t)(r1 - r0), hipMemcpyDeviceToHost, st));
             }
             if (traceDone) break;
             if (pass == 0) { // uploads are on their way: now the blends wait for the trace
@@ -1767,13 +1707,6 @@ int tptDraw(float time, int frameCount, int w, int h, float* backbuffer, int* ou
         HIPCHK(hipStreamWaitEvent(g.stream, g.evBandEnd, 0));
         HIPCHK(hipEventRecord(g.evResolve[T.slot], g.stream));
         g.resolveRecorded[T.slot] = true;
-        if (staged) {
-            for (int b = 0; b < kBands; ++b) { // the bands as they land: staging -> the caller's buffer
-                const int r0 = (int)((long long)rows * b / kBands), r1 = (int)((long long)rows * (b + 1) / kBands);
-                HIPCHK(hipEventSynchronize(g.evBandDone[b]));
-                g.copyPool->copy(reinterpret_cast<char*>(backbuffer) + rowBytes * r0, g.hostStage + rowBytes * r0, rowBytes * (size_t)(r1 - r0));
-            }
-        }
     } else {
         if (upload) {
             int rc = uploadBackbuffer(backbuffer, w, h);

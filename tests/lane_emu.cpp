@@ -118,6 +118,25 @@ void emu_group_info(const void* spheres, const void* mats, int count, int* out3)
 float emu_sinf(float x) { return tsinf(x); }
 float emu_cosf(float x) { return tcosf(x); }
 float emu_pow5f(float x) { return tpow5f(x); }
+// tsincosf (one evaluation of each polynomial, signs applied to the binary32 results) against tsinf / tcosf (glibc's branch
+// structure) for every float whose bit pattern lies in [loBits, hiBits], both signs: number of arguments whose sine or cosine differ
+long long emu_sincos_pair_mismatches(unsigned loBits, unsigned hiBits, float* firstBad)
+{
+    long long bad = 0;
+    for (unsigned long long b = loBits; b <= hiBits; ++b) {
+        for (unsigned sgn = 0; sgn < 2; ++sgn) {
+            const float y = u2f((uint32_t)b | (sgn << 31));
+            float sn, cs;
+            tsincosf(y, sn, cs);
+            if (f2u(sn) != f2u(tsinf(y)) || f2u(cs) != f2u(tcosf(y))) {
+                if (!bad && firstBad) *firstBad = y;
+                ++bad;
+            }
+        }
+    }
+    return bad;
+}
+void emu_sincos_pair(float y, float* outSin, float* outCos) { tsincosf(y, *outSin, *outCos); }
 
 // HitSpheres alone: n rays [n][6] = origin, unit direction; hs as tptSetKernelVariant numbers it: 0 = the product's default
 // (conservative filter + exact test: matrix-core filter's restatement for scenes with a table, groups for large scenes),

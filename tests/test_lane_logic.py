@@ -71,6 +71,30 @@ def test_device_math_mirror_equals_oracle_math(emu, oracle):
         assert emu.emu_pow5f(x) == oracle.lib.tpto_pow5f(x)
 
 
+def test_sincos_pair_all_floats(emu, oracle):
+    """tsincosf -- the pair the path calls: each of glibc's two polynomials evaluated once on unsigned operands, signs applied
+    to the binary32 results, swapped by the quadrant's parity -- returns the bits of tsinf / tcosf (glibc's own branch
+    structure, pinned to libm on the oracle side) for EVERY float with |y| <= 120, both signs (2.2e9 arguments; the path's
+    angles are 2 pi u, u = k / 2^24).  Pure IEEE binary64 / binary32 operations, no contraction: what holds here holds on the
+    device (which repeats the path's 2^24 arguments in test_gpu_math.py)."""
+    import ctypes as C
+    emu.emu_sincos_pair_mismatches.restype = C.c_longlong
+    emu.emu_sincos_pair_mismatches.argtypes = [C.c_uint, C.c_uint, C.POINTER(C.c_float)]
+    first = C.c_float(0)
+    hi = int(np.float32(120.0).view(np.uint32))
+    bad = emu.emu_sincos_pair_mismatches(0, hi, C.byref(first))
+    assert bad == 0, (bad, first.value)
+    # and against the oracle's own sinf / cosf (libm's bits) on the path's call forms
+    emu.emu_sincos_pair.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    sn, cs = C.c_float(), C.c_float()
+    rng = np.random.default_rng(2)
+    for r in list(rng.integers(0, 1 << 24, 20000)) + [0, 1, 2, (1 << 24) - 1, 1 << 21, 1 << 22, 1 << 23, 3 << 22]:
+        for a in (np.float32(r) / np.float32(16777216.0) * np.float32(2.0) * np.float32(3.1415926),
+                  np.float32(2.0) * np.float32(3.1415926) * (np.float32(r) / np.float32(16777216.0))):
+            emu.emu_sincos_pair(a, C.byref(sn), C.byref(cs))
+            assert sn.value == oracle.lib.tpto_sinf(a) and cs.value == oracle.lib.tpto_cosf(a), a
+
+
 def test_two_phase_filter_is_conservative_on_grazing_rays(emu, oracle):
     """Phase 1 of the two-phase HitSpheres is a cheaper, conservative filter (FMA chains + margin); phase 2 is the
     reference's exact arithmetic.  On rays that graze a sphere within 1e-8..1e-3 radii the two-phase result must equal

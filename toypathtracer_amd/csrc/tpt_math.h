@@ -219,7 +219,6 @@ TPT_HD float tcosf(float y)
 // returns the same bits as sinf/cosf).
 TPT_HD void tsincosf(float y, float& outSin, float& outCos)
 {
-    double x = y;
     if (abstop12(y) < abstop12(0x1p-12f)) {
         outSin = y;
         outCos = 1.0f;
@@ -227,15 +226,49 @@ TPT_HD void tsincosf(float y, float& outSin, float& outCos)
     }
     // glibc branches on |y| < pi/4 to skip the argument reduction; the reduction of such an argument is the identity (n = 0,
     // x - 0 * pi/2 = x, sign +1, same polynomials on the same x and x^2), so ONE path serves both and a wave whose lanes
-    // straddle pi/4 -- nearly every wave: the angle is uniform in [0, 2 pi) -- no longer runs the polynomials twice.  Same bits:
-    // test_gpu_math.py::test_sincos_pair_equals_sinf_cosf_on_the_whole_path_domain (all 2^24 arguments of both call forms).
-    int n;
-    x = reduce_fast(x, n);
-    double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
-    double xs = x * s, x2 = x * x;
-    bool neg = (n & 2) != 0;
-    outSin = sincos_poly(xs, x2, neg, n);
-    outCos = sincos_poly(xs, x2, neg, n ^ 1);
+    // straddle pi/4 -- nearly every wave: the angle is uniform in [0, 2 pi) -- no longer runs the polynomials twice.
+    //
+    // Each polynomial is evaluated ONCE, on the unsigned operands, and the signs are applied to the binary32 results:
+    //  * sinf_poly is odd in x and cosf_poly's sign factor multiplies every coefficient, so flipping the sign of the input
+    //    (sine) or of all coefficients (cosine) flips the sign of every intermediate -- products, fmas and the final
+    //    conversion round to nearest, which is symmetric -- and the result is the negated result, bit for bit;
+    //  * sin and cos of the pair take the two polynomials on the same (x, x^2): which one is the sine depends on the
+    //    quadrant's parity, so both are computed and swapped (written as two calls the compiler evaluated each polynomial
+    //    in both branches of every wave: 31 binary64 operations per pair, now 14).
+    // Same bits: tests/test_lane_logic.py::test_sincos_pair_all_floats (every float with |y| < 120 against tsinf / tcosf on the
+    // host) and test_gpu_math.py::test_sincos_pair_equals_sinf_cosf_on_the_whole_path_domain (all 2^24 arguments of both
+    // call forms on the device).
+    const double HPI_INV = 0x1.45F306DC9C883p+23, HPI = 0x1.921FB54442D18p0;
+    const double x0 = y;
+    const double r = x0 * HPI_INV;
+    const int32_t q = (int32_t)r + 0x800000;
+    const int n = q >> 24;
+    const double x = dfma(-(double)n, HPI, x0);
+    const double x2 = x * x;
+    // sinf_poly(x, n even)
+    const double S1 = -0x1.555545995a603p-3, S2 = 0x1.1107605230bc4p-7, S3 = -0x1.994eb3774cf24p-13;
+    const double x3 = x * x2;
+    const double s1 = dfma(x2, S3, S2);
+    const double x7 = x3 * x2;
+    const double sp = dfma(x3, S1, x);
+    const float sinPoly = (float)dfma(x7, s1, sp);
+    // cosf_poly (n odd), sign factor +1
+    const double C0 = 1.0, C1 = -0x1.ffffffd0c621cp-2, C2 = 0x1.55553e1068f19p-5, C3 = -0x1.6c087e89a359dp-10,
+                 C4 = 0x1.99343027bf8c3p-16;
+    const double x4 = x2 * x2;
+    const double c2 = dfma(x2, C4, C3);
+    const double c1 = dfma(x2, C1, C0);
+    const double x6 = x4 * x2;
+    const double cp = dfma(x4, C2, c1);
+    const float cosPoly = (float)dfma(x6, c2, cp);
+    // signs: the sine polynomial's argument is x * s with s = -1 in quadrants 1 and 2 (n & 3), the cosine polynomial's
+    // factor is -1 when n & 2; the quadrant's parity says which polynomial is the sine
+    const uint32_t sinFlip = (((uint32_t)n + 1u) & 2u) << 30; // n & 3 in {1, 2}
+    const uint32_t cosFlip = ((uint32_t)n & 2u) << 30;
+    const float a = u2f(f2u(sinPoly) ^ sinFlip), b = u2f(f2u(cosPoly) ^ cosFlip);
+    const bool odd = (n & 1) != 0;
+    outSin = odd ? b : a;
+    outCos = odd ? a : b;
 }
 
 // ---------------------------------------------------------------- powf(x, 5.0f)

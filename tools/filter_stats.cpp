@@ -112,6 +112,23 @@ int main(int argc, char** argv)
                 mxp = A.perRayPlane[idx] > mxp ? A.perRayPlane[idx] : mxp; mxb = A.perRayBehind[idx] > mxb ? A.perRayBehind[idx] : mxb; }
             tripsMs += mxm; tripsEs += mxe; tripsPs += mxp; tripsBs += mxb; groupsS++;
         }
+        {   // rays binned by candidate count before they are intersected (0 / 1 / 2 / 3+): waves of one bin, arrival order within
+            long long trips = 0, n64 = 0, cntBin[4] = {};
+            for (int bin = 0; bin < 4; ++bin) {
+                int fill = 0, mx = 0;
+                for (size_t i = 0; i < A.perRayMatrix.size(); ++i) {
+                    const int c = A.perRayMatrix[i];
+                    if ((c < 3 ? c : 3) != bin) continue;
+                    cntBin[bin]++;
+                    mx = c > mx ? c : mx;
+                    if (++fill == 64) { trips += mx; n64++; fill = 0; mx = 0; }
+                }
+                if (fill) { trips += mx; n64++; }
+            }
+            printf("    binned by candidate count (0 / 1 / 2 / 3+: %.1f / %.1f / %.1f / %.1f %% of the rays): %.2f trips per 64 rays\n",
+                   100.0 * cntBin[0] / A.rays, 100.0 * cntBin[1] / A.rays, 100.0 * cntBin[2] / A.rays, 100.0 * cntBin[3] / A.rays,
+                   (double)trips * 64.0 / A.rays);
+        }
         if (groups)
             printf("    phase-2 trips per 64 rays (largest count in the group): coherent groups %.2f (an exact filter: %.2f), scattered groups %.2f (exact: %.2f)\n"
                    "    with the plane cull: coherent %.2f scattered %.2f; with the behind-the-origin cull: coherent %.2f scattered %.2f\n",

@@ -378,6 +378,7 @@ def test_tile_mirror_snapshot(tpt_defaults, oracle):
     tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
     torch.cuda.synchronize()  # the fill runs on torch's stream; the library's streams do not wait for it
     mirrors = [torch.full((h + 1, w, 4), -1.0, dtype=torch.float32, device="cuda") for _ in range(3)]
+    torch.cuda.synchronize()  # (same for these fills)
     r0 = tpt.ray_counter_read()
     for f in range(frames):
         mbuf = mirrors[f % 3]

@@ -121,7 +121,7 @@ def cpu_baseline(width, height, spp, budget_s=5.0):
                 sample="%d frames of %dx%dx%dspp, oracle/tpt_oracle.c (OpenMP over rows), %.1f s" % (frames, width, height, spp, dt))
 
 
-def image_parity(image, rays_total, width, height, spp, frames, max_frames=64):
+def image_parity(image, rays_total, width, height, spp, frames, max_frames=64, max_samples=1.6e8):
     """Checker leg (untimed, never the product path): the final image of the run that was just timed -- every frame from
     frame 0 on a zeroed tile -- against the oracle's PER_PIXEL render of the same frames, byte for byte, ray totals equal.
     -> dict for the JSON line."""
@@ -129,8 +129,9 @@ def image_parity(image, rays_total, width, height, spp, frames, max_frames=64):
     from oracle_lib import SEED_PER_PIXEL, Oracle, fnv1a
     img = np.ascontiguousarray(image.detach().cpu().numpy() if hasattr(image, "detach") else image, np.float32)
     out = {"image_fnv": "%08x" % fnv1a(img), "parity_checked": False}
-    if frames > max_frames:
-        out["parity_note"] = "run of %d frames: the oracle leg is bounded to %d (use --parity-frames to raise it)" % (frames, max_frames)
+    if frames > max_frames or float(frames) * width * height * spp > max_samples:
+        out["parity_note"] = ("run of %d frames = %.3g camera samples: the oracle leg is bounded to %d frames and %.3g samples "
+                              "(--parity-frames / --parity-samples raise it)" % (frames, float(frames) * width * height * spp, max_frames, max_samples))
         return out
     t0 = time.perf_counter()
     ro, bo = Oracle.get().render_frames(width, height, spp, frames, seed_mode=SEED_PER_PIXEL)
@@ -166,8 +167,7 @@ def drawtest_host_path(api, width, height, frames=24):
 
 def batched_rate(api, torch, width, height, per_launch=8, launches=25):
     """tptDrawDeviceBatch: `per_launch` frames of the static scene per launch (same bits as one launch per frame)."""
-    tile = torch.zeros((height, width, 4), dtype=torch.float32, device="cuda")
-    torch.cuda.synchronize()
+    tile = torch.zeros((height, width, 4), dtype=torch.float32, device="cuda")  # (default-stream fill: the library's own stream is ordered behind it)
     api.UpdateTest(0.0, 0, width, height, FLAG_PROGRESSIVE)
     f = 0
     for _ in range(16):
@@ -186,8 +186,7 @@ def batched_rate(api, torch, width, height, per_launch=8, launches=25):
 def sync_caller_rate(api, torch, width, height, frames=60):
     """tptDrawDevice on a device tile with a synchronise after every frame: the reference's synchronous DrawTest contract
     without the PCIe copies (the library traces the next frames ahead of such a caller)."""
-    tile = torch.zeros((height, width, 4), dtype=torch.float32, device="cuda")
-    torch.cuda.synchronize()
+    tile = torch.zeros((height, width, 4), dtype=torch.float32, device="cuda")  # (default-stream fill: the library's own stream is ordered behind it)
     for f in range(8):
         api.UpdateTest(0.0, f, width, height, FLAG_PROGRESSIVE)
         api.draw_device(0.0, f, width, height, tile.data_ptr(), FLAG_PROGRESSIVE)
@@ -210,11 +209,12 @@ def row_serial_rate(api, width, height, frames=96):
     exact image (one RNG stream per row; the library traces the next 32 frames of a static scene ahead as one launch)."""
     api.set_seed_mode(0)
     bb = np.zeros((height, width, 4), np.float32)
-    api.UpdateTest(0.0, 0, width, height, FLAG_PROGRESSIVE)
-    api.DrawTest(0.0, 0, width, height, bb, FLAG_PROGRESSIVE)
+    for f in range(3):  # untimed: the library launches its 32-frame batches for a caller that has shown three consecutive frames
+        api.UpdateTest(0.0, f, width, height, FLAG_PROGRESSIVE)
+        api.DrawTest(0.0, f, width, height, bb, FLAG_PROGRESSIVE)
     drain_lookahead(api)
     rays, t0 = 0, time.perf_counter()
-    for f in range(1, 1 + frames):
+    for f in range(3, 3 + frames):
         api.UpdateTest(0.0, f, width, height, FLAG_PROGRESSIVE)
         rays += api.DrawTest(0.0, f, width, height, bb, FLAG_PROGRESSIVE)
     drain_lookahead(api)
@@ -227,8 +227,7 @@ def row_serial_batched_rate(api, torch, width, height, per_launch=32, launches=8
     """ROW_SERIAL seeds through tptDrawDeviceBatch: per_launch frames x rows lanes per launch (rows AND frames are independent
     RNG streams in the reference, Test.cpp:280) -- the reference's exact image, bit for bit, at GPU speed."""
     api.set_seed_mode(0)
-    tile = torch.zeros((height, width, 4), dtype=torch.float32, device="cuda")
-    torch.cuda.synchronize()
+    tile = torch.zeros((height, width, 4), dtype=torch.float32, device="cuda")  # (default-stream fill: the library's own stream is ordered behind it)
     api.UpdateTest(0.0, 0, width, height, FLAG_PROGRESSIVE)
     api.draw_device_batch(0.0, 0, per_launch, width, height, tile.data_ptr(), FLAG_PROGRESSIVE)
     r0 = api.ray_counter_read()  # synchronises
@@ -252,6 +251,7 @@ def main():
     ap.add_argument("--stripe-rows", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the host-pointer DrawTest and ROW_SERIAL legs after the timed region")
+    ap.add_argument("--extras", default="host,sync,batched,row_serial", help="which secondary legs run after the timed region (comma list of host, sync, batched, row_serial)")
     ap.add_argument("--hit-spheres", type=int, default=0, help="0 two-phase: matrix-core filter for <= 64 spheres, grouped traversal for >= 256 (default); 1 simple loop; 2 two-phase brute force; 3 as 0 with the packed VALU filter instead of the matrix-core one")
     ap.add_argument("--persistent", type=int, default=3, choices=[1, 3], help="3 path queues (default) 1 persistent waves with lane refill (the fallback kernel)")
     ap.add_argument("--fold", type=int, default=0, help="0 recursive (reference order, default) 1 forward")
@@ -270,6 +270,9 @@ def main():
                          "tptShardedFinish, what a C++ Test.h host uses; default for N > 1), torch = toypathtracer_amd/sharding.py over "
                          "torch.distributed, none = no exchange (default for N = 1: plain tptDrawDevice)")
     ap.add_argument("--parity-frames", type=int, default=64, help="check the final image against the oracle when the run has at most this many frames (0 = never)")
+    ap.add_argument("--parity-samples", type=float, default=1.6e8,
+                    help="... and at most this many camera samples in total (frames x width x height x spp): bounds the oracle leg to ~10 s "
+                         "of the host's cores -- 41 frames of configs[1], ONE frame of configs[2] (--workload c3 --prime 0 --warmup 0 --steps 1)")
     ap.add_argument("--prime", type=int, default=-1,
                     help="untimed frames rendered BEFORE the warm-up so that the frame pipeline (buffers of all slots, the library's "
                          "estimate of how deep this caller pipelines) is in its steady state when warm-up and timing start; "
@@ -320,6 +323,7 @@ def main():
     if exchange == "none" and world > 1:
         sys.exit("--exchange none needs --gpus 1")
     flags = FLAG_PROGRESSIVE | (FLAG_ANIMATE if args.animate else 0)
+    rccl_ranks = 0
     sf = None
     image_on_root = None
     if exchange == "cabi":
@@ -328,8 +332,9 @@ def main():
         if dist is not None:
             dist.broadcast_object_list(uid, src=0, device=device)
         api.comm_init(uid[0], world, rank, args.stripe_rows)
-        image_on_root = torch.zeros((height, width, 4), dtype=torch.float32, device=device)
-        torch.cuda.synchronize()  # (the fill ran on torch's stream; the library's streams do not wait for it)
+        rccl_ranks, rccl_rank, _lb = api.comm_info()  # what RCCL itself says (ncclCommCount / ncclCommUserRank), not the arguments above
+        assert (rccl_ranks, rccl_rank) == (world, rank), ("communicator of %d ranks, this is rank %d; expected %d / %d" % (rccl_ranks, rccl_rank, world, rank))
+        image_on_root = torch.zeros((height, width, 4), dtype=torch.float32, device=device)  # (filled on torch's default stream: the library's ordered streams wait for it)
         img_ptr = image_on_root.data_ptr()
 
         def step(frame):
@@ -459,7 +464,7 @@ def main():
             "metric": "Mray/s", "value": rays_total / dt / 1e6, "unit": "Mray/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "exchange": exchange, "rccl_ranks": world if exchange != "none" else 0,
+            "exchange": exchange, "rccl_ranks": rccl_ranks if exchange == "cabi" else (world if exchange == "torch" else 0),
             "config": {"workload": label, "width": width, "height": height, "spp": spp, "spheres": n_spheres,
                        "seed_mode": "per_pixel", "fold": "forward" if args.fold else "recursive",
                        "hit_spheres": ["two_phase" + ("+groups" if n_spheres >= 256 else "+matrix_core_filter" if n_spheres <= 64 else ""), "simple", "two_phase_brute_force", "two_phase_valu_filter"][args.hit_spheres], "kernel": {1: "persistent_waves", 3: "path_queues"}[args.persistent], "frame_overlap": args.overlap, "frames_per_launch": frames_per_launch,
@@ -497,32 +502,34 @@ def main():
         }
         total_frames = args.prime + args.warmup + args.steps
         if scene == "default" and not args.animate and args.parity_frames > 0:
-            out.update(image_parity(image, rays_all_frames, width, height, spp, total_frames, args.parity_frames))
+            out.update(image_parity(image, rays_all_frames, width, height, spp, total_frames, args.parity_frames, args.parity_samples))
         else:
             out.update(parity_checked=False, parity_note="oracle leg runs for the static default scene only (this workload's parity: tests/test_gpu_parity.py)")
-        if world == 1 and exchange != "cabi" and not args.no_extras:
+        extras = set() if args.no_extras else set(x for x in args.extras.split(",") if x)
+        if world == 1 and exchange != "cabi" and extras:
             # the same workload through the reference's own contract (host backbuffer, synchronous) and in its own seed mode
             api.set_ray_counter(None)
             api.set_stream(None)
             api.set_tile_mirror(None)
             api.set_row_shard(0, 1, 0)
-            ms, mr = drawtest_host_path(api, width, height)
-            out["drawtest_host_ms"], out["drawtest_host_Mray_s"] = ms, mr
-            out["drawtest_host_note"] = ("synchronous DrawTest(host float* backbuffer) per frame, the reference's own calling contract: backbuffer "
-                                         "upload + blend + download over PCIe in every call (default host-buffer mode), the next two frames "
-                                         "traced ahead of the caller (tptSetHostLookahead); never the headline value")
-            if not args.animate and width * height <= 1280 * 720:
+            if "host" in extras:
+                ms, mr = drawtest_host_path(api, width, height)
+                out["drawtest_host_ms"], out["drawtest_host_Mray_s"] = ms, mr
+                out["drawtest_host_note"] = ("synchronous DrawTest(host float* backbuffer) per frame, the reference's own calling contract: backbuffer "
+                                             "upload + blend + download over PCIe in every call (default host-buffer mode), the next two frames "
+                                             "traced ahead of the caller (tptSetHostLookahead); never the headline value")
+            if "sync" in extras and not args.animate and width * height <= 1280 * 720:
                 ms, mr = sync_caller_rate(api, torch, width, height)
                 out["sync_device_caller_ms"], out["sync_device_caller_Mray_s"] = ms, mr
                 out["sync_device_caller_note"] = ("tptDrawDevice + a synchronise after EVERY frame (device tile, no PCIe): the next two frames are "
                                                   "traced ahead of such a caller; never the headline value")
-            if args.persistent == 3 and args.hit_spheres != 1 and not args.animate and width * height <= 1280 * 720:
+            if "batched" in extras and args.persistent == 3 and args.hit_spheres != 1 and not args.animate and width * height <= 1280 * 720:
                 for k in (4, 8):
                     ms, mr = batched_rate(api, torch, width, height, per_launch=k, launches=max(4, 200 // k))
                     out["batched_%d_ms_per_frame" % k], out["batched_%d_Mray_s" % k] = ms, mr
                 out["batched_note"] = ("tptDrawDeviceBatch: k frames of the static scene per launch, blended in order by one more -- the same bits as "
                                        "k tptDrawDevice calls; a secondary figure, the headline value is one launch per frame")
-            if scene == "default" and width * height <= 1280 * 720:
+            if "row_serial" in extras and scene == "default" and width * height <= 1280 * 720:
                 ms, mr = row_serial_rate(api, width, height)
                 out["row_serial_ms"], out["row_serial_Mray_s"] = ms, mr
                 out["row_serial_note"] = ("seed mode 0: the reference's per-row RNG streams (bit-identical CPU image) through synchronous DrawTest(host buffer), frame by "

@@ -23,6 +23,14 @@
 #define TPT_HIP_H
 #include <stdint.h>
 
+/* The library is built with -fvisibility=hidden: exactly the functions declared here (and the six C++ symbols of
+ * tpt_test_api.h) are exported, nothing else (tests/test_abi.py compares `nm -D` with these headers). */
+#if defined(__GNUC__)
+#define TPT_API __attribute__((visibility("default")))
+#else
+#define TPT_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -34,18 +42,18 @@ enum { TPT_FLAG_ANIMATE = 1 << 0, TPT_FLAG_PROGRESSIVE = 1 << 1 };
 
 /* InitializeTest(), Test.h:10 / Test.cpp:240-246.  Picks the HIP device (env TPT_DEVICE, else
  * LOCAL_RANK, else 0), creates the stream, uploads the built-in 46-sphere scene. */
-int tptInitialize(void);
+TPT_API int tptInitialize(void);
 /* ShutdownTest(), Test.h:11 / Test.cpp:248-253. */
-int tptShutdown(void);
+TPT_API int tptShutdown(void);
 /* UpdateTest(time, frameCount, screenWidth, screenHeight, testFlags), Test.h:13 / Test.cpp:302-342:
  * animate spheres 1 and 8 if TPT_FLAG_ANIMATE, derive 1/r and r^2, emissive list, camera;
  * uploads the scene arrays when they changed. */
-int tptUpdate(float time, int frameCount, int screenWidth, int screenHeight, unsigned testFlags);
+TPT_API int tptUpdate(float time, int frameCount, int screenWidth, int screenHeight, unsigned testFlags);
 /* DrawTest(time, frameCount, w, h, backbuffer, outRayCount, testFlags), Test.h:14 / Test.cpp:344-367.
  * `backbuffer` is a HOST pointer to w*h*4 floats, read-modify-written in place (RGB blended with the
  * previous contents, alpha untouched); synchronous: on return the frame and *outRayCount are final.
  * With row sharding active (tptSetRowShard) only this rank's rows are touched. */
-int tptDraw(float time, int frameCount, int screenWidth, int screenHeight, float* backbuffer, int* outRayCount,
+TPT_API int tptDraw(float time, int frameCount, int screenWidth, int screenHeight, float* backbuffer, int* outRayCount,
             unsigned testFlags);
 /* The host-pointer path above keeps the reference's contract (synchronous, the caller's buffer read-modify-written in
  * place); three things make it fast, none changes a byte of the result:
@@ -67,24 +75,24 @@ int tptDraw(float time, int frameCount, int screenWidth, int screenHeight, float
  *    The same look-ahead serves tptDrawDevice for a SYNCHRONOUS caller -- one whose previous frame has already been blended
  *    when its next call arrives, twice in a row, for consecutive frames of one configuration (a caller that streams frames
  *    never meets that and is unaffected): 0.98 -> ~0.55 ms per 1280x720x4 frame for a host that waits for every frame. */
-int tptSetHostBufferMode(int hostBufferOnlyWrittenByDrawTest);
-int tptSetHostLookahead(int frames);
+TPT_API int tptSetHostBufferMode(int hostBufferOnlyWrittenByDrawTest);
+TPT_API int tptSetHostLookahead(int frames);
 /* how many frames were found traced ahead when their DrawTest / tptDrawDevice call arrived (monotonic; diagnostics, tests) */
-int tptDebugLookaheadHits(long long* outHits);
+TPT_API int tptGetLookaheadHits(long long* outHits);
 /* GetObjectCount / GetSceneDesc, Test.h:16-17 / Test.cpp:369-384: sizes are 20 / 36 / 88 bytes and
  * the copies are byte-compatible with the reference's Sphere / Material / Camera structs. */
-int tptGetObjectCount(int* outCount, int* outObjectSize, int* outMaterialSize, int* outCamSize);
-int tptGetSceneDesc(void* outObjects, void* outMaterials, void* outCam, void* outEmissives, int* outEmissiveCount);
+TPT_API int tptGetObjectCount(int* outCount, int* outObjectSize, int* outMaterialSize, int* outCamSize);
+TPT_API int tptGetSceneDesc(void* outObjects, void* outMaterials, void* outCam, void* outEmissives, int* outEmissiveCount);
 
 /* ================= 2. what the reference fixes at compile time, as run-time state ================= */
 
 /* DO_SAMPLES_PER_PIXEL, Config.h:22 (default 4). */
-int tptSetSamplesPerPixel(int spp);
+TPT_API int tptSetSamplesPerPixel(int spp);
 /* DO_LIGHT_SAMPLING (default 1), DO_ANIMATE_SMOOTHING (default 0.9f), DO_MITSUBA_COMPARE (default 0), Config.h:23-25 /
  * Test.cpp:95,143-145,209-214,226-227,273-274,312-313.  Without light sampling Lambert hits shoot no shadow rays and
  * emission is never suppressed; "Mitsuba compare" is the reference's only correctness method (readme.md:30): metal
  * roughness 0, constant sky (0.15, 0.21, 0.3), aperture 0 (takes effect at the next tptUpdate). */
-int tptSetConfig(int lightSampling, float animateSmoothing, int mitsubaCompare);
+TPT_API int tptSetConfig(int lightSampling, float animateSmoothing, int mitsubaCompare);
 /* RNG seeding.  0 = ROW_SERIAL: one XorShift stream per image row carried along x (Test.cpp:280);
  * bit-identical to the reference CPU image.  A frame alone is parallel over rows only (720 lanes of work), but rows AND
  * frames are independent streams: for a static scene DrawTest / tptDraw trace the next 32 frames ahead as ONE launch (rows x
@@ -92,42 +100,42 @@ int tptSetConfig(int lightSampling, float animateSmoothing, int mitsubaCompare);
  * to 32 frames per call (8-10 Gray/s).
  * 1 = PER_PIXEL (default): one stream per pixel, the reference's own GPU formula
  * (Cpp/Windows/ComputeShader.hlsl:380); parallel over pixels. */
-int tptSetSeedMode(int mode);
+TPT_API int tptSetSeedMode(int mode);
 /* Colour fold.  0 = RECURSIVE (default): matE + lightE + attenuation*Trace(...) nesting of
  * Test.cpp:216, bit-identical colours.  1 = FORWARD: radiance += throughput*e (same rays, colours
  * equal up to rounding, no LDS bounce stack). */
-int tptSetFoldMode(int mode);
+TPT_API int tptSetFoldMode(int mode);
 /* Replace the static scene tables (Test.cpp:13-31, 46-64).  spheres: count x 20 B {center xyz, radius,
  * invRadius(ignored)}; materials: count x 36 B {int type; albedo xyz; emissive xyz; roughness; ri}.
  * count <= 0 or NULL restores the built-in scene. */
-int tptSetScene(const void* spheres, const void* materials, int count);
+TPT_API int tptSetScene(const void* spheres, const void* materials, int count);
 /* Camera ctor arguments (Maths.h:418; defaults Test.cpp:309-319).  NULL lookFrom restores defaults. */
-int tptSetCamera(const float* lookFrom, const float* lookAt, float vfovDegrees, float aperture, float focusDist);
+TPT_API int tptSetCamera(const float* lookFrom, const float* lookAt, float vfovDegrees, float aperture, float focusDist);
 
 /* ================= 3. device-resident / multi-GPU path ================= */
 
 /* Use an existing HIP stream (hipStream_t passed as void*, e.g. torch.cuda.current_stream().cuda_stream).
  * NULL -> the context's own stream. */
-int tptSetStream(void* hipStream);
+TPT_API int tptSetStream(void* hipStream);
 /* Row sharding for one-process-per-GPU rendering: the image's rows are dealt out in stripes of
  * `stripeRows` rows, round-robin over `numParts` ranks; this context renders the stripes of `part`
  * into a COMPACT local tile (tptLocalRowCount(h) rows).  Seeds depend on the global (x,y) only, so
  * the union of the tiles is bit-identical to a 1-GPU render.  (0,1,0) or numParts<=1 disables. */
-int tptSetRowShard(int stripeRows, int numParts, int part);
-int tptLocalRowCount(int screenHeight);
+TPT_API int tptSetRowShard(int stripeRows, int numParts, int part);
+TPT_API int tptLocalRowCount(int screenHeight);
 /* global image row of local tile row `localRow` */
-int tptLocalRowToGlobal(int localRow);
+TPT_API int tptLocalRowToGlobal(int localRow);
 /* Asynchronous draw into a DEVICE buffer holding this rank's tile: localRows*w*4 floats, the
  * accumulation buffer stays resident in HBM across frames.  Enqueued on the context's stream;
  * returns immediately.  Ray counts accumulate in a device counter (tptRayCounterRead). */
-int tptDrawDevice(float time, int frameCount, int screenWidth, int screenHeight, float* deviceTile, unsigned testFlags);
+TPT_API int tptDrawDevice(float time, int frameCount, int screenWidth, int screenHeight, float* deviceTile, unsigned testFlags);
 /* Several frames per launch: frames firstFrame .. firstFrame + nFrames - 1 of the scene and camera as of the last tptUpdate
  * (what the reference's main loop renders while nothing moves: TestWin.cpp:313-316 with kFlagAnimate off), traced by ONE
  * kernel launch and blended into the tile in frame order by one more.  Bit-identical to nFrames tptDrawDevice calls; a
  * launch's fixed costs (pool ramp-up and drain, no launch shorter than its longest pixel, queue latencies) are paid once
  * per batch instead of once per frame -- what bounds small frames and tiles of a sharded frame.  Path-queue kernel only
  * (the default); frames up to 8192 x 8192; kFlagAnimate is refused (the scene changes every frame). */
-int tptDrawDeviceBatch(float time, int firstFrame, int nFrames, int screenWidth, int screenHeight, float* deviceTile, unsigned testFlags);
+TPT_API int tptDrawDeviceBatch(float time, int firstFrame, int nFrames, int screenWidth, int screenHeight, float* deviceTile, unsigned testFlags);
 /* Frame pipelining of the asynchronous path: the trace kernels of up to `frames` consecutive tptDrawDevice
  * calls may be in flight at once (each on its own internal stream, writing its own per-frame colour
  * buffer); the progressive blend into the tile (Test.cpp:293-295) is a separate, ordered kernel on the
@@ -138,26 +146,26 @@ int tptDrawDeviceBatch(float time, int firstFrame, int nFrames, int screenWidth,
  * not been initialised yet (ROCm's default of 4 makes 3 streams slower than 2), then MEASURES how many streams really
  * run side by side and clamps the pipeline to that (tptGetPipelineInfo).  Twice as many frames may be ENQUEUED ahead
  * (frames f and f + frames share a stream). */
-int tptSetFrameOverlap(int frames);
-/* Stream batching (opt-in, default off): a caller that streams consecutive frames of one static configuration with SMALL frames -- fewer
+TPT_API int tptSetFrameOverlap(int frames);
+/* Stream batching (default ON since round 4; tptSetStreamBatching(0) or env TPT_STREAM_BATCH=0 turns it off): a caller that streams consecutive frames of one static configuration with SMALL frames -- fewer
  * than 2.4 M samples (rows x width x spp): tiles of a sharded frame, 640x360 -- is bound by the latency of a launch (no launch is
  * shorter than its longest pixel's sequential samples), not by arithmetic.  For such a caller tptDrawDevice / tptDrawSharded trace
  * the frames of the next 1-7 calls in the SAME launch (2 / 4 / 8 frames per launch for halves / quarters / eighths of 1280x720x4)
  * and every later call only blends its own colour plane: each frame is still delivered, in order, with its own ray count (the
  * counter and the mirrored snapshot are exact per frame), bit-identical to one launch per frame.  A call that does not continue
- * the sequence (other frame number, size, flags, scene, ...) drops the unserved planes: GPU time only.  1 turns it on (also env TPT_STREAM_BATCH=1 at tptInitialize). */
-int tptSetStreamBatching(int enable);
+ * the sequence (other frame number, size, flags, scene, ...) drops the unserved planes: GPU time only. */
+TPT_API int tptSetStreamBatching(int enable);
 /* Display conversion of a device-resident FULL image (w*h float4, row 0 = bottom) into w*h RGBA8 in device memory,
  * top row first: the reference's own conversion for its C++ path, Cpp/Emscripten/main.cpp:63-79
  * (c8 = min(sqrtf(c)*255, 255), alpha 255).  Enqueued on the context's stream; 4x less data to download than
  * the float buffer. */
-int tptDisplayRGBA8(const float* deviceTile, int screenWidth, int screenHeight, unsigned char* deviceRGBA);
+TPT_API int tptDisplayRGBA8(const float* deviceTile, int screenWidth, int screenHeight, unsigned char* deviceRGBA);
 /* Synchronise the stream and return the monotonic total of rays traced by this context. */
-int tptRayCounterRead(int64_t* outTotalRays);
+TPT_API int tptRayCounterRead(int64_t* outTotalRays);
 /* Let the caller own the ray counter: `deviceU64` points to one zero-initialised 64-bit word in device
  * memory (e.g. a torch int64 tensor) that the kernels atomically add to; NULL -> the internal counter.
  * Lets the multi-GPU host sum-reduce the counters with RCCL without a host round trip. */
-int tptSetRayCounter(void* deviceU64);
+TPT_API int tptSetRayCounter(void* deviceU64);
 /* Sharded hosts: from the next tptDrawDevice on, the progressive blend also writes every blended pixel of the tile to
  * `deviceMirror` (same size and layout as the tile) and the current ray-counter value to the 8 bytes at
  * `deviceCounterOut` (may be NULL) -- the snapshot handed to the collective while later frames keep accumulating into
@@ -166,8 +174,8 @@ int tptSetRayCounter(void* deviceU64);
  * the moment of the blend, not a per-frame count: with later frames already tracing it includes their rays so far, and
  * is exact for "all frames up to f" only once nothing later is in flight (the last frame's snapshot after a synchronise,
  * which is what tptShardedFinish and sharding.finish() read). */
-int tptSetTileMirror(float* deviceMirror, void* deviceCounterOut);
-int tptSynchronize(void);
+TPT_API int tptSetTileMirror(float* deviceMirror, void* deviceCounterOut);
+TPT_API int tptSynchronize(void);
 
 /* ---- multi-GPU inside the library: one process per GPU, RCCL over xGMI (replaces the row fan-out / join of
  * DrawTest, Test.cpp:357-361, across GPUs).  A C++ host needs nothing but these five calls and a way to hand 128 bytes from
@@ -183,35 +191,37 @@ int tptSynchronize(void);
  * depend on the global (x, y) only: the assembled image is bit-identical to a 1-GPU render.  librccl is dlopen()ed by
  * tptCommInit / tptCommGetUniqueId; a single-GPU host never loads it. */
 #define TPT_COMM_ID_BYTES 128
-int tptCommGetUniqueId(void* outId128);
-int tptCommInit(const void* id128, int nRanks, int rank, int stripeRows);
+TPT_API int tptCommGetUniqueId(void* outId128);
+TPT_API int tptCommInit(const void* id128, int nRanks, int rank, int stripeRows);
 /* Measurement aid, no RCCL: this process plays rank 0 of an nRanks-way run alone -- same tile, snapshot ring, events and
  * assemble kernel, a device copy of its own slice in place of the gather (the other ranks' rows of the image stay zero).
  * Shows what one GPU sustains as rank 0 of N (bench.py --emulate-ranks N).  Paired with tptCommDestroy like tptCommInit. */
-int tptCommInitLoopback(int nRanks, int stripeRows);
-int tptCommDestroy(void);
-int tptDrawSharded(float time, int frameCount, int screenWidth, int screenHeight, float* deviceImageOnRoot, unsigned testFlags);
+TPT_API int tptCommInitLoopback(int nRanks, int stripeRows);
+/* size of the communicator and this process's rank as RCCL reports them (ncclCommCount / ncclCommUserRank), loopback flag */
+TPT_API int tptCommInfo(int* outRanks, int* outRank, int* outLoopback);
+TPT_API int tptCommDestroy(void);
+TPT_API int tptDrawSharded(float time, int frameCount, int screenWidth, int screenHeight, float* deviceImageOnRoot, unsigned testFlags);
 /* nFrames (1..32) consecutive frames per call, traced by one launch per rank (tptDrawDeviceBatch) and followed by ONE exchange:
  * rank 0's image is that of the batch's last frame.  Same bits as nFrames tptDrawSharded calls. */
-int tptDrawShardedBatch(float time, int firstFrame, int nFrames, int screenWidth, int screenHeight, float* deviceImageOnRoot, unsigned testFlags);
+TPT_API int tptDrawShardedBatch(float time, int firstFrame, int nFrames, int screenWidth, int screenHeight, float* deviceImageOnRoot, unsigned testFlags);
 /* waits for every exchange enqueued so far; rank 0: sum of all ranks' ray counters as of the last gathered frame, other
  * ranks: their own.  Counters are running totals since tptInitialize / tptSetRayCounter (before the first sharded frame:
  * this rank's own running total), so callers take differences. */
-int tptShardedFinish(int64_t* outTotalRays);
+TPT_API int tptShardedFinish(int64_t* outTotalRays);
 
 /* hipEvent bracket on the context's stream, for kernel-only timing (as the reference times its
  * Dispatch with timestamp queries, TestWin.cpp:299-302). */
-int tptTimerBegin(void);
-int tptTimerEnd(float* outMilliseconds); /* synchronises */
+TPT_API int tptTimerBegin(void);
+TPT_API int tptTimerEnd(float* outMilliseconds); /* synchronises */
 
 /* Per-launch timing of the trace kernel: between Begin and End every tptDrawDevice brackets its trace
  * launch with a hipEvent pair recorded on the stream that launch goes to (the internal trace streams when
  * frames overlap).  End synchronises and returns the SUM of the individual launch durations and their
  * number -- the same per-dispatch durations a rocprofv3 kernel trace reports. */
-int tptKernelTimingBegin(int maxLaunches);
-int tptKernelTimingEnd(float* outSumMilliseconds, int* outLaunches);
+TPT_API int tptKernelTimingBegin(int maxLaunches);
+TPT_API int tptKernelTimingEnd(float* outSumMilliseconds, int* outLaunches);
 
-/* ================= 4. tuning / test hooks ================= */
+/* ================= 4. tuning and diagnostics (unit-test entry points: tpt_test_hooks.h, a separate build) ================= */
 
 /* hitSpheres: 0 = two-phase (default: a conservative filter + the reference's exact test for what passes.  The filter runs
  * on the matrix cores for scenes of <= 64 spheres that binary16 operands can carry, as packed FP32 on the VALU otherwise;
@@ -222,36 +232,17 @@ int tptKernelTimingEnd(float* outSumMilliseconds, int* outLaunches);
  * only -- anything else falls back to 1), 1 = persistent waves with lane refill (any other value selects 3).  ldsScene:
  * 1 = stage sphere records and materials in LDS (default when they fit), 0 = read them from global memory, -1 = auto.
  * All variants produce identical bits. */
-int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene);
-/* device math unit tests: op 0 sqrt 1 div 2 sin 3 cos 4 pow5 5 rnd01^16 6 schlick 7 normalize.x 8 / 9 sin / cos of the sincos pair; host arrays */
-int tptTestMath(int op, const float* a, const float* b, float* out, int n);
-/* intersect n host rays ([n][6] = origin, UNIT direction -- the reference asserts it, Maths.h:337; the two-phase
- * filter's error bound assumes it) with the current scene on the GPU */
-int tptTestHitSpheres(int hitSpheres, const float* rays, int* outId, float* outT, int n);
-/* self-check: tpt_math.h's fast correctly-rounded sqrt (op 0) / 1.0f / sqrtf (op 1) against the compiler's correctly rounded
- * expansions for EVERY binary32 bit pattern in [lo, hi] on the device; mismatch count + the first offending inputs */
-int tptTestMathExhaustive(int op, unsigned lo, unsigned hi, unsigned long long* outMismatches, unsigned* outFirst8);
-/* phase 1 of HitSpheres as the path-queue kernel runs it for scenes of <= 64 spheres: on the matrix cores
- * (v_mfma_f32_32x32x16_f16 over an 11-term expansion of the filter's discriminant, every f32 factor split into two binary16
- * pieces).  n host rays -> candidate masks (sphere p at bit 63 - p; may be NULL) and / or the nearest hit through the filter
- * + the exact test of its candidates (outId / outT; may be NULL). */
-int tptTestMatrixFilter(const float* rays, unsigned long long* outMask, int* outId, float* outT, int n);
+TPT_API int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene);
 /* kernel resource facts for DESIGN/bench: occupancy (blocks/CU), LDS bytes/block, grid size of the last launch */
-int tptGetLaunchInfo(int* outBlocksPerCU, int* outLdsBytes, int* outGridBlocks, int* outNumCUs);
+TPT_API int tptGetLaunchInfo(int* outBlocksPerCU, int* outLdsBytes, int* outGridBlocks, int* outNumCUs);
 /* Facts about the frame pipeline: hardware queues the runtime really runs side by side for this process (measured at
  * tptInitialize with one spinning wave per trace stream: GPU_MAX_HW_QUEUES only counts if it was set before the HIP
  * runtime started), the frames-in-flight limit that results (tptSetFrameOverlap's value clamped to what those queues can
  * carry), the deepest pipeline the caller has built so far (decides the grid of a launch), and how often the per-slot
  * buffers were (re-)allocated (once per frame shape; never on the steady-state path). */
-int tptGetPipelineInfo(int* outHwQueues, int* outOverlapEffective, int* outStreamDepth, int* outSlotReservations);
-/* profiling builds only (-DTPT_STATS): 128 counters, wave-level entries [i] / lane counts [32+i] of the
- * state machine's blocks (enum ST_* in tpt_trace.h); the shipped build returns an error. */
-int tptDebugStats(unsigned long long* out128, int reset);
-/* per-chunk accumulated ray counts and the chunk order table of the last launch (cost-ordered work distribution
- * of the persistent kernel); either pointer may be NULL; returns the number of chunks copied */
-int tptDebugChunkOrder(unsigned* outCost, unsigned* outOrder, int capacity);
-const char* tptGetLastError(void);
-const char* tptGetDeviceName(void);
+TPT_API int tptGetPipelineInfo(int* outHwQueues, int* outOverlapEffective, int* outStreamDepth, int* outSlotReservations);
+TPT_API const char* tptGetLastError(void);
+TPT_API const char* tptGetDeviceName(void);
 
 #ifdef __cplusplus
 }

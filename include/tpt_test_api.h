@@ -20,17 +20,22 @@
 //     tptSetSeedMode(0) gives the reference's exact CPU image.
 #pragma once
 #include <stdint.h>
+#if defined(__GNUC__)
+#define TPT_CXX_API __attribute__((visibility("default")))
+#else
+#define TPT_CXX_API
+#endif
 
 enum TestFlags {
     kFlagAnimate = (1 << 0),
     kFlagProgressive = (1 << 1),
 };
 
-void InitializeTest();
-void ShutdownTest();
+TPT_CXX_API void InitializeTest();
+TPT_CXX_API void ShutdownTest();
 
-void UpdateTest(float time, int frameCount, int screenWidth, int screenHeight, unsigned testFlags);
-void DrawTest(float time, int frameCount, int screenWidth, int screenHeight, float* backbuffer, int& outRayCount, unsigned testFlags);
+TPT_CXX_API void UpdateTest(float time, int frameCount, int screenWidth, int screenHeight, unsigned testFlags);
+TPT_CXX_API void DrawTest(float time, int frameCount, int screenWidth, int screenHeight, float* backbuffer, int& outRayCount, unsigned testFlags);
 
-void GetObjectCount(int& outCount, int& outObjectSize, int& outMaterialSize, int& outCamSize);
-void GetSceneDesc(void* outObjects, void* outMaterials, void* outCam, void* outEmissives, int* outEmissiveCount);
+TPT_CXX_API void GetObjectCount(int& outCount, int& outObjectSize, int& outMaterialSize, int& outCamSize);
+TPT_CXX_API void GetSceneDesc(void* outObjects, void* outMaterials, void* outCam, void* outEmissives, int* outEmissiveCount);

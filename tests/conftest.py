@@ -61,9 +61,7 @@ def tpt():
     api.ShutdownTest()
 
 
-@pytest.fixture()
-def tpt_defaults(tpt):
-    """Reset every run-time knob to its default before a test."""
+def _reset_knobs(tpt):
     tpt.set_scene(None)
     tpt.set_camera(None)
     tpt.set_samples_per_pixel(4)
@@ -75,30 +73,28 @@ def tpt_defaults(tpt):
     tpt.set_frame_overlap(16)
     tpt.set_host_buffer_mode(False)
     tpt.set_host_lookahead(2)
-    tpt.set_stream_batching(os.environ.get("TPT_FORCE_STREAM_BATCH", "0") == "1")  # opt-in feature: off unless a test (or the environment) asks for it
+    tpt.set_stream_batching(os.environ.get("TPT_FORCE_STREAM_BATCH", "1") == "1")  # the library's default; TPT_FORCE_STREAM_BATCH=0 runs the suite without it
     return tpt
 
 
-@pytest.fixture(autouse=True, scope="session")
-def _torch_fills_complete_before_the_library_sees_the_buffer():
-    """torch.zeros(..., device="cuda") enqueues its fill on torch's current stream; the library works on its own non-blocking
-    streams, which do not wait for it.  A test that hands such a tensor to the library straight away races the fill against the
-    library's writes (seen as an all-zero assembled image or a garbage snapshot counter once in a few suite runs, when long
-    batched launches of an earlier test were still occupying the GPU).  Every CUDA tensor the tests create is therefore complete
-    when torch.zeros returns.  (A host has the same obligation: INTEGRATION.md section 3.)"""
-    try:
-        import torch
-    except ImportError:
-        yield
-        return
-    orig = torch.zeros
+@pytest.fixture()
+def tpt_defaults(tpt):
+    """Reset every run-time knob to its default before a test."""
+    return _reset_knobs(tpt)
 
-    def zeros(*a, **k):
-        t = orig(*a, **k)
-        if t.is_cuda:
-            torch.cuda.synchronize()
-        return t
 
-    torch.zeros = zeros
-    yield
-    torch.zeros = orig
+@pytest.fixture(scope="session")
+def _hooks_session(tpt):
+    yield tpt
+    tpt.shutdown_hooks()
+
+
+@pytest.fixture()
+def tpt_hooks(_hooks_session):
+    """The HOOKS build of the library (libtoypathtracer_hip_hooks.so: the product's sources + include/tpt_test_hooks.h) for the
+    unit tests of the math layer / HitSpheres / the matrix filter.  Inside the test every call of the api module goes to that
+    build (its own context); the product library stays loaded and initialised beside it."""
+    tpt = _hooks_session
+    with tpt.using_hooks():
+        _reset_knobs(tpt)
+        yield tpt

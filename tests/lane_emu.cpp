@@ -6,6 +6,7 @@
 // packing against the oracle without a GPU.  What it cannot cover (wave-level refill, LDS staging,
 // atomics, the device compiler) is covered by the `-m gpu` parity tests.
 #include "tpt_scene.h"
+#include "tpt_shard.h"
 #include <stdint.h>
 #include <vector>
 
@@ -114,6 +115,82 @@ void emu_group_info(const void* spheres, const void* mats, int count, int* out3)
     PackedScene P;
     packScene(S, M, P);
     out3[0] = P.nGroups; out3[1] = P.nGroupPairs; out3[2] = P.nBig;
+}
+// tdivByPi's 3-instruction fast form (q0 = a Y, r = fma(-pi, q0, a), q = fma(r, Y, q0), Y = RN(1 / kPI)) against the IEEE
+// quotient a / kPI for EVERY significand of a, at the given binary exponent: the number of mismatches (plain fmaf on the host
+// is what v_fma_f32 computes).  The guard of tdivByPi hands arguments outside {+0} u [2^-100, 2^126) to the IEEE division.
+long long emu_div_pi_mismatches(int exponent, unsigned* firstBad)
+{
+    long long bad = 0;
+    for (uint32_t m = 0; m < (1u << 23); ++m) {
+        const float a = ldexpf(u2f(0x3f800000u | m), exponent);
+        const float want = a / TPT_PI, got = tdivByPiFast(a);
+        if (f2u(want) != f2u(got)) {
+            if (!bad && firstBad) *firstBad = f2u(a);
+            ++bad;
+        }
+    }
+    return bad;
+}
+// ---- the C-ABI exchange (tptDrawSharded / tptShardedFinish, tpt_host.cpp) replayed on the CPU with the product's own index
+// functions (tpt_shard.h): every rank "renders" its tile -- pixel (x, gy) carries the code gy * w + x, written through the
+// kernel's local -> global row map exactly as mapItem / the colour store address it -- the resolve kernel's snapshot layout
+// ([padRows + 1][w] pixels, the counter bit-cast into the first 8 bytes of the extra row), the gather (rank-major concatenation:
+// what ncclGather delivers on the root), tptAssembleKernel's inverse map and tptShardedFinish's counter reads.
+//   out:  image[h * w]    the assembled codes (must be gy * w + x everywhere)
+//         info[0..3]      padRows, sum of the counters as tptShardedFinish reads them (low 32 bits), ring slot used, errors found
+//         rowOfRank0[h]   for every image row: its row in the flattened receive buffer (sharding.py's rowmap)
+// counterOf(r) = (r + 1) * 1000003 + frames is what rank r's counter row carries.
+long long emu_shard_exchange(int w, int h, int S, int N, int ring, unsigned long long frames, long long* image, long long* info, long long* rowOfRank0)
+{
+    const int padRows = shardPadRows(h, S, N);
+    const size_t snap = shardSnapshotPixels(padRows, w);
+    std::vector<f4> gathered(snap * (size_t)N);
+    for (size_t i = 0; i < gathered.size(); ++i) gathered[i].x = gathered[i].y = gathered[i].z = gathered[i].w = -1.0f;
+    long long errors = 0;
+    int covered = 0;
+    for (int r = 0; r < N; ++r) {
+        const int rows = shardLocalRows(h, S, N, r);
+        covered += rows;
+        if (rows > padRows) ++errors;
+        f4* send = gathered.data() + snap * (size_t)r; // (the gather: rank r's snapshot lands at slot r of the root's buffer)
+        // the launch's stripe constants as enqueueTrace sets them
+        const int stripeRows = N > 1 ? S : (h > 0 ? h : 1), stripeStride = N > 1 ? S * N : stripeRows, stripeOffset = N > 1 ? S * r : 0;
+        for (int ly = 0; ly < rows; ++ly) {
+            const int gy = shardKernelLocalToGlobal(ly, stripeRows, stripeStride, stripeOffset);
+            if (gy != shardLocalToGlobal(ly, S, N, r) || gy < 0 || gy >= h) ++errors;
+            if (shardKernelGlobalToLocal(gy, stripeRows, stripeStride, stripeOffset) != ly) ++errors;
+            if (shardOwner(gy, S, N) != r || shardGlobalToLocal(gy, S, N) != ly) ++errors;
+            for (int x = 0; x < w; ++x) {
+                f4 v;
+                v.x = (float)(gy * w + x); // (exact below 2^24)
+                v.y = (float)gy; v.z = (float)x; v.w = 1.0f;
+                send[(size_t)ly * w + x] = v;
+            }
+        }
+        const unsigned long long counter = (unsigned long long)(r + 1) * 1000003ull + frames + (1ull << 40); // (needs both words)
+        memcpy(&send[shardCounterPixel(padRows, w)], &counter, 8);
+    }
+    if (covered != h) ++errors;
+    for (int gy = 0; gy < h; ++gy) {
+        for (int x = 0; x < w; ++x) {
+            const f4 v = gathered[shardGatheredPixel(x, gy, w, S, N, padRows)];
+            image[(size_t)gy * w + x] = (long long)v.x;
+            if (v.y != (float)gy || v.z != (float)x) ++errors;
+        }
+        rowOfRank0[gy] = (long long)(shardGatheredPixel(0, gy, w, S, N, padRows) / (size_t)w);
+    }
+    unsigned long long total = 0;
+    for (int r = 0; r < N; ++r) { // tptShardedFinish on rank 0
+        unsigned long long v = 0;
+        memcpy(&v, &gathered[(size_t)r * snap + shardCounterPixel(padRows, w)], 8);
+        total += v;
+    }
+    info[0] = padRows;
+    info[1] = (long long)total;
+    info[2] = shardRingSlot(frames, ring);
+    info[3] = errors;
+    return errors;
 }
 float emu_sinf(float x) { return tsinf(x); }
 float emu_cosf(float x) { return tcosf(x); }

@@ -9,10 +9,15 @@ import pytest
 from oracle_lib import ROOT
 
 
-def header_symbols():
-    text = open(os.path.join(ROOT, "include", "tpt_hip.h")).read()
+def header_symbols(name="tpt_hip.h"):
+    text = open(os.path.join(ROOT, "include", name)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(tpt[A-Z]\w*)\s*\(", text)))
+
+
+def exported(path):
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path]).decode()
+    return sorted(line.split()[-1] for line in out.splitlines() if line.strip())
 
 
 def test_library_exports_every_declared_symbol():
@@ -23,6 +28,17 @@ def test_library_exports_every_declared_symbol():
     assert sorted(api.C_ABI_SYMBOLS) == declared, "api.C_ABI_SYMBOLS out of sync with include/tpt_hip.h"
     for name in declared:
         assert hasattr(lib, name), name
+
+
+def test_library_exports_exactly_its_abi():
+    """-fvisibility=hidden + csrc/exports.map: the dynamic symbol table of the product library is the C ABI of include/tpt_hip.h
+    plus the reference's six C++ symbols and NOTHING else -- no internal helper, no kernel stub, no libstdc++ instantiation, no
+    unit-test hook.  The hooks build (the GPU suite's unit tests) adds exactly include/tpt_test_hooks.h."""
+    from toypathtracer_amd import api
+    assert exported(api.library_path()) == sorted(header_symbols() + api.CXX_ABI_SYMBOLS)
+    hooks = header_symbols("tpt_test_hooks.h")
+    assert sorted(hooks) == sorted(api.HOOK_SYMBOLS)
+    assert exported(api.hooks_library_path()) == sorted(header_symbols() + hooks + api.CXX_ABI_SYMBOLS)
 
 
 def test_library_exports_reference_cxx_symbols():

@@ -177,10 +177,11 @@ def test_drawtest_lookahead_changes_nothing(tpt_defaults, oracle, lookahead):
 
 
 def test_drawtest_in_the_reference_seed_mode_is_served_from_batched_lookahead(tpt_defaults, oracle):
-    """tptSetSeedMode(0) + plain synchronous DrawTest calls -- the literal drop-in with the reference's own pixels: the library
-    traces this frame and the 31 after it as ONE launch (rows x frames lanes, a ray counter per frame) and the batch after
-    that as soon as the first is being served.  Every frame's bytes and ray count equal the oracle's ROW_SERIAL render, across
-    the batch boundary (frames 31 -> 32 -> 33), after a jump in frameCount, a restart at 0 and a different size in between."""
+    """tptSetSeedMode(0) + plain synchronous DrawTest calls -- the literal drop-in with the reference's own pixels: from the third
+    consecutive frame of one configuration on the library traces that frame and the 31 after it as ONE launch (rows x frames
+    lanes, a ray counter per frame), and the batch after that once the first has been hit.  Every frame's bytes and ray count
+    equal the oracle's ROW_SERIAL render, across the batch boundary (frames 33 -> 34), after a jump in frameCount, a restart
+    at 0 and a different size in between."""
     from common import oracle_frames
     tpt = tpt_defaults
     tpt.set_seed_mode(SEED_ROW_SERIAL)
@@ -197,13 +198,29 @@ def test_drawtest_in_the_reference_seed_mode_is_served_from_batched_lookahead(tp
         r, _ = oracle.render(s, m, cam, w, h, 2, f, seed_mode=SEED_ROW_SERIAL, backbuffer=ob)
         want.append(r)
     assert per == want and bb.tobytes() == ob.tobytes()
-    assert tpt.lookahead_hits() - hits0 >= 35  # frames 1..35 (and 41, 1) were already traced when their call arrived
+    assert tpt.lookahead_hits() - hits0 == 33  # frames 3..35 were already traced when their call arrived (0, 1, 2 and the jumps 40, 41, 0, 1 were not: a batch is launched for a caller that has shown its pattern only)
     per2, bb2 = _draw_seq(tpt, [0, 1, 2], 96, 64)
     ro2, bo2, pero2 = oracle_frames(oracle, 96, 64, 2, 3, seed_mode=SEED_ROW_SERIAL)
     assert per2 == pero2 and bb2.tobytes() == bo2.tobytes()
     tpt.set_host_lookahead(0)  # look-ahead off: frame by frame, same bits
     per3, bb3 = _draw_seq(tpt, [0, 1, 2], 96, 64)
     assert per3 == pero2 and bb3.tobytes() == bo2.tobytes()
+
+
+def test_drawtest_in_the_reference_seed_mode_survives_a_refused_batch(tpt_defaults, oracle):
+    """A frame the batched launch cannot take (wider than 8192 pixels) in seed mode 0: the look-ahead is refused, DrawTest is not
+    -- every call is served by the single-frame path, with the oracle's bytes and ray counts, and the refusal is remembered
+    (no retry per call).  (Round 3 returned the batch's error from every DrawTest once the caller looked sequential.)"""
+    from common import oracle_frames
+    tpt = tpt_defaults
+    tpt.set_seed_mode(SEED_ROW_SERIAL)
+    tpt.set_samples_per_pixel(1)
+    w, h = 8200, 2
+    hits0 = tpt.lookahead_hits()
+    per, bb = _draw_seq(tpt, [0, 1, 2, 3, 4], w, h)
+    ro, bo, pero = oracle_frames(oracle, w, h, 1, 5, seed_mode=SEED_ROW_SERIAL)
+    assert per == pero and bb.tobytes() == bo.tobytes()
+    assert tpt.lookahead_hits() == hits0
 
 
 def test_stream_batching_delivers_every_frame_with_its_own_ray_count(tpt_defaults, oracle):
@@ -226,7 +243,7 @@ def test_stream_batching_delivers_every_frame_with_its_own_ray_count(tpt_default
         tpt.set_ray_counter(counter.data_ptr())
         tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
         snaps, counts = [], []
-        torch.cuda.synchronize()
+        stream.wait_stream(torch.cuda.current_stream())  # the host's own stream: ordering it against the fills is the host's job
         try:
             with torch.cuda.stream(stream):
                 for f, spp in seq:
@@ -500,7 +517,6 @@ def test_synchronous_device_caller_gets_lookahead_and_the_same_bits(tpt_defaults
     ro, bo, per_frame = oracle_frames(oracle, w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
     for synchronous in (True, False):
         tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
-        torch.cuda.synchronize()
         hits0 = tpt.lookahead_hits()
         last = tpt.ray_counter_read()
         for f in range(frames):
@@ -519,17 +535,40 @@ def test_synchronous_device_caller_gets_lookahead_and_the_same_bits(tpt_defaults
             assert hits >= frames - 4, hits
     # a change of configuration in the middle drops what was traced ahead
     tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
-    torch.cuda.synchronize()
     for f in range(6):
         tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
         tpt.draw_device(0.0, f, w, h, tile.data_ptr(), FLAG_PROGRESSIVE)
         tpt.synchronize()
     tpt.set_samples_per_pixel(2)
     tile2 = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
-    torch.cuda.synchronize()
     for f in range(3):
         tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
         tpt.draw_device(0.0, f, w, h, tile2.data_ptr(), FLAG_PROGRESSIVE)
         tpt.synchronize()
     _, b2, _ = oracle_frames(oracle, w, h, 2, 3, seed_mode=SEED_PER_PIXEL)
     assert tile2.cpu().numpy().tobytes() == b2.tobytes()
+
+
+def test_default_stream_fill_is_ordered_before_the_librarys_first_touch(tpt_defaults, oracle):
+    """The ordering contract of the device path: the context's own stream is a blocking stream, so
+    a tile filled on the legacy default stream (hipMemset, a torch op) is complete before the library's first blend reads it --
+    even when that fill is still queued behind tens of milliseconds of other GPU work when tptDrawDevice is called -- and a
+    default-stream read after the call sees the blended frame.  (Round 3 had every library stream non-blocking: the late fill
+    wiped the first frames.  This test fails on that build.)"""
+    import torch
+    from common import oracle_frames
+    tpt = tpt_defaults
+    w, h, frames = 320, 200, 3
+    _, bo, _ = oracle_frames(oracle, w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
+    a = torch.randn((4096, 4096), device="cuda")
+    for rep in range(3):
+        for _ in range(40):
+            a = (a @ a).clamp_(-1.0, 1.0)  # ~50 ms of default-stream work in front of the fill
+        tile = torch.full((h, w, 4), 123.0, dtype=torch.float32, device="cuda")
+        tile.zero_()                         # the fill the library must not overtake
+        for f in range(frames):
+            tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+            tpt.draw_device(0.0, f, w, h, tile.data_ptr(), FLAG_PROGRESSIVE)
+        got = tile.clone()                   # default stream: ordered behind the library's blends, no synchronise in between
+        assert got.cpu().numpy().tobytes() == bo.tobytes(), rep
+        tpt.synchronize()

@@ -162,9 +162,9 @@ def test_sphere_count_edges(tpt_defaults, oracle, n):
     assert rays == ro and bb.tobytes() == bo.tobytes()
 
 
-def test_hit_spheres_kernel_vs_oracle(tpt_defaults, oracle):
+def test_hit_spheres_kernel_vs_oracle(tpt_hooks, oracle):
     import ctypes as C
-    tpt = tpt_defaults
+    tpt = tpt_hooks
     tpt.UpdateTest(0.0, 0, 64, 64, 2)
     rng = np.random.default_rng(5)
     n = 20000
@@ -187,12 +187,12 @@ def test_hit_spheres_kernel_vs_oracle(tpt_defaults, oracle):
         assert np.array_equal(ts.view(np.uint32), want_t.view(np.uint32))
 
 
-def test_two_phase_filter_is_conservative_on_grazing_rays_gpu(tpt_defaults):
+def test_two_phase_filter_is_conservative_on_grazing_rays_gpu(tpt_hooks):
     """As tests/test_lane_logic.py's grazing-ray test, on the device: the FMA filter of phase 1 (v_pk_fma_f32) must never
     drop a sphere the exact loop hits.  2M rays through the built-in scene, 200k through the 4096-sphere scene."""
     from common import grazing_rays
     from toypathtracer_amd.scenes import stress_scene
-    tpt = tpt_defaults
+    tpt = tpt_hooks
     for scene, n in ((None, 2000000), (stress_scene(4096, 64), 200000), (stress_scene(20000, 160), 100000)):
         if scene is None:
             tpt.set_scene(None)
@@ -282,8 +282,8 @@ def test_device_resident_path_with_torch_tile(tpt_defaults, oracle):
     tpt = tpt_defaults
     w, h, frames = 256, 144, 4
     tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
-    torch.cuda.synchronize()  # the fill runs on torch's stream; the library's streams do not wait for it
     stream = torch.cuda.Stream()
+    stream.wait_stream(torch.cuda.current_stream())  # the host's own stream: ordering it against the fill is the host's job
     tpt.set_stream(stream.cuda_stream)
     r0 = tpt.ray_counter_read()
     with torch.cuda.stream(stream):
@@ -308,7 +308,6 @@ def test_seventy_pipelined_frames_at_config2(tpt_defaults, oracle, persist, over
     tpt.set_frame_overlap(overlap)
     w, h, frames = 1280, 720, 70
     tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
-    torch.cuda.synchronize()  # the fill runs on torch's stream; the library's streams do not wait for it
     r0 = tpt.ray_counter_read()
     for f in range(frames):
         tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
@@ -376,9 +375,7 @@ def test_tile_mirror_snapshot(tpt_defaults, oracle):
     tpt = tpt_defaults
     w, h, frames = 160, 96, 6
     tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
-    torch.cuda.synchronize()  # the fill runs on torch's stream; the library's streams do not wait for it
     mirrors = [torch.full((h + 1, w, 4), -1.0, dtype=torch.float32, device="cuda") for _ in range(3)]
-    torch.cuda.synchronize()  # (same for these fills)
     r0 = tpt.ray_counter_read()
     for f in range(frames):
         mbuf = mirrors[f % 3]
@@ -412,7 +409,6 @@ def test_frame_overlap_is_bit_identical(tpt_defaults, oracle, overlap):
     if overlap == 16:
         w, h = 640, 360  # enough work per frame that many launches really are in flight (adaptive grid size kicks in)
     tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
-    torch.cuda.synchronize()  # the fill runs on torch's stream; the library's streams do not wait for it
     r0 = tpt.ray_counter_read()
     tpt.kernel_timing_begin(frames)
     for f in range(frames):
@@ -475,7 +471,6 @@ def test_animated_scene_async_upload_ring(tpt_defaults, oracle, overlap):
     w, h, frames = 96, 64, 80
     flags = FLAG_PROGRESSIVE | FLAG_ANIMATE
     tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
-    torch.cuda.synchronize()  # the fill runs on torch's stream; the library's streams do not wait for it
     r0 = tpt.ray_counter_read()
     for f in range(frames):
         t = 0.37 * f
@@ -520,15 +515,14 @@ def test_both_kernels_full_size_and_stress(tpt_defaults, oracle, variant, fold):
     assert per == pero and bb.tobytes() == bo.tobytes()
 
 
-def test_cost_ordered_chunks_table_is_a_permutation_and_image_unchanged(tpt_defaults, oracle):
+def test_cost_ordered_chunks_table_is_a_permutation_and_image_unchanged(tpt_hooks, oracle):
     """The persistent kernel hands out 8x8 tiles expensive-first from the previous frames' ray counts; the order table
     is rebuilt while other frames are in flight and must stay a permutation (every tile rendered exactly once)."""
     import torch
-    tpt = tpt_defaults
+    tpt = tpt_hooks
     tpt.set_kernel_variant(0, 1, -1)  # the lane-refill kernel (the fallback of the path-queue kernel) owns this mechanism
     w, h, frames = 640, 360, 20
     tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
-    torch.cuda.synchronize()  # the fill runs on torch's stream; the library's streams do not wait for it
     r0 = tpt.ray_counter_read()
     for f in range(frames):
         tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
@@ -581,7 +575,7 @@ def _mixed_rays(rng, s, n):
     return np.concatenate([g, np.concatenate([o.astype(np.float32), d], 1)], 0).astype(np.float32)
 
 
-def test_matrix_filter_sign_agrees_with_the_exact_slot_sum(tpt_defaults, emu, oracle):
+def test_matrix_filter_sign_agrees_with_the_exact_slot_sum(tpt_hooks, emu, oracle):
     """The error model behind the matrix-core filter's slack (tpt_trace.h, phase1MatrixH), checked on the device: the sign
     bit v_mfma_f32_32x32x16_f16 delivers for a (sphere, ray) equals the sign of the EXACT sum of the 32 slot products
     (binary64 on the host, same table, same ray slots) whenever that sum is further than 64 u x (sum of magnitudes) from
@@ -590,7 +584,7 @@ def test_matrix_filter_sign_agrees_with_the_exact_slot_sum(tpt_defaults, emu, or
     binary16 range keep every sphere."""
     from test_lane_logic import _matrix_masks
     from toypathtracer_amd.scenes import stress_scene
-    tpt = tpt_defaults
+    tpt = tpt_hooks
     rng = np.random.default_rng(5)
     from common import matrix_scene
     scenes = [oracle.default_scene()] + [matrix_scene(oracle, n) for n in (1, 3, 17, 32, 33, 40, 47, 56, 64)]
@@ -617,12 +611,12 @@ def test_matrix_filter_sign_agrees_with_the_exact_slot_sum(tpt_defaults, emu, or
     tpt.set_scene(None)
 
 
-def test_matrix_filter_hits_equal_the_exact_loop_on_grazing_rays(tpt_defaults, oracle):
+def test_matrix_filter_hits_equal_the_exact_loop_on_grazing_rays(tpt_hooks, oracle):
     """Conservative in practice: for two million rays that graze a sphere within 1e-8..1e-3 radii, the nearest hit through the
     matrix-core filter + exact test of its candidates equals the all-exact loop (the reference's arithmetic for every
     sphere), id and t bit for bit."""
     from common import grazing_rays
-    tpt = tpt_defaults
+    tpt = tpt_hooks
     s, m = oracle.default_scene()
     tpt.set_scene(s, m)
     n = 1 << 21

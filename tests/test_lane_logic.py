@@ -275,3 +275,17 @@ def test_config_switches_reproduce_reference_variants(emu, oracle, case):
         assert rays == case["rays"] and "%08x" % fnv1a(bb) == case["fnv"]
     finally:
         emu.emu_set_config(1, 0.9, 0)
+
+
+def test_division_by_pi_all_significands(emu):
+    """tpt_math.h's tdivByPi: the 3-instruction form with the correctly rounded reciprocal of kPI as a constant equals the IEEE
+    quotient a / kPI for every one of the 2^23 significands of a, across the exponent range its guard admits ([2^-100, 2^126);
+    +0 maps to +0).  (The variable-divisor form, tdivSafeNum, rests on the device run over all 2^46 significand pairs:
+    tools/exhaustive/exhaustive_div.hip, profiles/r04/r04_run1.log.)"""
+    import ctypes as C
+    emu.emu_div_pi_mismatches.restype = C.c_longlong
+    emu.emu_div_pi_mismatches.argtypes = [C.c_int, C.POINTER(C.c_uint)]
+    first = C.c_uint(0)
+    for e in (-100, -64, -24, -3, -1, 0, 1, 2, 3, 60, 125):
+        bad = emu.emu_div_pi_mismatches(e, C.byref(first))
+        assert bad == 0, (e, bad, hex(first.value))

@@ -102,3 +102,35 @@ def test_gather_reassembles_the_single_process_image(oracle, world, h, stripe, m
         rays_sum += r
     assert total == rays_sum
     assert img.tobytes() == bb.tobytes()
+
+
+@pytest.mark.parametrize("world,h,stripe,w", [(2, 42, 4, 7), (3, 50, 8, 5), (8, 100, 8, 3), (8, 2160, 8, 2), (8, 720, 8, 2), (4, 1080, 8, 2), (5, 33, 3, 4), (2, 8, 8, 4), (8, 5, 8, 4), (1, 17, 8, 3)])
+def test_cabi_exchange_index_math_equals_the_python_twin(emu, world, h, stripe, w):
+    """The C-ABI exchange a Test.h host drives (tptDrawSharded / tptShardedFinish) has never run with more than one rank on
+    hardware; its index arithmetic -- csrc/tpt_shard.h, the very functions tpt_host.cpp and the kernels call: rows per rank,
+    the kernel's local <-> global row maps, padRows, the [padRows + 1][w] snapshot with the counter row, the rank-major
+    receive buffer, tptAssembleKernel's inverse map, the ring slot, the counter reads of tptShardedFinish -- is replayed on
+    the CPU for EVERY rank (tests/lane_emu.cpp: emu_shard_exchange) and held against toypathtracer_amd/sharding.py, whose
+    gather the gloo tests above run for real at world sizes 2 / 3 / 8.  Uneven heights, ranks without rows, 1 rank included."""
+    import ctypes as C
+    from toypathtracer_amd import sharding
+    fn = emu.emu_shard_exchange
+    fn.restype = C.c_longlong
+    fn.argtypes = [C.c_int] * 5 + [C.c_ulonglong, C.c_void_p, C.c_void_p, C.c_void_p]
+    image = np.full(h * w, -7, np.int64)
+    info = np.zeros(4, np.int64)
+    rowmap = np.zeros(h, np.int64)
+    frames = 5
+    assert fn(w, h, stripe, world, 4, frames, image.ctypes.data, info.ctypes.data, rowmap.ctypes.data) == 0
+    assert np.array_equal(image, np.arange(h * w))                       # every pixel found its way home
+    pad = int(info[0])                                                   # the equal-count gather's tile height: whole stripes,
+    tallest = sharding.padded_rows(h, stripe, world)                     # at least the tallest rank's rows (the twin pads to exactly that)
+    assert pad % stripe == 0 and tallest <= pad < tallest + stripe
+    assert int(info[1]) == sum((r + 1) * 1000003 + frames + (1 << 40) for r in range(world))  # 64-bit counters, exact
+    assert int(info[2]) == frames % 4                                    # snapshot ring slot
+    want = np.empty(h, np.int64)                                         # ShardedFrame.rowmap: row of the flattened receive buffer
+    for p in range(world):
+        g = sharding.local_to_global_rows(h, stripe, world, p)
+        assert len(g) == sharding.local_row_count(h, stripe, world, p)
+        want[g] = p * (pad + 1) + np.arange(len(g))
+    assert np.array_equal(rowmap, want)

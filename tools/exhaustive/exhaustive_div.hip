@@ -1,4 +1,4 @@
-// tools/exhaustive/exhaustive_div.hip -- experiment harness (not product), WRITTEN IN ROUND 3, NOT YET RUN (no GPU time left):
+// tools/exhaustive/exhaustive_div.hip -- experiment harness (not product), written in round 3, run in round 4 (profiles/r04/r04_div.log):
 // candidate short sequences for the correctly rounded binary32 quotient a / b against hipcc's IEEE expansion
 // (v_div_scale x 2, v_rcp, 5 fma, v_div_fmas, v_div_fixup: ~10 VALU instructions, 11 sites in tptTraceQueueKernel).
 //
@@ -52,6 +52,8 @@ __device__ __forceinline__ float divV3(float a, float b, float y0)
 struct Result {
     unsigned long long bad[3];
     unsigned firstA[3], firstB[3];
+    unsigned badB[3];        // how many significands of b have at least one failing a
+    unsigned listB[3][16];   // the first few of them (is the failure set a handful of b's a guard could name?)
 };
 
 // one thread per significand of b; a walks all 2^23 significands of [1, 2)
@@ -75,6 +77,8 @@ __global__ void __launch_bounds__(256) divKernel(uint32_t firstB, uint32_t count
     for (int v = 0; v < 3; ++v)
         if (bad[v]) {
             if (atomicAdd(&out->bad[v], bad[v]) == 0ull) { out->firstA[v] = fa[v]; out->firstB[v] = mb; }
+            const unsigned k = atomicAdd(&out->badB[v], 1u);
+            if (k < 16u) out->listB[v][k] = mb;
         }
 }
 
@@ -100,7 +104,10 @@ int main(int argc, char** argv)
     const char* names[3] = {"V1 (4 instr)", "V2 (6 instr, Markstein)", "V3 (8 instr)"};
     for (int v = 0; v < 3; ++v) {
         printf("%-26s mismatches %llu", names[v], h.bad[v]);
-        if (h.bad[v]) printf("  (first: a = 0x%08x b = 0x%08x)", 0x3f800000u | h.firstA[v], 0x3f800000u | h.firstB[v]);
+        if (h.bad[v]) {
+            printf("  (first: a = 0x%08x b = 0x%08x); %u significands of b affected:", 0x3f800000u | h.firstA[v], 0x3f800000u | h.firstB[v], h.badB[v]);
+            for (unsigned k = 0; k < h.badB[v] && k < 16u; ++k) printf(" %06x", h.listB[v][k]);
+        }
         printf("\n");
     }
     return 0;

@@ -29,16 +29,20 @@ class TptError(RuntimeError):
     pass
 
 
-_lib = None
+_lib = None        # the library the module's functions currently talk to
+_product = None    # libtoypathtracer_hip.so
+_hooks = None      # libtoypathtracer_hip_hooks.so (the same sources + include/tpt_test_hooks.h), loaded by using_hooks()
 
 # every symbol include/tpt_hip.h declares (checked by tests/test_abi.py)
 C_ABI_SYMBOLS = [
     "tptInitialize", "tptShutdown", "tptUpdate", "tptDraw", "tptGetObjectCount", "tptGetSceneDesc",
     "tptSetSamplesPerPixel", "tptSetConfig", "tptSetSeedMode", "tptSetFoldMode", "tptSetScene", "tptSetCamera", "tptSetStream",
     "tptSetRowShard", "tptLocalRowCount", "tptLocalRowToGlobal", "tptDrawDevice", "tptRayCounterRead", "tptSetRayCounter", "tptSetFrameOverlap", "tptDisplayRGBA8", "tptKernelTimingBegin", "tptKernelTimingEnd",
-    "tptSynchronize", "tptTimerBegin", "tptTimerEnd", "tptSetKernelVariant", "tptTestMath", "tptTestMathExhaustive", "tptTestHitSpheres",
-    "tptDrawDeviceBatch", "tptDrawShardedBatch", "tptDebugLookaheadHits", "tptCommGetUniqueId", "tptCommInit", "tptCommInitLoopback", "tptCommDestroy", "tptDrawSharded", "tptShardedFinish", "tptGetLaunchInfo", "tptGetPipelineInfo", "tptSetHostBufferMode", "tptSetHostLookahead", "tptSetStreamBatching", "tptTestMatrixFilter", "tptSetTileMirror", "tptGetLastError", "tptGetDeviceName", "tptDebugStats", "tptDebugChunkOrder",
+    "tptSynchronize", "tptTimerBegin", "tptTimerEnd", "tptSetKernelVariant",
+    "tptDrawDeviceBatch", "tptDrawShardedBatch", "tptGetLookaheadHits", "tptCommGetUniqueId", "tptCommInit", "tptCommInitLoopback", "tptCommInfo", "tptCommDestroy", "tptDrawSharded", "tptShardedFinish", "tptGetLaunchInfo", "tptGetPipelineInfo", "tptSetHostBufferMode", "tptSetHostLookahead", "tptSetStreamBatching", "tptSetTileMirror", "tptGetLastError", "tptGetDeviceName",
 ]
+# include/tpt_test_hooks.h: exported by the second build (libtoypathtracer_hip_hooks.so) only
+HOOK_SYMBOLS = ["tptTestMath", "tptTestMathExhaustive", "tptTestHitSpheres", "tptTestMatrixFilter", "tptDebugStats", "tptDebugChunkOrder"]
 # the reference's own C++ symbols (nm of the compiled Test.cpp), exported for link-level drop-in
 CXX_ABI_SYMBOLS = [
     "_Z14InitializeTestv", "_Z12ShutdownTestv", "_Z10UpdateTestfiiij", "_Z8DrawTestfiiiPfRij",
@@ -51,22 +55,12 @@ def library_path():
     return os.environ.get("TPT_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtoypathtracer_hip.so")
 
 
-def load_library():
-    """dlopen the HIP library (built by __graft_entry__.build() / csrc/build.sh). Fails loudly."""
-    global _lib
-    if _lib is not None:
-        return _lib
-    # one hardware queue per in-flight trace kernel (the runtime's default of 4 serialises deeper frame pipelining);
-    # must be in the environment before the HIP runtime initialises
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
-    try:  # torch ships its own HIP runtime: load it first so both sides share one libamdhip64 in the process
-        import torch  # noqa: F401
-    except ImportError:
-        pass
-    path = library_path()
-    if not os.path.exists(path):
-        raise TptError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-                       "(toypathtracer_amd/csrc/build.sh). There is no CPU fallback.")
+def hooks_library_path():
+    # (a profiling build selected with TPT_LIB carries the hooks itself: tools/build_variant.sh passes -DTPT_TEST_HOOKS)
+    return os.environ.get("TPT_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtoypathtracer_hip_hooks.so")
+
+
+def _bind(path, hooks):
     lib = C.CDLL(path)
     i, f, u, p = C.c_int, C.c_float, C.c_uint, C.c_void_p
     sigs = {
@@ -79,16 +73,85 @@ def load_library():
         "tptSetRayCounter": [p], "tptSetTileMirror": [p, p], "tptSetFrameOverlap": [i], "tptDisplayRGBA8": [p, i, i, p], "tptKernelTimingBegin": [i],
         "tptKernelTimingEnd": [C.POINTER(f), C.POINTER(i)],
         "tptSynchronize": [], "tptTimerBegin": [], "tptTimerEnd": [C.POINTER(f)], "tptSetKernelVariant": [i, i, i],
-        "tptDebugStats": [p, i], "tptDebugChunkOrder": [p, p, i], "tptTestMath": [i, p, p, p, i], "tptTestMathExhaustive": [i, u, u, p, p], "tptTestHitSpheres": [i, p, p, p, i], "tptTestMatrixFilter": [p, p, p, p, i], "tptGetLaunchInfo": [C.POINTER(i)] * 4, "tptGetPipelineInfo": [C.POINTER(i)] * 4, "tptCommGetUniqueId": [p], "tptCommInit": [p, i, i, i], "tptCommInitLoopback": [i, i], "tptCommDestroy": [], "tptDrawSharded": [f, i, i, i, p, u], "tptDrawShardedBatch": [f, i, i, i, i, p, u], "tptDrawDeviceBatch": [f, i, i, i, i, p, u], "tptShardedFinish": [C.POINTER(C.c_int64)], "tptSetHostBufferMode": [i], "tptDebugLookaheadHits": [C.POINTER(C.c_longlong)], "tptSetHostLookahead": [i], "tptSetStreamBatching": [i],
+        "tptGetLaunchInfo": [C.POINTER(i)] * 4, "tptGetPipelineInfo": [C.POINTER(i)] * 4, "tptCommGetUniqueId": [p], "tptCommInit": [p, i, i, i], "tptCommInitLoopback": [i, i], "tptCommInfo": [C.POINTER(i)] * 3, "tptCommDestroy": [], "tptDrawSharded": [f, i, i, i, p, u], "tptDrawShardedBatch": [f, i, i, i, i, p, u], "tptDrawDeviceBatch": [f, i, i, i, i, p, u], "tptShardedFinish": [C.POINTER(C.c_int64)], "tptSetHostBufferMode": [i], "tptGetLookaheadHits": [C.POINTER(C.c_longlong)], "tptSetHostLookahead": [i], "tptSetStreamBatching": [i],
     }
+    if hooks:
+        sigs.update({"tptDebugStats": [p, i], "tptDebugChunkOrder": [p, p, i], "tptTestMath": [i, p, p, p, i], "tptTestMathExhaustive": [i, u, u, p, p],
+                     "tptTestHitSpheres": [i, p, p, p, i], "tptTestMatrixFilter": [p, p, p, p, i]})
     for name, args in sigs.items():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = i
     lib.tptGetLastError.restype = C.c_char_p
     lib.tptGetDeviceName.restype = C.c_char_p
-    _lib = lib
     return lib
+
+
+def _preload():
+    # one hardware queue per in-flight trace kernel (the runtime's default of 4 serialises deeper frame pipelining);
+    # must be in the environment before the HIP runtime initialises
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+    try:  # torch ships its own HIP runtime: load it first so both sides share one libamdhip64 in the process
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
+def load_library():
+    """dlopen the HIP library (built by __graft_entry__.build() / csrc/build.sh). Fails loudly."""
+    global _lib, _product
+    if _lib is not None:
+        return _lib
+    _preload()
+    path = library_path()
+    if not os.path.exists(path):
+        raise TptError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(toypathtracer_amd/csrc/build.sh). There is no CPU fallback.")
+    _product = _bind(path, hooks=bool(os.environ.get("TPT_LIB")) and _has_hooks(path))
+    _lib = _product
+    return _lib
+
+
+def _has_hooks(path):
+    try:
+        return hasattr(C.CDLL(path), "tptTestMath")
+    except OSError:
+        return False
+
+
+class using_hooks:
+    """Context manager: inside it every function of this module talks to the HOOKS build of the library
+    (libtoypathtracer_hip_hooks.so: the same sources plus the unit-test entry points of include/tpt_test_hooks.h), which is
+    initialised on first use and has its own context -- scene, knobs and pipeline are separate from the product library's.
+    Used by the GPU suite for math / HitSpheres / filter unit tests; every render test runs on the product library."""
+
+    def __enter__(self):
+        global _lib, _hooks
+        load_library()
+        if _hooks is None:
+            path = hooks_library_path()
+            if path == library_path():
+                _hooks = _product
+            else:
+                if not os.path.exists(path):
+                    raise TptError(f"{path} is missing (toypathtracer_amd/csrc/build.sh builds it beside the product library)")
+                _hooks = _bind(path, hooks=True)
+        self._prev = _lib
+        _lib = _hooks
+        _chk(_lib.tptInitialize(), "tptInitialize (hooks build)")
+        return self
+
+    def __exit__(self, *exc):
+        global _lib
+        _lib = self._prev
+        return False
+
+
+def shutdown_hooks():
+    global _hooks
+    if _hooks is not None and _hooks is not _product:
+        _hooks.tptShutdown()
+    _hooks = None
 
 
 def _chk(rc, where):
@@ -285,6 +348,13 @@ def comm_init_loopback(n_ranks, stripe_rows=8):
     _chk(load_library().tptCommInitLoopback(n_ranks, stripe_rows), "tptCommInitLoopback")
 
 
+def comm_info():
+    """(ranks, rank, loopback) as the communicator itself reports them (ncclCommCount / ncclCommUserRank)"""
+    v = [C.c_int() for _ in range(3)]
+    _chk(load_library().tptCommInfo(*[C.byref(x) for x in v]), "tptCommInfo")
+    return v[0].value, v[1].value, bool(v[2].value)
+
+
 def comm_destroy():
     _chk(load_library().tptCommDestroy(), "tptCommDestroy")
 
@@ -322,7 +392,7 @@ def set_stream_batching(enable):
 
 def lookahead_hits():
     v = C.c_longlong()
-    _chk(load_library().tptDebugLookaheadHits(C.byref(v)), "tptDebugLookaheadHits")
+    _chk(load_library().tptGetLookaheadHits(C.byref(v)), "tptGetLookaheadHits")
     return v.value
 
 

@@ -9,9 +9,13 @@
 // There is deliberately NO CPU rendering path in this library: if HIP is unavailable every entry
 // point fails loudly.
 #include "../../include/tpt_hip.h"
+#if defined(TPT_TEST_HOOKS)
+#include "../../include/tpt_test_hooks.h" // unit-test / profiling entry points: the second build only (csrc/build.sh)
+#endif
 #include "../../include/tpt_test_api.h"
 #include "tpt_device.h"
 #include "tpt_scene.h"
+#include "tpt_shard.h"
 #include <hip/hip_runtime.h>
 #include <thread>
 #include <rccl/rccl.h> // types and prototypes only: the library is dlopen()ed when tptCommInit is called
@@ -43,6 +47,8 @@ struct Context {
     static const int kOrderTables = kMaxSlots + 2;  // rotating chunk-order tables: more than frames in flight
     bool inited = false;
     int device = 0, numCUs = 0;
+    int reservedCUs = 0;   // CUs the trace streams' CU mask leaves to the blend / assemble / copy kernels (tptInitialize)
+    int traceCUs = 0;      // numCUs - reservedCUs: what a trace launch can occupy
     std::string deviceName, err;
     hipStream_t ownStream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -71,6 +77,7 @@ struct Context {
         size_t offGPairs = 0, offGSph = 0, offGId = 0, offBSph = 0, offBId = 0; // grouped representation (large scenes)
         size_t offAmat = 0; // matrix-core filter table (small scenes)
         int mxR1 = -1;
+        int flags = 0;
         int nSpheres = 0, nPairs = 0, nLights = 0;
         int nGroups = 0, nGroupPairs = 0, nBig = 0;
         hipEvent_t evUploaded = nullptr;
@@ -109,6 +116,7 @@ struct Context {
     f4* dStack[kMaxSlots] = {};         // recursive fold: global bounce stacks / spill levels (one per trace stream: the first kMaxOverlap entries)
     size_t stackCap = 0, colourCap = 0, pathCap = 0; // bytes per slot; all reserved slots have the same capacities
     int slotsReserved = 0;              // slots [0, slotsReserved) hold buffers of those capacities
+    int smallStreak = 0;                // consecutive launches that needed a quarter of the reserved colour slot or less (reserveSlotBuffers)
     int slotReservations = 0;           // how often the slot buffers were (re-)allocated (tptGetPipelineInfo)
     // cost-ordered chunk distribution (persistent kernel)
     unsigned* dChunkCost = nullptr;
@@ -150,6 +158,15 @@ struct Context {
         TraceTicket T;
         int counterBase = 0;
     } rsb[2];
+    struct HostCaller { // tptDraw: are the calls consecutive frames of one configuration?  (gates the row-serial batches)
+        int frame = 0, w = 0, h = 0, streak = 0;
+        unsigned flags = 0;
+        unsigned long long key = 0;
+        // a configuration whose batched launch was refused (frame too large for a batch, not enough device memory): served frame
+        // by frame from then on instead of failing (or retrying the reservation) on every call
+        int refusedW = 0, refusedH = 0;
+        unsigned long long refusedKey = 0;
+    } hostCaller;
     unsigned long long* dRaysBatch = nullptr; // [2][kMaxBatch] per-frame ray counters of those two batches
     // Streaming callers of tptDrawDevice / tptDrawSharded with SMALL frames (tiles of a sharded frame, 640x360): a launch cannot
     // be shorter than its longest pixel's sequential samples, so frame by frame such callers are bound by launch latency, not
@@ -167,7 +184,7 @@ struct Context {
     static const int kStreamBatchMax = 8, kStreamRing = 64;
     unsigned long long* dRaysStream = nullptr; // [kStreamRing][kStreamBatchMax]
     unsigned long long streamBatches = 0;       // batches launched (ring index)
-    int streamBatch = 0;                        // tptSetStreamBatching(1) / env TPT_STREAM_BATCH=1: on (opt-in)
+    int streamBatch = 1;                        // on by default since round 4; tptSetStreamBatching(0) / env TPT_STREAM_BATCH=0 turn it off
     // tptDrawDevice: is the caller synchronous (the previous frame's blend has completed by the time the next call arrives)
     // and are its calls consecutive frames of one configuration?  Then the next frames are traced ahead for it too.
     struct DeviceCaller {
@@ -176,7 +193,7 @@ struct Context {
         unsigned long long key = 0;
         int syncStreak = 0, seqStreak = 0;
     } devCaller;
-    long long aheadHits = 0;            // frames that were found traced ahead when their call arrived (tptDebugLookaheadHits)
+    long long aheadHits = 0;            // frames that were found traced ahead when their call arrived (tptGetLookaheadHits)
     unsigned long long* dRaysAhead = nullptr; // [kMaxSlots] per-slot ray counters of frames traced ahead of their call (both synchronous paths)
     unsigned long long configEpoch = 1;       // bumped by every call that changes what a frame looks like
 
@@ -199,6 +216,8 @@ struct Context {
         decltype(&ncclCommInitRank) CommInitRank = nullptr;
         decltype(&ncclCommDestroy) CommDestroy = nullptr;
         decltype(&ncclGather) Gather = nullptr;
+        decltype(&ncclCommCount) CommCount = nullptr;
+        decltype(&ncclCommUserRank) CommUserRank = nullptr;
         decltype(&ncclGetErrorString) GetErrorString = nullptr;
     } shard;
     size_t frameCap = 0;
@@ -251,22 +270,8 @@ int hipFail(hipError_t e, const char* what)
         if (_e != hipSuccess) return hipFail(_e, #x); \
     } while (0)
 
-int localRows(int h)
-{
-    if (g.numParts <= 1 || g.stripeRows <= 0) return h;
-    const int S = g.stripeRows, stride = S * g.numParts, off = S * g.part;
-    int full = h / stride, rem = h % stride;
-    int rows = full * S;
-    int extra = rem - off;
-    if (extra > 0) rows += extra < S ? extra : S;
-    return rows;
-}
-int localToGlobal(int ly)
-{
-    if (g.numParts <= 1 || g.stripeRows <= 0) return ly;
-    const int S = g.stripeRows;
-    return (ly / S) * S * g.numParts + S * g.part + (ly % S);
-}
+int localRows(int h) { return shardLocalRows(h, g.stripeRows, g.numParts, g.part); }          // (tpt_shard.h)
+int localToGlobal(int ly) { return shardLocalToGlobal(ly, g.stripeRows, g.numParts, g.part); }
 
 template <class T>
 int ensureDev(T*& p, int& cap, int need)
@@ -343,6 +348,7 @@ int stageScene()
     S.bytes = offAmat + bAmat;
     S.offAmat = offAmat;
     S.mxR1 = bAmat ? P.mxR1 : -1;
+    S.flags = P.flags;
     S.offSph4 = offSph4; S.offInvR = offInvR; S.offMats = offMats; S.offLights = offLights;
     S.offGPairs = offGPairs; S.offGSph = offGSph; S.offGId = offGId; S.offBSph = offBSph; S.offBId = offBId;
     S.nSpheres = P.nSpheres; S.nPairs = P.nPairs; S.nLights = P.nLights;
@@ -383,6 +389,7 @@ SceneView deviceView()
     sv.nBig = S->nBig;
     sv.amatH = reinterpret_cast<const uint32_t*>(S->dev + S->offAmat);
     sv.mxR1 = S->mxR1;
+    sv.flags = S->flags;
     return sv;
 }
 
@@ -494,6 +501,46 @@ int probeHardwareQueues()
     return 0;
 }
 
+// The trace streams.  Their kernels are persistent workgroups that fill every CU they may use for the whole frame; the short
+// kernels of the ordered chain behind them (blend, snapshot, assemble, display) then wait for a workgroup slot to come free --
+// 6 us of work took 52-137 us (profiles/r03).  With TPT_RESERVE_CUS = n > 0 the trace streams are created with a CU mask
+// (hipExtStreamCreateWithCUMask) that leaves n CUs -- spread evenly over the XCDs: bit i of the mask is CU i / 8 of XCD i % 8,
+// tools/probes/cumask_probe.hip -- to everything else; grids are sized for the CUs that remain.
+int createTraceStreams()
+{
+    int reserve = 0;
+    if (const char* e = getenv("TPT_RESERVE_CUS")) reserve = atoi(e);
+    if (reserve < 0) reserve = 0;
+    if (reserve > g.numCUs / 2) reserve = g.numCUs / 2;
+    const int mode = getenv("TPT_RESERVE_MODE") ? atoi(getenv("TPT_RESERVE_MODE")) : 0;
+    g.reservedCUs = 0;
+    g.traceCUs = g.numCUs;
+    if (reserve > 0) {
+        const int words = (g.numCUs + 31) / 32;
+        std::vector<uint32_t> mask((size_t)words, 0xffffffffu);
+        if (g.numCUs % 32) mask[(size_t)words - 1] = (1u << (g.numCUs % 32)) - 1u;
+        for (int i = 0; i < reserve; ++i) {
+            // mode 0: the lowest bits; mode 1: one bit per 32-bit word in turn; mode 2: the highest bits
+            const int bit = mode == 1 ? (i % words) * 32 + i / words : (mode == 2 ? g.numCUs - 1 - i : i);
+            mask[(size_t)bit / 32] &= ~(1u << (bit % 32));
+        }
+        bool ok = true;
+        for (int k = 0; k < Context::kMaxOverlap && ok; ++k) ok = hipExtStreamCreateWithCUMask(&g.traceStream[k], (uint32_t)words, mask.data()) == hipSuccess;
+        if (ok) {
+            g.reservedCUs = reserve;
+            g.traceCUs = g.numCUs - reserve;
+            return 0;
+        }
+        (void)hipGetLastError();
+        for (int k = 0; k < Context::kMaxOverlap; ++k) {
+            if (g.traceStream[k]) (void)hipStreamDestroy(g.traceStream[k]);
+            g.traceStream[k] = nullptr;
+        }
+    }
+    for (int k = 0; k < Context::kMaxOverlap; ++k) HIPCHK(hipStreamCreateWithFlags(&g.traceStream[k], hipStreamNonBlocking));
+    return 0;
+}
+
 } // namespace
 
 extern "C" {
@@ -524,7 +571,15 @@ int tptInitialize(void)
     g.device = dev;
     g.numCUs = prop.multiProcessorCount;
     g.deviceName = std::string(prop.name) + " (" + prop.gcnArchName + ")";
-    HIPCHK(hipStreamCreateWithFlags(&g.ownStream, hipStreamNonBlocking));
+    // The context's own stream -- the ordered chain that touches the CALLER's device buffers (blend into the tile, mirror and
+    // counter snapshot, display conversion) -- is a BLOCKING stream: HIP then orders it against the legacy default stream in
+    // both directions, like any library that "works on the default stream".  A host that fills its tile with hipMemset / a
+    // torch op on the default stream and calls tptDrawDevice straight away is ordered (the blend waits for the fill), and so is
+    // a host that reads the tile from the default stream after the call.  (Round 3 had it non-blocking: a fill still queued
+    // behind earlier GPU work landed AFTER the library's writes.)  The trace streams stay non-blocking: their kernels write
+    // only the library's own colour slots, and nothing the caller does on the default stream may serialise them.  A caller
+    // that hands over its own stream (tptSetStream) gets everything enqueued there instead.
+    HIPCHK(hipStreamCreateWithFlags(&g.ownStream, hipStreamDefault));
     g.stream = g.ownStream;
     HIPCHK(hipEventCreateWithFlags(&g.evOrder, kOrderingEvent));
     g.orderDone = true;
@@ -534,7 +589,10 @@ int tptInitialize(void)
     // (memsets go to the stream that orders them against the first kernels: every stream of this context is
     //  non-blocking, the legacy null stream would order nothing)
     HIPCHK(hipMemsetAsync(g.dWork, 0, 64 * Context::kMaxSlots, g.stream));
-    for (int k = 0; k < Context::kMaxOverlap; ++k) HIPCHK(hipStreamCreateWithFlags(&g.traceStream[k], hipStreamNonBlocking));
+    {
+        int rc = createTraceStreams();
+        if (rc) return rc;
+    }
     for (int k = 0; k < Context::kMaxSlots; ++k) {
         HIPCHK(hipEventCreateWithFlags(&g.evTrace[k], kOrderingEvent));
         HIPCHK(hipEventCreateWithFlags(&g.evResolve[k], kOrderingEvent));
@@ -551,7 +609,7 @@ int tptInitialize(void)
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dRaysStream), sizeof(unsigned long long) * Context::kStreamRing * Context::kStreamBatchMax));
     HIPCHK(hipMemsetAsync(g.dRaysStream, 0, sizeof(unsigned long long) * Context::kStreamRing * Context::kStreamBatchMax, g.stream));
     g.sbatch.used = false;
-    if (const char* esb = getenv("TPT_STREAM_BATCH")) g.streamBatch = atoi(esb) != 0; // (opt-in)
+    if (const char* esb = getenv("TPT_STREAM_BATCH")) g.streamBatch = atoi(esb) != 0; // (default on)
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dRaysBatch), sizeof(unsigned long long) * 2 * kMaxBatch));
     HIPCHK(hipMemsetAsync(g.dRaysBatch, 0, sizeof(unsigned long long) * 2 * kMaxBatch, g.stream));
     g.rsb[0].used = g.rsb[1].used = false;
@@ -756,6 +814,9 @@ int tptSetFrameOverlap(int frames)
 
 int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene)
 {
+    if (hitSpheres < 0 || hitSpheres > 3) return fail("tptSetKernelVariant: hitSpheres 0 (two-phase) 1 (simple) 2 (two-phase, no groups) 3 (two-phase, VALU filter)");
+    if (persistent != 1 && persistent != 3)
+        return fail("tptSetKernelVariant: persistent 3 (path queues, the default) or 1 (lane refill); the thread-per-pixel (0) and lane-sorting (2) kernels were removed in round 3");
     g.hs = hitSpheres == 1 ? HS_SIMPLE : HS_TWO_PHASE;
     const int allow = hitSpheres == 2 ? 0 : 1, matrix = hitSpheres == 3 ? 0 : 1; // 3: the packed VALU filter everywhere (no matrix-core table)
     if (allow != g.allowGroups || matrix != g.useMatrix) {
@@ -763,7 +824,7 @@ int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene)
         g.useMatrix = matrix;
         g.sceneDirty = true; // the staged scene set carries (or not) the grouped arrays / the matrix table
     }
-    g.persist = persistent == 1 ? 1 : 3; // 3 = path queues (default), 1 = lane-refill kernel; the experimental variants 0 and 2 are gone
+    g.persist = persistent; // 3 = path queues (default), 1 = lane-refill kernel
     g.configEpoch++;
     g.ldsScene = ldsScene < 0 ? -1 : (ldsScene ? 1 : 0);
     return 0;
@@ -875,7 +936,12 @@ int reserveSlotBuffers(int nSlots, size_t colourBytes, size_t stackBytes, size_t
 { // (stack / path buffers are used while the kernel runs only: indexed by stream, allocated for the first kMaxOverlap slots)
     // Memory that a large batched frame pinned is given back when the caller returns to frames a quarter of that size and more
     // than 1 GiB of colour slots is held (one drain, like a growth); anything smaller stays (no churn between similar shapes).
-    const bool shrink = colourBytes * 4 <= g.colourCap && g.colourCap * (size_t)g.slotsReserved > (1ull << 30);
+    // ... and only after 8 launches in a row were that small: a caller that alternates large batches with a small tail chunk
+    // (33..40 frames through tptDrawDeviceBatch: 32 + 1..8) must not free and re-allocate gigabytes on every call.
+    const bool small = colourBytes * 4 <= g.colourCap && g.colourCap * (size_t)g.slotsReserved > (1ull << 30);
+    g.smallStreak = small ? g.smallStreak + 1 : 0;
+    const bool shrink = small && g.smallStreak >= 8;
+    if (shrink) g.smallStreak = 0;
     if (!shrink && nSlots <= g.slotsReserved && colourBytes <= g.colourCap && stackBytes <= g.stackCap && pathBytes <= g.pathCap) return 0;
     int rc = syncAllStreams();
     if (rc) return rc;
@@ -980,7 +1046,7 @@ void sizeGrid(FramePlan& P)
     KernelArgs& a = P.a;
     int occUse = P.occ;
     if (g.maxBlocksPerCU > 0 && g.maxBlocksPerCU < occUse) occUse = g.maxBlocksPerCU;
-    const int resident = g.numCUs * occUse; // workgroups that can be co-resident
+    const int resident = g.traceCUs * occUse; // workgroups that can be co-resident (on the CUs the trace streams may use)
     const int wavesPerBlock = P.threadsPerBlock / 64;
     int chunk = P.rowSerial ? 1 : TPT_CHUNK_PIXELS;
     // small frames: hand out single 8x8 tiles so every resident wave gets several chunks
@@ -999,7 +1065,7 @@ void sizeGrid(FramePlan& P)
         // the same rate whether 8 or 64 of its lanes are alive, so the items are dealt out over as many waves as there are
         // SIMDs (4 per CU), at least 4 lanes each.
         // (k launches in flight -- the deepest pipeline this caller has built so far -- share the SIMDs: k times the lanes)
-        const int simds = g.numCUs * 4, k = g.depthOverride > 0 ? g.depthOverride : (g.streamDepth > 1 ? g.streamDepth : 1);
+        const int simds = g.traceCUs * 4, k = g.depthOverride > 0 ? g.depthOverride : (g.streamDepth > 1 ? g.streamDepth : 1);
         int cap = (int)(((long long)a.numChunks * k + simds - 1) / simds);
         cap = cap < 4 ? 4 : (cap > 64 ? 64 : cap);
         a.laneCap = cap;
@@ -1051,7 +1117,7 @@ int maxGridBlocks(const FramePlan& P)
 {
     const KernelArgs& a = P.a;
     const int wavesPerBlock = P.threadsPerBlock / 64;
-    const int resident = g.numCUs * P.occ;
+    const int resident = g.traceCUs * P.occ;
     const int minChunk = P.rowSerial ? 1 : 64;
     const int byWork = (((a.numItems + minChunk - 1) / minChunk) * P.batch + wavesPerBlock - 1) / wavesPerBlock;
     int m = resident < byWork ? resident : byWork;
@@ -1599,33 +1665,54 @@ int tptDraw(float time, int frameCount, int w, int h, float* backbuffer, int* ou
     int raySlot = -1;
     const unsigned long long* rayPtr = nullptr;
     bool servedFromBatch = false;
-    if (g.seedMode == SEED_ROW_SERIAL && stable && pipelined && !sharded && g.lookahead > 0 && rows > 0 && !g.mirror) {
-        // ---- 1r. the reference's own seed mode: this frame and the 31 after it as ONE launch (rows x frames lanes), the batch
-        //          after that one launched as soon as this one starts being served (a wrong guess costs GPU time only)
+    Context::HostCaller& HC = g.hostCaller;
+    HC.streak = (frameCount == HC.frame + 1 && w == HC.w && h == HC.h && testFlags == HC.flags && key == HC.key) ? HC.streak + 1 : 0;
+    HC.frame = frameCount; HC.w = w; HC.h = h; HC.flags = testFlags; HC.key = key;
+    const bool batchRefused = HC.refusedKey == key && HC.refusedW == w && HC.refusedH == h;
+    if (g.seedMode == SEED_ROW_SERIAL && stable && pipelined && !sharded && g.lookahead > 0 && rows > 0 && !g.mirror && !batchRefused) {
+        // ---- 1r. the reference's own seed mode: a frame alone is `rows` lanes of work, so the frames AHEAD are traced as one
+        //          launch (rows x frames lanes) and served one by one.  A batch is 32 frames of GPU work for one delivered
+        //          frame, so it is only launched for a caller that has shown its pattern -- the third consecutive frame of one
+        //          configuration (a one-shot DrawTest, or a host that jumps about, takes the plain path below) -- and the batch
+        //          after it only once the first one has been hit.  A batch the pipeline refuses (frame wider than 8192, over 4 GiB
+        //          of colour planes, not enough device memory) is retried at half the size, down to 2 frames; if nothing fits
+        //          the configuration is served frame by frame: DrawTest never fails because of the look-ahead.
         auto matches = [&](const Context::RowSerialBatch& B) {
             return B.used && B.w == w && B.h == h && B.flags == testFlags && B.key == key && frameCount == B.firstFrame + B.next;
         };
         auto launch = [&](int which, int firstFrame) -> int {
             Context::RowSerialBatch& B = g.rsb[which];
             B.used = false;
-            B.firstFrame = firstFrame; B.n = kMaxBatch; B.next = 0; B.w = w; B.h = h; B.flags = testFlags; B.key = key;
             // (two banks of per-frame counters; the batch being served keeps its bank when it moves from [1] to [0])
-            B.counterBase = (which == 1 && g.rsb[0].used && g.rsb[0].counterBase == 0) ? kMaxBatch : 0;
-            int rc = enqueueTrace(firstFrame, w, h, testFlags, g.dRaysBatch + B.counterBase, B.T, B.n, 1);
-            if (rc) return rc;
-            B.used = B.T.valid;
+            const int bank = (which == 1 && g.rsb[0].used && g.rsb[0].counterBase == 0) ? kMaxBatch : 0;
+            for (int n = kMaxBatch; n >= 2; n /= 2) {
+                if (w > 8192 || h > 8192 || (long long)rows * w * n > (1ll << 30) || (unsigned long long)rows * w * 16ull * n > (4ull << 30)) continue;
+                B.firstFrame = firstFrame; B.n = n; B.next = 0; B.w = w; B.h = h; B.flags = testFlags; B.key = key;
+                B.counterBase = bank;
+                if (enqueueTrace(firstFrame, w, h, testFlags, g.dRaysBatch + B.counterBase, B.T, B.n, 1) == 0) {
+                    B.used = B.T.valid;
+                    return 0;
+                }
+            }
+            HC.refusedKey = key; HC.refusedW = w; HC.refusedH = h; // nothing fits: frame by frame from here on
             return 0;
         };
-        if (!matches(g.rsb[0])) {
-            int rc = discardLookahead();
-            if (rc) return rc;
-            if ((rc = launch(0, frameCount))) return rc;
-        } else {
+        if (matches(g.rsb[0])) {
             g.aheadHits++;
+        } else {
+            if (g.rsb[0].used || g.rsb[1].used) {
+                int rc = discardLookahead();
+                if (rc) return rc;
+            }
+            if (HC.streak >= 2) {
+                int rc = discardLookahead();
+                if (rc) return rc;
+                if ((rc = launch(0, frameCount))) return rc;
+            }
         }
         Context::RowSerialBatch& B = g.rsb[0];
         if (B.used) {
-            if (B.next == 0 && !g.rsb[1].used) {
+            if (B.next >= 1 && !g.rsb[1].used && !(HC.refusedKey == key && HC.refusedW == w && HC.refusedH == h)) {
                 int rc = launch(1, B.firstFrame + B.n);
                 if (rc) return rc;
             }
@@ -1788,7 +1875,10 @@ int loadRccl()
     S.CommDestroy = reinterpret_cast<decltype(S.CommDestroy)>(dlsym(S.lib, "ncclCommDestroy"));
     S.Gather = reinterpret_cast<decltype(S.Gather)>(dlsym(S.lib, "ncclGather"));
     S.GetErrorString = reinterpret_cast<decltype(S.GetErrorString)>(dlsym(S.lib, "ncclGetErrorString"));
-    if (!S.GetUniqueId || !S.CommInitRank || !S.CommDestroy || !S.Gather || !S.GetErrorString) return fail("tptComm: librccl lacks a needed symbol");
+    S.CommCount = reinterpret_cast<decltype(S.CommCount)>(dlsym(S.lib, "ncclCommCount"));
+    S.CommUserRank = reinterpret_cast<decltype(S.CommUserRank)>(dlsym(S.lib, "ncclCommUserRank"));
+    if (!S.GetUniqueId || !S.CommInitRank || !S.CommDestroy || !S.Gather || !S.GetErrorString || !S.CommCount || !S.CommUserRank)
+        return fail("tptComm: librccl lacks a needed symbol");
     return 0;
 }
 int ncclFail(ncclResult_t r, const char* what)
@@ -1829,7 +1919,7 @@ int startShard(int nRanks, int rank, int stripeRows)
 {
     Context::Shard& S = g.shard;
     S.nRanks = nRanks; S.rank = rank; S.stripeRows = stripeRows; S.frames = 0;
-    HIPCHK(hipStreamCreateWithFlags(&S.commStream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&S.commStream, hipStreamDefault)); // blocking, like the context's own stream: the assemble kernel writes the caller's image
     for (int k = 0; k < Context::Shard::kRing; ++k) {
         HIPCHK(hipEventCreateWithFlags(&S.evSnap[k], kOrderingEvent));
         HIPCHK(hipEventCreateWithFlags(&S.evSent[k], kOrderingEvent));
@@ -1864,6 +1954,23 @@ int tptCommInitLoopback(int nRanks, int stripeRows)
     if (g.shard.active) return fail("tptCommInitLoopback: already initialised (tptCommDestroy first)");
     g.shard.loopback = true;
     return startShard(nRanks, 0, stripeRows);
+}
+
+// What the communicator itself says about its size and this process's rank (ncclCommCount / ncclCommUserRank -- not the
+// arguments tptCommInit was given), and whether it is the loopback stand-in.
+int tptCommInfo(int* outRanks, int* outRank, int* outLoopback)
+{
+    Context::Shard& S = g.shard;
+    if (!S.active) return fail("tptCommInfo: call tptCommInit first");
+    int n = S.nRanks, r = S.rank;
+    if (!S.loopback) {
+        NCCLCHK(S.CommCount(S.comm, &n));
+        NCCLCHK(S.CommUserRank(S.comm, &r));
+    }
+    if (outRanks) *outRanks = n;
+    if (outRank) *outRank = r;
+    if (outLoopback) *outLoopback = S.loopback ? 1 : 0;
+    return 0;
 }
 
 int tptCommDestroy(void)
@@ -1908,33 +2015,32 @@ int tptDrawShardedBatch(float time, int frameCount, int nFrames, int w, int h, f
         int rc = releaseShardBuffers();
         if (rc) return rc;
         HIPCHK(hipStreamSynchronize(g.stream));
-        const int stripes = (h + S.stripeRows - 1) / S.stripeRows;
-        S.padRows = ((stripes + S.nRanks - 1) / S.nRanks) * S.stripeRows; // rank 0 owns the most stripes; whole stripes
+        S.padRows = shardPadRows(h, S.stripeRows, S.nRanks); // rank 0 owns the most stripes; whole stripes
         const size_t rowBytes = (size_t)w * 4 * sizeof(float);
         HIPCHK(hipMalloc(reinterpret_cast<void**>(&S.tile), rowBytes * (size_t)S.padRows));
         HIPCHK(hipMemsetAsync(S.tile, 0, rowBytes * (size_t)S.padRows, g.stream));
         for (int k = 0; k < Context::Shard::kRing; ++k) {
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&S.send[k]), rowBytes * (size_t)(S.padRows + 1)));
-            HIPCHK(hipMemsetAsync(S.send[k], 0, rowBytes * (size_t)(S.padRows + 1), g.stream));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&S.send[k]), shardSnapshotPixels(S.padRows, w) * sizeof(f4)));
+            HIPCHK(hipMemsetAsync(S.send[k], 0, shardSnapshotPixels(S.padRows, w) * sizeof(f4), g.stream));
         }
         if (S.rank == 0) {
-            HIPCHK(hipMalloc(reinterpret_cast<void**>(&S.gathered), rowBytes * (size_t)(S.padRows + 1) * (size_t)S.nRanks));
-            HIPCHK(hipMemsetAsync(S.gathered, 0, rowBytes * (size_t)(S.padRows + 1) * (size_t)S.nRanks, g.stream));
+            HIPCHK(hipMalloc(reinterpret_cast<void**>(&S.gathered), shardSnapshotPixels(S.padRows, w) * sizeof(f4) * (size_t)S.nRanks));
+            HIPCHK(hipMemsetAsync(S.gathered, 0, shardSnapshotPixels(S.padRows, w) * sizeof(f4) * (size_t)S.nRanks, g.stream));
             HIPCHK(hipStreamSynchronize(g.stream)); // the communication stream writes it next
         }
         S.w = w; S.h = h;
     }
-    const int k = (int)(S.frames % Context::Shard::kRing);
+    const int k = shardRingSlot(S.frames, Context::Shard::kRing);
     S.frames++;
     // the snapshot this frame's resolve kernel writes must have left the GPU (gather of the frame that used it last)
     if (S.sentRecorded[k]) HIPCHK(hipStreamWaitEvent(g.stream, S.evSent[k], 0));
-    const size_t tileFloats = (size_t)S.padRows * w * 4;
+    const size_t tileFloats = shardCounterPixel(S.padRows, w) * 4;
     int rc = tptSetTileMirror(S.send[k], S.send[k] + tileFloats); // blended tile -> snapshot, ray counter -> first 8 bytes of the extra row
     if (rc) return rc;
     if ((rc = nFrames > 1 ? tptDrawDeviceBatch(time, frameCount, nFrames, w, h, S.tile, testFlags) : tptDrawDevice(time, frameCount, w, h, S.tile, testFlags))) return rc;
     HIPCHK(hipEventRecord(S.evSnap[k], g.stream));
     HIPCHK(hipStreamWaitEvent(S.commStream, S.evSnap[k], 0));
-    const size_t count = (size_t)(S.padRows + 1) * w * 4;
+    const size_t count = shardSnapshotPixels(S.padRows, w) * 4;
     if (S.loopback) HIPCHK(hipMemcpyAsync(S.gathered, S.send[k], count * sizeof(float), hipMemcpyDeviceToDevice, S.commStream));
     else NCCLCHK(S.Gather(S.send[k], S.gathered, count, ncclFloat32, 0, S.comm, S.commStream));
     if (S.rank == 0) HIPCHK(tptLaunchAssemble(S.gathered, deviceImageOnRoot, w, h, S.stripeRows, S.nRanks, S.padRows, S.commStream));
@@ -1964,21 +2070,21 @@ int tptShardedFinish(int64_t* outTotalRays)
     if (S.rank == 0) {
         for (int r = 0; r < S.nRanks; ++r) {
             unsigned long long v = 0;
-            const char* src = reinterpret_cast<const char*>(S.gathered) + rowBytes * ((size_t)r * (S.padRows + 1) + S.padRows);
+            const char* src = reinterpret_cast<const char*>(S.gathered) + sizeof(f4) * ((size_t)r * shardSnapshotPixels(S.padRows, S.w) + shardCounterPixel(S.padRows, S.w));
             HIPCHK(hipMemcpy(&v, src, sizeof(v), hipMemcpyDeviceToHost));
             total += (long long)v;
         }
     } else {
-        const int k = (int)((S.frames - 1) % Context::Shard::kRing);
+        const int k = shardRingSlot(S.frames - 1, Context::Shard::kRing);
         unsigned long long v = 0;
-        HIPCHK(hipMemcpy(&v, reinterpret_cast<const char*>(S.send[k]) + rowBytes * (size_t)S.padRows, sizeof(v), hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(&v, reinterpret_cast<const char*>(S.send[k]) + sizeof(f4) * shardCounterPixel(S.padRows, S.w), sizeof(v), hipMemcpyDeviceToHost));
         total = (long long)v;
     }
     if (outTotalRays) *outTotalRays = total;
     return 0;
 }
 
-int tptDebugLookaheadHits(long long* outHits)
+int tptGetLookaheadHits(long long* outHits)
 {
     if (outHits) *outHits = g.aheadHits;
     return 0;
@@ -2002,6 +2108,7 @@ int tptGetLaunchInfo(int* outBlocksPerCU, int* outLdsBytes, int* outGridBlocks, 
     return 0;
 }
 
+#if defined(TPT_TEST_HOOKS) // ---- unit-test / profiling entry points (include/tpt_test_hooks.h): not in the product library
 // debugging aid for the cost-ordered work distribution: copies the accumulated per-chunk ray counts and the order
 // table given to the most recent launch (either pointer may be NULL); returns the number of chunks
 int tptDebugChunkOrder(unsigned* outCost, unsigned* outOrder, int capacity)
@@ -2135,6 +2242,8 @@ int tptTestHitSpheres(int hitSpheres, const float* rays, int* outId, float* outT
     (void)hipFree(dr); (void)hipFree(dt); (void)hipFree(di);
     return 0;
 }
+
+#endif // TPT_TEST_HOOKS
 
 } // extern "C"
 

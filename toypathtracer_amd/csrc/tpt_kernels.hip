@@ -21,6 +21,7 @@
 //
 // No MFMA: there is no dense contraction in this path (46-long select/min reduction per lane).
 #include "tpt_device.h"
+#include "tpt_shard.h"
 
 namespace tpt {
 
@@ -45,16 +46,8 @@ __device__ __forceinline__ bool mapItem(const KernelArgs& a, int idx, int& x, in
     ly = ty * 8 + (within >> 3);
     return x < a.fc.width && ly < a.nLocalRows;
 }
-__device__ __forceinline__ int localRowToGlobal(const KernelArgs& a, int ly)
-{
-    return (ly / a.stripeRows) * a.stripeStride + a.stripeOffset + (ly % a.stripeRows);
-}
-
-__device__ __forceinline__ int globalRowToLocal(const KernelArgs& a, int gy) // inverse of localRowToGlobal, for rows of this rank
-{
-    const int q = gy / a.stripeStride;
-    return q * a.stripeRows + (gy - q * a.stripeStride - a.stripeOffset);
-}
+__device__ __forceinline__ int localRowToGlobal(const KernelArgs& a, int ly) { return shardKernelLocalToGlobal(ly, a.stripeRows, a.stripeStride, a.stripeOffset); }
+__device__ __forceinline__ int globalRowToLocal(const KernelArgs& a, int gy) { return shardKernelGlobalToLocal(gy, a.stripeRows, a.stripeStride, a.stripeOffset); } // rows of this rank
 
 __device__ __forceinline__ void storeColour(const KernelArgs& a, const Lane& L)
 {
@@ -143,9 +136,7 @@ __global__ void __launch_bounds__(256) tptAssembleKernel(const f4* __restrict__ 
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= width * height) return;
     const int gy = i / width, x = i - gy * width;
-    const int stripe = gy / stripeRows, rank = stripe % nRanks;
-    const int ly = (stripe / nRanks) * stripeRows + (gy - stripe * stripeRows);
-    image[i] = gathered[((size_t)rank * (padRows + 1) + ly) * width + x];
+    image[i] = gathered[shardGatheredPixel(x, gy, width, stripeRows, nRanks, padRows)]; // (tpt_shard.h)
 }
 
 // One wave that spins for `ticks` of the 100 MHz wall clock: tptInitialize launches one per trace stream to measure how
@@ -408,10 +399,25 @@ __device__ __forceinline__ f4 mk4(float x, float y, float z, float w)
 #ifndef TPT_MATRIX_FILTER
 #define TPT_MATRIX_FILTER 1 // phase 1 of HitSpheres on the matrix cores (v_mfma_f32_32x32x16_f16, f16-split operands) for scenes with a table; 0: packed VALU filter only
 #endif
+#ifndef TPT_P2_DEAL
+// Phase 2 of HitSpheres with the matrix filter: 0 = every lane walks its own candidate mask (4.15 trips per wave for 1.72
+// candidates per ray); n > 0 = n trips in place, then the wave's LEFTOVER (ray, sphere) pairs are dealt out evenly over its
+// lanes through a pair list in LDS and merged per ray with ds_min_u64 on (t bits, sphere id) -- the reference's
+// first-strictly-less rule (Maths.cpp:171-190); see hitSpheresDeal
+#define TPT_P2_DEAL 0
+#endif
+#ifndef TPT_P2_DEAL_SHADOW
+#define TPT_P2_DEAL_SHADOW TPT_P2_DEAL /* in-place trips of a shadow ray (2.7 candidates on average instead of 1.7) */
+#endif
+#ifndef TPT_STACK_NT
+#define TPT_STACK_NT 0 // 1: bounce-stack levels 1-9 (global memory) are written / read with non-temporal accesses
+#endif
+#define TPT_Q_SPH_FIXED 1024 /* bytes at LDS offset 0 for {centre, r^2} of scenes of <= 64 spheres: DS offsets fold into the instructions */
+#define TPT_Q_DEAL_BYTES (TPT_P2_DEAL ? TPT_Q_WAVES * 144 : 0) /* per wave: 64 x 2 B pair list + the counter */
 #ifndef TPT_Q_PATHS
 // paths per workgroup (<= TPT_Q_P): what the path records in LDS are sized for.  960 with the matrix filter: its 4-KB operand
 // table has to fit beside them for two workgroups per CU (2 x 80 KB); measured no slower than 1024 (profiles/r03/r03_run10.log)
-#define TPT_Q_PATHS (TPT_MATRIX_FILTER ? 960 : TPT_Q_P)
+#define TPT_Q_PATHS (TPT_MATRIX_FILTER ? (TPT_P2_DEAL ? 944 : 960) : TPT_Q_P)
 #endif
 #ifndef TPT_Q_FUSE_MIN
 #define TPT_Q_FUSE_MIN 48 // a batch intersects its own rays when at least this many lanes still hold one
@@ -423,7 +429,7 @@ struct QueueCtl {
     unsigned tail[8];
     unsigned poolTotal;       // pixels sitting in the private chunk pools of this workgroup's waves (+ fetches in flight)
     unsigned globalExhausted; // some wave saw the global chunk counter run out
-    unsigned frameRays[32];   // batched launch: rays traced for each frame of the batch by this workgroup
+    unsigned frameRays[32];   // batched launch: rays traced for each frame of the batch by this workgroup (flushed to the global counter every 2^31: see the push)
 };
 
 // Push every lane's path id to the queue of its class `cls` (Q_FREE..Q_LAMBERT, or -1 for none): one returning LDS atomic
@@ -500,6 +506,74 @@ __device__ __forceinline__ int qPop(volatile unsigned short* q, unsigned* head, 
     return (int)n;
 }
 
+#if TPT_P2_DEAL
+// Phase 2 of HitSpheres for a whole wave (every lane calls it; lanes without a ray pass cand = 0): the reference's exact test
+// (testSphere, Maths.cpp:171-190) for the candidates the matrix filter left -- `inplace` trips by the lane that owns the ray,
+// then the LEFTOVER candidates of all lanes are dealt out evenly:
+//   * a lane with k leftovers reserves k entries of the wave's pair list with one LDS atomic and writes (its path id, sphere)
+//     pairs; it parks its ray {o, d} and its best hit so far -- the 64-bit key (t bits << 32 | sphere id) -- in planes 0 / 1 of
+//     its own path record, which are dead while the path is held by this wave (they are rewritten when the iteration ends);
+//   * lane j of the wave takes entry j: reads the ray from the owner's record, runs testSphere, and merges a hit into the
+//     owner's key with ds_min_u64 -- smaller t wins, equal t: the lower sphere index, which is what ascending order with a
+//     strict t < hitT gives the reference (t > tMin > 0, so the bit patterns order like the values);
+//   * the owner reads its key back.
+// More than 64 leftovers in a wave: the surplus is tested in place by its owner (rare).  One wave, no barrier: a wave's LDS
+// operations execute in order; wave_barrier only keeps the compiler from moving them.
+__device__ __forceinline__ int hitSpheresDeal(const f4* sph, uint64_t cand, f3 o, f3 d, float& outT, int inplace, volatile unsigned short* list,
+                                              unsigned* listCount, f4* st, int p, int lane)
+{
+    float hitT = TPT_MAX_T;
+    int id = -1;
+#pragma unroll 1
+    for (int k = 0; k < inplace; ++k) {
+        if (cand) {
+            const int i = __builtin_clzll(cand);
+            cand &= ~(0x8000000000000000ull >> i);
+            testSphere(sph[i], i, o, d, TPT_MIN_T, hitT, id);
+        }
+    }
+    if (__ballot(cand != 0ull) != 0ull) {
+        const unsigned n = (unsigned)__popcll(cand);
+        if (lane == 0) *listCount = 0u;
+        __builtin_amdgcn_wave_barrier();
+        if (n != 0u) {
+            unsigned pos = atomicAdd(listCount, n);
+            while (cand) {
+                const int i = __builtin_clzll(cand);
+                cand &= ~(0x8000000000000000ull >> i);
+                if (pos < 64u)
+                    list[pos] = (unsigned short)((p << 6) | i);
+                else
+                    testSphere(sph[i], i, o, d, TPT_MIN_T, hitT, id); // the wave's list is full: in place
+                ++pos;
+            }
+            st[p] = mk4(u2f((uint32_t)id), hitT, o.x, o.y); // {key lo = id, key hi = t bits, o.x, o.y}
+            st[TPT_Q_PATHS + p] = mk4(o.z, d.x, d.y, d.z);
+        }
+        __builtin_amdgcn_wave_barrier();
+        unsigned total = __hip_atomic_load(listCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        total = total < 64u ? total : 64u;
+        if ((unsigned)lane < total) {
+            const unsigned e = list[lane];
+            const int po = (int)(e >> 6), i = (int)(e & 63u);
+            const f4 r0 = st[po], r1 = st[TPT_Q_PATHS + po];
+            float ht = TPT_MAX_T;
+            int hid = -1;
+            testSphere(sph[i], i, mk3(r0.z, r0.w, r1.x), mk3(r1.y, r1.z, r1.w), TPT_MIN_T, ht, hid);
+            if (hid >= 0) atomicMin(reinterpret_cast<unsigned long long*>(&st[po]), ((unsigned long long)f2u(ht) << 32) | (unsigned long long)(uint32_t)hid);
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (n != 0u) {
+            const f4 k = st[p];
+            id = (int)f2u(k.x);
+            hitT = k.y;
+        }
+    }
+    outT = hitT;
+    return id;
+}
+#endif
+
 // The path record, 64 B in LDS, four f4 planes [plane][path]:
 //   [0] ray origin -- for a path waiting in a class queue: the HIT POSITION orig + dir * t (Maths.cpp:195) -- .xyz, rng
 //   [1] ray direction .xyz, {sample : 11, depth : 4, doMatE : 1, hit id : 16}
@@ -526,19 +600,25 @@ tptTraceQueueKernel(const KernelArgs a)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS layout: everything of fixed size first, at compile-time offsets (immediates in the DS instructions instead of base
     // registers): path records, rings, control block, frame constants; then the scene arrays, whose sizes the launch decides
-    constexpr int kOffQ = TPT_Q_NF4 * TPT_Q_PATHS * 16;
+    // (kernels that stage the scene keep {centre, r^2} of up to 64 spheres -- every scene the matrix filter serves -- at offset
+    //  0: phase 2 then addresses a sphere with sphere index x 16 and an immediate, like the path records)
+    constexpr int kOffSt = LDS_SCENE ? TPT_Q_SPH_FIXED : 0;
+    constexpr int kOffQ = kOffSt + TPT_Q_NF4 * TPT_Q_PATHS * 16;
     constexpr int kOffCtl = kOffQ + Q_COUNT * TPT_Q_P * 2;
-    constexpr int kOffFc = kOffCtl + (((int)sizeof(QueueCtl) + 63) & ~63);
+    constexpr int kOffDeal = kOffCtl + (((int)sizeof(QueueCtl) + 63) & ~63);
+    constexpr int kOffFc = kOffDeal + TPT_Q_DEAL_BYTES;
     constexpr int kOffScene = kOffFc + (((int)sizeof(FrameConsts) + 15) & ~15);
-    f4* st = reinterpret_cast<f4*>(smem);
+    f4* st = reinterpret_cast<f4*>(smem + kOffSt);
     volatile unsigned short* q = reinterpret_cast<volatile unsigned short*>(smem + kOffQ);
     QueueCtl* ctl = reinterpret_cast<QueueCtl*>(smem + kOffCtl);
     // the frame constants the camera code reads (22 camera floats, 1/w, 1/h): in LDS, read where a sample starts, instead of
     // ~30 SGPRs held (and spilled) across the whole loop
     FrameConsts* ldsFc = reinterpret_cast<FrameConsts*>(smem + kOffFc);
     const int nPad = a.scene.nPairs * 2;
-    f4* ldsSph = reinterpret_cast<f4*>(smem + kOffScene);
-    int off = kOffScene + (LDS_SCENE ? nPad * 16 : 0);
+    const bool sphFixed = LDS_SCENE && nPad * 16 <= TPT_Q_SPH_FIXED;
+    f4* ldsSphFixed = reinterpret_cast<f4*>(smem);
+    f4* ldsSph = sphFixed ? ldsSphFixed : reinterpret_cast<f4*>(smem + kOffScene);
+    int off = kOffScene + ((LDS_SCENE && !sphFixed) ? nPad * 16 : 0);
     float* ldsInvR = reinterpret_cast<float*>(smem + off);
     off += LDS_SCENE ? ((nPad * 4 + 15) & ~15) : 0;
     f4* ldsLights = reinterpret_cast<f4*>(smem + off);
@@ -589,6 +669,14 @@ tptTraceQueueKernel(const KernelArgs a)
 
     const FrameConsts& fc = a.fc;
     const unsigned long long laneBelow = (1ull << lane) - 1ull;
+#if TPT_MATRIX_FILTER
+    SceneView svM = sv; // what phase 2 behind the matrix filter reads: {centre, r^2} at their compile-time LDS address
+    svM.sph4 = ldsSphFixed;
+#endif
+#if TPT_P2_DEAL
+    volatile unsigned short* dealList = reinterpret_cast<volatile unsigned short*>(smem + kOffDeal + (tid >> 6) * 144);
+    unsigned* dealCount = reinterpret_cast<unsigned*>(smem + kOffDeal + (tid >> 6) * 144 + 128);
+#endif
     f4* colSum = st + 2 * TPT_Q_PATHS;                        // plane 2: per-path colour sums + pixel coordinates
     int chunkNext = 0, chunkEnd = 0; // this wave's private pixel pool
     int chunkFrame = 0;              // batched launch: the frame of the batch that pool belongs to
@@ -854,7 +942,7 @@ tptTraceQueueKernel(const KernelArgs a)
                     l1 = sv.lights[j * 2 + 1];
                     lightId = (int)f2u(l1.w);
                     go = ray && lightId != recId; // Test.cpp:100: not the sphere itself
-                    if (go) d2 = qLightRay(sv.lights[j * 2], ro, rng, lam.cosAMax);
+                    if (go) d2 = qLightRay(sv.lights[j * 2], ro, rng, lam.cosAMax, (sv.flags & SCENE_LIGHT_R2_DIV_SAFE) != 0);
                 }
 #if TPT_MATRIX_FILTER
                 // phase 1 of HitSpheres for the whole wave on the matrix cores: every lane takes part (this loop is wave-uniform);
@@ -862,11 +950,21 @@ tptTraceQueueKernel(const KernelArgs a)
                 uint64_t cand = 0ull;
                 if (LDS_SCENE && useMatrix) cand = phase1MatrixH(ldsA, mxR1, sv.nSpheres, ro, d2);
 #endif
+#if TPT_P2_DEAL
+                int dealId = -1;
+                float dealT = TPT_MAX_T;
+                if (LDS_SCENE && useMatrix) // (wave-uniform: every lane takes part, lanes without a ray as helpers only)
+                    dealId = hitSpheresDeal(ldsSphFixed, go ? cand : 0ull, ro, d2, dealT, shadow ? TPT_P2_DEAL_SHADOW : TPT_P2_DEAL, dealList, dealCount, st, p, lane);
+#endif
                 if (go) {
                     TPT_STAT(ST_STEP);
                     float t;
-#if TPT_MATRIX_FILTER
-                    const int id = (LDS_SCENE && useMatrix) ? hitSpheresCandidates(sv, cand, ro, d2, TPT_MIN_T, TPT_MAX_T, t)
+#if TPT_P2_DEAL
+                    int id = dealId;
+                    t = dealT;
+                    if (!(LDS_SCENE && useMatrix)) id = hitSpheres<LDS_SCENE ? HS_TWO_PHASE : HS_TWO_PHASE_GROUPS>(sv, ro, d2, TPT_MIN_T, TPT_MAX_T, t);
+#elif TPT_MATRIX_FILTER
+                    const int id = (LDS_SCENE && useMatrix) ? hitSpheresCandidates(svM, cand, ro, d2, TPT_MIN_T, TPT_MAX_T, t)
                                                             : hitSpheres<LDS_SCENE ? HS_TWO_PHASE : HS_TWO_PHASE_GROUPS>(sv, ro, d2, TPT_MIN_T, TPT_MAX_T, t);
 #else
                     const int id = hitSpheres<LDS_SCENE ? HS_TWO_PHASE : HS_TWO_PHASE_GROUPS>(sv, ro, d2, TPT_MIN_T, TPT_MAX_T, t);
@@ -900,7 +998,16 @@ tptTraceQueueKernel(const KernelArgs a)
             st[1 * TPT_Q_PATHS + p] = mk4(rd.x, rd.y, rd.z, u2f(w));
         }
         if (toFree) cls = Q_FREE;
-        if (BATCH && iterRays != 0u) atomicAdd(&ctl->frameRays[f2u(colSum[p].w) >> 26], iterRays); // (one LDS atomic per lane and iteration)
+        if (BATCH && iterRays != 0u) { // (one LDS atomic per lane and iteration)
+            const unsigned fr = f2u(colSum[p].w) >> 26;
+            const unsigned old = atomicAdd(&ctl->frameRays[fr], iterRays);
+            // a 32-bit counter per workgroup and frame can wrap on a very large frame at high spp on a small grid: the lane whose
+            // addition crosses 2^31 moves 2^31 rays to the frame's global counter (one lane per crossing)
+            if (__builtin_expect(old < 0x80000000u && old + iterRays >= 0x80000000u, 0)) {
+                atomicSub(&ctl->frameRays[fr], 0x80000000u);
+                atomicAdd(a.rayCounter + (size_t)fr * a.rayCounterStride, 0x80000000ull);
+            }
+        }
         TPT_TSTAMP(tsInt);
         TPT_TADD(64 + pick * 4 + 2, tsClass, tsInt);
         // (the cold state is global memory, but every wave that can pop this path runs on this CU and shares its L1:
@@ -946,8 +1053,9 @@ tptTraceQueueKernel(const KernelArgs a)
 #endif
 }
 
+#if defined(TPT_TEST_HOOKS)
 // ---------------------------------------------------------------- unit-test kernels (GPU parity of the math layer)
-// op: 0 sqrt(a) 1 a/b 2 tsinf(a) 3 tcosf(a) 4 tpow5f(a) 5 rnd01 stream (a = seed bits) 6 schlick(a,b) 7 1/sqrt-normalize.x 8 / 9 sin / cos of tsincosf(a)
+// op: 0 sqrt(a) 1 a/b 2 tsinf(a) 3 tcosf(a) 4 tpow5f(a) 5 rnd01 stream (a = seed bits) 6 schlick(a,b) 7 1/sqrt-normalize.x 8 / 9 sin / cos of tsincosf(a) 10 tdivSafeNum(a, b) 11 tdivByPi(a)
 __global__ void tptMathTestKernel(int op, const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int n)
 {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -968,6 +1076,8 @@ __global__ void tptMathTestKernel(int op, const float* __restrict__ a, const flo
     case 7: r = normalize(mk3(x, y, 1.0f)).x; break;
     case 8: { float sn, cs; tsincosf(x, sn, cs); r = sn; break; } // the pair the path uses, against ops 2 / 3
     case 9: { float sn, cs; tsincosf(x, sn, cs); r = cs; break; }
+    case 10: r = tdivSafeNum(x, y); break; // Scatter's r^2 / d^2 (numerator range-checked on the host, divisor guarded in the function)
+    case 11: r = tdivByPi(x); break;       // Scatter's x / kPI
     }
     out[i] = r;
 }
@@ -1023,11 +1133,14 @@ __global__ void __launch_bounds__(64) tptMatrixFilterTestKernel(const KernelArgs
     }
 }
 
+#endif // TPT_TEST_HOOKS
+
 } // namespace tpt
 
 // ---------------------------------------------------------------- launch glue (called from tpt_host.cpp)
 using namespace tpt;
 
+#if defined(TPT_TEST_HOOKS)
 int tptReadStats(unsigned long long* out64)
 {
 #if defined(TPT_STATS)
@@ -1047,6 +1160,7 @@ int tptResetStats()
     return -1;
 #endif
 }
+#endif // TPT_TEST_HOOKS
 
 size_t tptLdsBytes(const KernelArgs& a, int fold, bool ldsScene)
 {
@@ -1108,9 +1222,9 @@ size_t tptQueueLdsBytes(const KernelArgs& a, bool ldsScene)
 {
     const int nPad = a.scene.nPairs * 2;
     size_t bytes = 0;
-    if (ldsScene) bytes += (size_t)nPad * 16 + (((size_t)nPad * 4 + 15) & ~(size_t)15) + (size_t)a.scene.nSpheres * 48;
+    if (ldsScene) bytes += TPT_Q_SPH_FIXED + ((size_t)nPad * 16 <= TPT_Q_SPH_FIXED ? 0 : (size_t)nPad * 16) + (((size_t)nPad * 4 + 15) & ~(size_t)15) + (size_t)a.scene.nSpheres * 48;
     bytes += (size_t)a.scene.nLights * 32;
-    bytes += (size_t)TPT_Q_NF4 * TPT_Q_PATHS * 16 + (size_t)Q_COUNT * TPT_Q_P * 2 + ((sizeof(QueueCtl) + 63) & ~(size_t)63) + ((sizeof(FrameConsts) + 15) & ~(size_t)15);
+    bytes += (size_t)TPT_Q_NF4 * TPT_Q_PATHS * 16 + (size_t)Q_COUNT * TPT_Q_P * 2 + ((sizeof(QueueCtl) + 63) & ~(size_t)63) + ((sizeof(FrameConsts) + 15) & ~(size_t)15) + TPT_Q_DEAL_BYTES;
 #if TPT_MATRIX_FILTER
     if (ldsScene && a.scene.mxR1 >= 0) bytes += TPT_MXH_TABLE_DWORDS * sizeof(uint32_t) + 64;
 #endif
@@ -1194,6 +1308,7 @@ hipError_t tptLaunchResolveBatch(float* tile, const f4* frameColour, int nPixels
     return hipGetLastError();
 }
 
+#if defined(TPT_TEST_HOOKS)
 hipError_t tptLaunchMathTest(int op, const float* a, const float* b, float* out, int n, hipStream_t stream)
 {
     hipLaunchKernelGGL(tptMathTestKernel, dim3((n + 255) / 256), dim3(256), 0, stream, op, a, b, out, n);
@@ -1217,3 +1332,4 @@ hipError_t tptLaunchHitTest(const KernelArgs& a, int hs, const float* rays, int*
         hipLaunchKernelGGL(tptHitTestKernel<HS_TWO_PHASE_GROUPS>, dim3((n + 255) / 256), dim3(256), 0, stream, a, rays, outId, outT, n);
     return hipGetLastError();
 }
+#endif // TPT_TEST_HOOKS

@@ -109,6 +109,57 @@ TPT_HD float trsqrt2(float x)
 }
 TPT_HD double dfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+// Correctly rounded binary32 division in 6 instructions instead of hipcc's 11 (v_div_scale x 2, v_rcp, 5 fma / mul,
+// v_div_fmas, v_div_fixup): Markstein's sequence  y0 = v_rcp_f32(b); e = fma(-b, y0, 1); y1 = fma(e, y0, y0); q0 = a y1;
+// r = fma(-b, q0, a); q = fma(r, y1, q0).  PROVEN BY EXHAUSTION on the device, not by argument: tools/exhaustive/
+// exhaustive_div.hip compares it with the compiler's expansion for ALL 2^23 x 2^23 pairs of significands (42 s of an
+// MI355X, profiles/r04/r04_run1.log: 0 mismatches; the 4-instruction form without the reciprocal refinement fails for
+// 47 045 pairs).  A quotient's significand depends on the operands' significands only as long as no intermediate leaves the
+// normal range, so the result holds for every a, b with exponents in [-60, 60] (r = a - b q0 ~ 2^-24 a stays normal); a
+// generic guard on both operands would cost what the sequence saves, so the two hot call sites use forms whose guard is one
+// range check:
+//   tdivSafeNum(a, b): a is known (checked on the host) to lie in [2^-60, 2^60]; b is checked here -- Scatter's r^2 / d^2;
+//   tdivByPi(a):       b = kPI; a >= +0 (a product of a clamped cosine and a solid angle), 0 or >= 2^-100 takes the
+//                      3-instruction form with the correctly rounded reciprocal of kPI as a constant (every significand of a
+//                      checked on the host: tests/test_lane_logic.py::test_division_by_pi_all_significands).
+// Everything else, and the host build, runs the plain IEEE division.
+#define TPT_DIV_LO 0x21800000u /* 2^-60 */
+#define TPT_DIV_HI 0x5d800000u /* 2^60 */
+TPT_HD bool tdivInRange(float x) { return f2u(x) - TPT_DIV_LO <= TPT_DIV_HI - TPT_DIV_LO; } // (positive, finite, |exponent| <= 60)
+TPT_HD float tdivSafeNum(float a, float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float y0 = __builtin_amdgcn_rcpf(b);
+    const float e = __builtin_fmaf(-b, y0, 1.0f);
+    const float y1 = __builtin_fmaf(e, y0, y0);
+    const float q0 = a * y1;
+    const float r = __builtin_fmaf(-b, q0, a);
+    float q = __builtin_fmaf(r, y1, q0);
+    if (__builtin_expect(!tdivInRange(b), 0)) q = a / b;
+    return q;
+#else
+    return a / b;
+#endif
+}
+#define TPT_INV_PI 0.318309903144836425781f /* RN(1 / 3.1415926f): 0x3ea2f984 */
+TPT_HD float tdivByPiFast(float a) // the 3-instruction form alone (host-checkable: plain fmaf)
+{
+    const float q0 = a * TPT_INV_PI;
+    const float r = __builtin_fmaf(-TPT_PI, q0, a);
+    return __builtin_fmaf(r, TPT_INV_PI, q0);
+}
+TPT_HD float tdivByPi(float a)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    float q = tdivByPiFast(a);
+    // +0 and [2^-100, 2^126) take the fast form; negative, tiny, huge and non-finite arguments the IEEE expansion
+    if (__builtin_expect(f2u(a) - 1u >= 0x7e800000u - 1u || (f2u(a) != 0u && f2u(a) < 0x0d800000u), 0)) q = a / TPT_PI;
+    return q;
+#else
+    return a / TPT_PI;
+#endif
+}
+
 // ---------------------------------------------------------------- float3
 struct f3 {
     float x, y, z;
@@ -366,6 +417,10 @@ TPT_HD float tpow5f(float x)
         if (ylogx <= -150.0) return u2f(sign_bias ? 0x80000000u : 0u);
     }
     return pow_exp2_inline(ylogx, sign_bias);
+}
+TPT_HD float schlickR0(float cosine, float r0sq) // the same with r0^2 = ((1 - ri) / (1 + ri))^2 taken from the material record (packScene)
+{
+    return r0sq + (1 - r0sq) * tpow5f(1 - cosine);
 }
 TPT_HD float schlick(float cosine, float ri) // Maths.h:327-332
 {

@@ -127,6 +127,7 @@ struct PackedScene {
     int nGroups = 0, nGroupPairs = 0, nBig = 0;
     std::vector<uint32_t> amatH; // [2][2][64][4] A operands of the matrix-core filter (phase1MatrixH); empty: not available
     int mxR1 = -1;
+    int flags = 0;               // SCENE_* bits (tpt_trace.h)
 };
 
 // a_k of one sphere for the matrix-core filter (tpt_trace.h, phase1MatrixH): binary64, rounded once; a_9 carries the
@@ -318,6 +319,7 @@ inline void packScene(std::vector<SpherePOD>& S, const std::vector<MaterialPOD>&
     P.mats.assign((size_t)n * 3, zero);
     P.lights.clear();
     P.emissive.clear();
+    P.flags = SCENE_LIGHT_R2_DIV_SAFE;
     const float negInf = u2f(0xff800000u);
     for (int i = 0; i < nPad; ++i) {
         float cx = 0, cy = 0, cz = 0, sq = negInf; // padding sphere: filter value = -inf, never a candidate
@@ -331,11 +333,14 @@ inline void packScene(std::vector<SpherePOD>& S, const std::vector<MaterialPOD>&
             const MaterialPOD& m = M[i];
             f4 m0 = {m.albedo[0], m.albedo[1], m.albedo[2], u2f((uint32_t)m.type)};
             f4 m1 = {m.emissive[0], m.emissive[1], m.emissive[2], m.roughness};
-            f4 m2 = {m.ri, 0, 0, 0};
+            float r0 = (1 - m.ri) / (1 + m.ri); // schlick, Maths.h:329-330; 1.0f / ri: Test.cpp:168 -- the reference's own operations, done once
+            r0 = r0 * r0;
+            f4 m2 = {m.ri, 1.0f / m.ri, r0, 0};
             P.mats[(size_t)i * 3] = m0;
             P.mats[(size_t)i * 3 + 1] = m1;
             P.mats[(size_t)i * 3 + 2] = m2;
             if (m.emissive[0] > 0 || m.emissive[1] > 0 || m.emissive[2] > 0) { // Test.cpp:334
+                if (!tdivInRange(S[i].radius * S[i].radius)) P.flags &= ~SCENE_LIGHT_R2_DIV_SAFE;
                 f4 l0 = {cx, cy, cz, S[i].radius};
                 f4 l1 = {m.emissive[0], m.emissive[1], m.emissive[2], u2f((uint32_t)i)};
                 P.lights.push_back(l0);
@@ -379,6 +384,7 @@ inline SceneView viewOf(const PackedScene& P)
     sv.nBig = P.nBig;
     sv.amatH = P.amatH.empty() ? nullptr : P.amatH.data();
     sv.mxR1 = P.mxR1;
+    sv.flags = P.flags;
     return sv;
 }
 

@@ -53,7 +53,8 @@ struct CameraPOD {
 //            wave-uniform reads -> scalar loads; odd counts are padded with sq = -inf (never hit)
 //   sph4   : {cx,cy,cz,sqRadius} per sphere for the phase-2 gather (staged into LDS by the kernel)
 //   invR   : 1/radius per sphere (Maths.h:359)
-//   mats   : 3 x f4 per sphere {albedo.xyz,type} {emissive.xyz,roughness} {ri,-,-,-}
+//   mats   : 3 x f4 per sphere {albedo.xyz,type} {emissive.xyz,roughness} {ri, 1/ri, schlick's r0^2, -} (the last two: what
+//            Scatter / schlick derive from ri alone, Test.cpp:168 / Maths.h:329-330, computed once on the host with the same IEEE operations)
 //   lights : 2 x f4 per emissive sphere {cx,cy,cz,radius} {emissive.xyz, id}
 struct SceneView {
     const float* pairs;
@@ -77,7 +78,9 @@ struct SceneView {
     // second sphere tile that hold spheres (0, 4, ..., 16); mxR1 < 0: no table.
     const uint32_t* amatH;
     int mxR1;
+    int flags; // SCENE_* bits (packScene)
 };
+enum { SCENE_LIGHT_R2_DIV_SAFE = 1 }; // every light's radius^2 lies in [2^-60, 2^60]: Scatter's r^2 / d^2 may take tdivSafeNum (tpt_math.h)
 #ifndef TPT_GROUP
 #define TPT_GROUP 16 /* members per group, <= 32 */
 #endif
@@ -1045,6 +1048,26 @@ struct QStack {
     f4* spill;  // level k >= 1 at spill[(k - 1) * stride]
     int stride;
 };
+// (-DTPT_STACK_NT=1, experiment: the spilled levels are written once and read once, much later -- non-temporal accesses keep
+//  them from displacing the half-written colour lines in the L2s)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(TPT_STACK_NT) && TPT_STACK_NT
+typedef float tptV4 __attribute__((ext_vector_type(4)));
+TPT_HD void spillStore(f4* p, f4 v)
+{
+    tptV4 x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<tptV4*>(p));
+}
+TPT_HD f4 spillLoad(const f4* p)
+{
+    const tptV4 x = __builtin_nontemporal_load(reinterpret_cast<const tptV4*>(p));
+    f4 v;
+    v.x = x[0]; v.y = x[1]; v.z = x[2]; v.w = x[3];
+    return v;
+}
+#else
+TPT_HD void spillStore(f4* p, f4 v) { *p = v; }
+TPT_HD f4 spillLoad(const f4* p) { return *p; }
+#endif
 TPT_HD void qStackPush(const QStack& s, int level, f3 e, int attId)
 {
     f4 v;
@@ -1052,7 +1075,7 @@ TPT_HD void qStackPush(const QStack& s, int level, f3 e, int attId)
     if (level == 0)
         *s.l0 = v;
     else
-        s.spill[(level - 1) * s.stride] = v;
+        spillStore(&s.spill[(level - 1) * s.stride], v);
 }
 // hit normal, Maths.cpp:196-197
 TPT_HD f3 qNormal(const SceneView& sv, int id, f3 pos)
@@ -1092,7 +1115,7 @@ TPT_HD f3 qFold(const SceneView& sv, f3 term, int depth, const QStack& s)
         for (int k = 0; k < 5; ++k) {
             ent[k].x = ent[k].y = ent[k].z = ent[k].w = 0.0f;
             const int lvl = g5 * 5 + k;
-            if (lvl < depth) ent[k] = lvl == 0 ? *s.l0 : s.spill[(lvl - 1) * s.stride];
+            if (lvl < depth) ent[k] = lvl == 0 ? *s.l0 : spillLoad(&s.spill[(lvl - 1) * s.stride]);
         }
 #pragma unroll
         for (int k = 4; k >= 0; --k) {
@@ -1117,7 +1140,8 @@ TPT_HD f3 qDielectric(const SceneView& sv, const FrameConsts& fc, f3 pos, f3 rdi
     (void)fc;
     const f3 normal = qNormal(sv, id, pos);
     const f4 m1 = sv.mats[id * 3 + 1];
-    const float ri = sv.mats[id * 3 + 2].x;
+    const f4 m2 = sv.mats[id * 3 + 2]; // {ri, 1.0f / ri, r0^2}: the division of Test.cpp:168 and schlick's r0 (Maths.h:329-330) depend on the material only
+    const float ri = m2.x;
     const f3 refl = reflect(rdir, normal);
     f3 outwardN, refr = mk3(0, 0, 0);
     float nint, cosine, reflProb;
@@ -1128,11 +1152,11 @@ TPT_HD f3 qDielectric(const SceneView& sv, const FrameConsts& fc, f3 pos, f3 rdi
         cosine = ri * dn;
     } else {
         outwardN = normal;
-        nint = 1.0f / ri;
+        nint = m2.y;
         cosine = -dn;
     }
     if (refract(rdir, outwardN, nint, refr))
-        reflProb = schlick(cosine, ri);
+        reflProb = schlickR0(cosine, m2.z);
     else
         reflProb = 1;
     const f3 pick = rnd01(rng) < reflProb ? refl : refr;
@@ -1171,7 +1195,7 @@ TPT_HD void qLambertBegin(const SceneView& sv, f3 pos, f3 rdir, int id, uint32_t
     q.lightE = mk3(0, 0, 0);
     q.cosAMax = 0.0f;
 }
-TPT_HD f3 qLightRay(const f4 l0, f3 pos, uint32_t& rng, float& cosAMax)
+TPT_HD f3 qLightRay(const f4 l0, f3 pos, uint32_t& rng, float& cosAMax, bool fastDiv)
 {
     TPT_STAT(ST_LIGHTGEN);
     const f3 sc = mk3(l0.x, l0.y, l0.z);
@@ -1180,7 +1204,8 @@ TPT_HD f3 qLightRay(const f4 l0, f3 pos, uint32_t& rng, float& cosAMax)
     const f3 sw = toL * trsqrt2(d2); // normalize(sc - pos)
     const f3 su = normalize(cross((sw.x < 0 ? -sw.x : sw.x) > 0.01f ? mk3(0, 1, 0) : mk3(1, 0, 0), sw));
     const f3 sv_ = cross(sw, su);
-    cosAMax = tsqrt(1.0f - l0.w * l0.w / d2);
+    const float r2 = l0.w * l0.w;
+    cosAMax = tsqrt(1.0f - (fastDiv ? tdivSafeNum(r2, d2) : r2 / d2)); // (fastDiv is wave-uniform: a scene flag)
     const float eps1 = rnd01(rng), eps2 = rnd01(rng);
     const float cosA = 1.0f - eps1 + eps1 * cosAMax;
     const float sinA = tsqrt(1.0f - cosA * cosA);
@@ -1201,7 +1226,7 @@ TPT_HD void qLightShade(const f4 l1, f3 l, QLambert& q)
     const float omega = 2 * TPT_PI * (1 - q.cosAMax);
     const float dln = dot(l, q.nl);
     const float mx = 0.0f < dln ? dln : 0.0f; // std::max(0.0f, dln)
-    q.lightE = q.lightE + (q.albedo * mk3(l1.x, l1.y, l1.z)) * (mx * omega / TPT_PI);
+    q.lightE = q.lightE + (q.albedo * mk3(l1.x, l1.y, l1.z)) * tdivByPi(mx * omega);
 }
 
 // Pixel complete: the frame's colour of this pixel, averaged over the samples (Test.cpp:291).

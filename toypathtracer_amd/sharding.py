@@ -111,8 +111,11 @@ class ShardedFrame:
             self.comm_stream = torch.cuda.Stream(device=self.device)
             self.ev_ready = [torch.cuda.Event() for _ in range(depth)]   # send buffer filled (render stream)
             self.ev_free = [torch.cuda.Event() for _ in range(depth)]    # send buffer consumed (comm stream)
-            # the buffers above were filled on torch's current stream; the library and the two streams here do not wait for it
-            torch.cuda.synchronize(self.device)
+            # the buffers above were filled on torch's current stream: both streams wait for those fills (a stream dependency, not a
+            # device synchronise; the library works on render_stream once the caller passes it to tptSetStream)
+            cur = torch.cuda.current_stream(self.device)
+            self.render_stream.wait_stream(cur)
+            self.comm_stream.wait_stream(cur)
         else:
             self.render_stream = self.comm_stream = None
 

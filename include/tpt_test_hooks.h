@@ -21,6 +21,10 @@ TPT_API int tptTestMathExhaustive(int op, unsigned lo, unsigned hi, unsigned lon
  * pieces).  n host rays -> candidate masks (sphere p at bit 63 - p; may be NULL) and / or the nearest hit through the filter
  * + the exact test of its candidates (outId / outT; may be NULL). */
 TPT_API int tptTestMatrixFilter(const float* rays, unsigned long long* outMask, int* outId, float* outT, int n);
+/* the matrix-core filter over the GROUP BOUNDS of the current grouped scene (>= 256 spheres) against the reference's
+ * discriminant for every member sphere: violations = (ray, member) pairs with discr > 0 whose group the filter dropped (must be
+ * 0); touched = groups kept, exact = members with discr > 0, both summed over the rays.  n host rays ([n][6], unit direction). */
+TPT_API int tptTestGroupFilter(const float* rays, int n, unsigned long long* outViolations, unsigned long long* outTouched, unsigned long long* outExact);
 /* profiling builds only (-DTPT_STATS): 128 counters, wave-level entries [i] / lane counts [32+i] of the
  * state machine's blocks (enum ST_* in tpt_trace.h); the shipped build returns an error. */
 TPT_API int tptDebugStats(unsigned long long* out128, int reset);

@@ -192,6 +192,41 @@ long long emu_shard_exchange(int w, int h, int S, int N, int ring, unsigned long
     info[3] = errors;
     return errors;
 }
+// The matrix-core filter over the GROUP BOUNDS of a grouped scene (buildGroupMatrixTable), through its host restatement
+// (phase1MatrixHRef, slackShift 1), against the reference's discriminant of every member (Maths.cpp:171-178):
+// out[0] = (ray, member) pairs with discr > 0 whose group the filter dropped (must be 0), out[1] = groups kept (summed over the
+// rays), out[2] = members with discr > 0, out[3] = tiles of 64 groups (0: the scene has no table).
+void emu_group_matrix_check(const void* spheres, const void* mats, int count, const float* rays, int nRays, long long* out)
+{
+    std::vector<SpherePOD> S((const SpherePOD*)spheres, (const SpherePOD*)spheres + count);
+    std::vector<MaterialPOD> M((const MaterialPOD*)mats, (const MaterialPOD*)mats + count);
+    PackedScene P;
+    packScene(S, M, P);
+    out[0] = out[1] = out[2] = 0;
+    out[3] = P.gmxTiles;
+    for (int i = 0; i < nRays && P.gmxTiles > 0; ++i) {
+        const f3 o = mk3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]), d = mk3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
+        for (int t = 0; t < P.gmxTiles; ++t) {
+            const int left = P.nGroups - t * 64, nEnt = left < 64 ? left : 64;
+            const uint64_t m = phase1MatrixHRef(P.gmatH.data() + (size_t)t * TPT_MXH_TABLE_DWORDS, 16, nEnt, o, d, nullptr, nullptr, 1);
+            out[1] += __builtin_popcountll(m);
+            for (int q = 0; q < nEnt; ++q) {
+                const bool kept = (m >> (63 - q)) & 1ull;
+                for (int j = 0; j < TPT_GROUP; ++j) {
+                    const f4 s = P.gsph[(size_t)(t * 64 + q) * TPT_GROUP + j];
+                    const float coX = s.x - o.x, coY = s.y - o.y, coZ = s.z - o.z;
+                    const float nb = coX * d.x + coY * d.y + coZ * d.z;
+                    const float c = coX * coX + coY * coY + coZ * coZ - s.w;
+                    const float discr = nb * nb - c;
+                    if (discr > 0) {
+                        out[2]++;
+                        if (!kept) out[0]++;
+                    }
+                }
+            }
+        }
+    }
+}
 float emu_sinf(float x) { return tsinf(x); }
 float emu_cosf(float x) { return tcosf(x); }
 float emu_pow5f(float x) { return tpow5f(x); }

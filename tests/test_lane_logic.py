@@ -289,3 +289,27 @@ def test_division_by_pi_all_significands(emu):
     for e in (-100, -64, -24, -3, -1, 0, 1, 2, 3, 60, 125):
         bad = emu.emu_div_pi_mismatches(e, C.byref(first))
         assert bad == 0, (e, bad, hex(first.value))
+
+
+@pytest.mark.parametrize("n,grid", [(4096, 64), (1000, 32), (20000, 160)])
+def test_group_bound_matrix_filter_keeps_every_group_with_an_accepted_member(emu, n, grid):
+    """Grouped scenes (>= 256 spheres): the bounding spheres go through the matrix-core filter with doubled slack
+    (buildGroupMatrixTable / hitSpheresGroupedDeal).  Host restatement of that filter against the reference's discriminant of
+    EVERY member sphere, for rays that graze spheres within 1e-8 .. 1e-3 radii and for random rays: a member the reference accepts
+    never sits in a dropped group.  (The device's MFMA accumulation differs from the restatement's within the error model both
+    are conservative under; the device itself is checked by tests/test_gpu_parity.py::test_group_matrix_filter_on_the_device.)"""
+    import ctypes as C
+    from common import grazing_rays
+    from toypathtracer_amd.scenes import stress_scene
+    s, m = stress_scene(n, grid)
+    rng = np.random.default_rng(11)
+    k = 1500 if n <= 4096 else 300
+    o = np.stack([rng.uniform(-grid / 2, grid / 2, k), rng.uniform(0.0, 8.0, k), rng.uniform(-grid / 2, grid / 2, k)], 1)
+    d = rng.normal(size=(k, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    rays = np.concatenate([grazing_rays(s, k, seed=3), np.concatenate([o.astype(np.float32), d], 1)], 0).astype(np.float32)
+    out = np.zeros(4, np.int64)
+    emu.emu_group_matrix_check.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    emu.emu_group_matrix_check(s.ctypes.data, m.ctypes.data, n, rays.ctypes.data, len(rays), out.ctypes.data)
+    assert out[3] > 0 and out[2] > len(rays) and out[0] == 0, out
+    assert out[1] / len(rays) < 40  # (and the filter filters: a few groups per ray, not hundreds)

@@ -42,7 +42,7 @@ C_ABI_SYMBOLS = [
     "tptDrawDeviceBatch", "tptDrawShardedBatch", "tptGetLookaheadHits", "tptCommGetUniqueId", "tptCommInit", "tptCommInitLoopback", "tptCommInfo", "tptCommDestroy", "tptDrawSharded", "tptShardedFinish", "tptGetLaunchInfo", "tptGetPipelineInfo", "tptSetHostBufferMode", "tptSetHostLookahead", "tptSetStreamBatching", "tptSetTileMirror", "tptGetLastError", "tptGetDeviceName",
 ]
 # include/tpt_test_hooks.h: exported by the second build (libtoypathtracer_hip_hooks.so) only
-HOOK_SYMBOLS = ["tptTestMath", "tptTestMathExhaustive", "tptTestHitSpheres", "tptTestMatrixFilter", "tptDebugStats", "tptDebugChunkOrder"]
+HOOK_SYMBOLS = ["tptTestMath", "tptTestMathExhaustive", "tptTestHitSpheres", "tptTestMatrixFilter", "tptTestGroupFilter", "tptDebugStats", "tptDebugChunkOrder"]
 # the reference's own C++ symbols (nm of the compiled Test.cpp), exported for link-level drop-in
 CXX_ABI_SYMBOLS = [
     "_Z14InitializeTestv", "_Z12ShutdownTestv", "_Z10UpdateTestfiiij", "_Z8DrawTestfiiiPfRij",
@@ -77,7 +77,7 @@ def _bind(path, hooks):
     }
     if hooks:
         sigs.update({"tptDebugStats": [p, i], "tptDebugChunkOrder": [p, p, i], "tptTestMath": [i, p, p, p, i], "tptTestMathExhaustive": [i, u, u, p, p],
-                     "tptTestHitSpheres": [i, p, p, p, i], "tptTestMatrixFilter": [p, p, p, p, i]})
+                     "tptTestHitSpheres": [i, p, p, p, i], "tptTestMatrixFilter": [p, p, p, p, i], "tptTestGroupFilter": [p, i, p, p, p]})
     for name, args in sigs.items():
         fn = getattr(lib, name)
         fn.argtypes = args
@@ -463,3 +463,13 @@ def test_matrix_filter(rays, hits=False):
     _chk(load_library().tptTestMatrixFilter(rays.ctypes.data, masks.ctypes.data, ids.ctypes.data if hits else None,
                                             ts.ctypes.data if hits else None, n), "tptTestMatrixFilter")
     return (masks, ids, ts) if hits else masks
+
+
+def test_group_filter(rays):
+    """the matrix-core filter over the group bounds of the current grouped scene vs the reference's discriminant of every member:
+    (violations, groups kept per ray, members with a positive discriminant per ray)"""
+    rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
+    n = rays.shape[0]
+    v = [C.c_ulonglong(0) for _ in range(3)]
+    _chk(load_library().tptTestGroupFilter(rays.ctypes.data, n, C.byref(v[0]), C.byref(v[1]), C.byref(v[2])), "tptTestGroupFilter")
+    return int(v[0].value), v[1].value / n, v[2].value / n

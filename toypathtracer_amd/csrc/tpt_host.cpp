@@ -77,6 +77,8 @@ struct Context {
         size_t offGPairs = 0, offGSph = 0, offGId = 0, offBSph = 0, offBId = 0; // grouped representation (large scenes)
         size_t offAmat = 0; // matrix-core filter table (small scenes)
         int mxR1 = -1;
+        size_t offGmat = 0; // the same for the group bounds of a grouped scene
+        int gmxTiles = 0;
         int flags = 0;
         int nSpheres = 0, nPairs = 0, nLights = 0;
         int nGroups = 0, nGroupPairs = 0, nBig = 0;
@@ -305,7 +307,10 @@ int stageScene()
                  offLights = offMats + align256(bMats), offGPairs = offLights + align256(bLights + 32),
                  offGSph = offGPairs + align256(bGPairs), offGId = offGSph + align256(bGSph), offBSph = offGId + align256(bGId),
                  offBId = offBSph + align256(bBSph), offAmat = offBId + align256(bBId + 32);
-    const size_t bAmat = (g.useMatrix && tptQueueMatrixFilter() && P.mxR1 >= 0) ? P.amatH.size() * sizeof(uint32_t) : 0, total = offAmat + align256(bAmat + 32);
+    const size_t bAmat = (g.useMatrix && tptQueueMatrixFilter() && P.mxR1 >= 0) ? P.amatH.size() * sizeof(uint32_t) : 0;
+    const size_t offGmat = offAmat + align256(bAmat + 32);
+    const size_t bGmat = (grouped && g.useMatrix && tptQueueMatrixFilter() && P.gmxTiles > 0) ? P.gmatH.size() * sizeof(uint32_t) : 0;
+    const size_t total = offGmat + align256(bGmat + 32);
     if (!S.evUploaded) HIPCHK(hipEventCreateWithFlags(&S.evUploaded, kOrderingEvent));
     // the previous copy out of this staging blob (kSceneSets uploads ago) must have left the host before we overwrite it:
     // only ever waits when the host has run more than 16 animated frames ahead of the GPU
@@ -345,9 +350,12 @@ int stageScene()
         if (bBId) memcpy(S.stage + offBId, P.bid.data(), bBId);
     }
     if (bAmat) memcpy(S.stage + offAmat, P.amatH.data(), bAmat);
-    S.bytes = offAmat + bAmat;
+    if (bGmat) memcpy(S.stage + offGmat, P.gmatH.data(), bGmat);
+    S.bytes = offGmat + bGmat;
     S.offAmat = offAmat;
     S.mxR1 = bAmat ? P.mxR1 : -1;
+    S.offGmat = offGmat;
+    S.gmxTiles = bGmat ? P.gmxTiles : 0;
     S.flags = P.flags;
     S.offSph4 = offSph4; S.offInvR = offInvR; S.offMats = offMats; S.offLights = offLights;
     S.offGPairs = offGPairs; S.offGSph = offGSph; S.offGId = offGId; S.offBSph = offBSph; S.offBId = offBId;
@@ -389,6 +397,8 @@ SceneView deviceView()
     sv.nBig = S->nBig;
     sv.amatH = reinterpret_cast<const uint32_t*>(S->dev + S->offAmat);
     sv.mxR1 = S->mxR1;
+    sv.gmatH = reinterpret_cast<const uint32_t*>(S->dev + S->offGmat);
+    sv.gmxTiles = S->gmxTiles;
     sv.flags = S->flags;
     return sv;
 }
@@ -940,7 +950,11 @@ int reserveSlotBuffers(int nSlots, size_t colourBytes, size_t stackBytes, size_t
     // (33..40 frames through tptDrawDeviceBatch: 32 + 1..8) must not free and re-allocate gigabytes on every call.
     const bool small = colourBytes * 4 <= g.colourCap && g.colourCap * (size_t)g.slotsReserved > (1ull << 30);
     g.smallStreak = small ? g.smallStreak + 1 : 0;
-    const bool shrink = small && g.smallStreak >= 8;
+    // ... and never while a frame that was traced ahead (look-ahead, a row-serial or stream batch being served) still waits
+    // for its blend: its ticket points into the very buffers a shrink frees.
+    bool ticketsOut = g.rsb[0].used || g.rsb[1].used || g.sbatch.used;
+    for (int k = 0; k < 4; ++k) ticketsOut = ticketsOut || g.ahead[k].used;
+    const bool shrink = small && g.smallStreak >= 8 && !ticketsOut;
     if (shrink) g.smallStreak = 0;
     if (!shrink && nSlots <= g.slotsReserved && colourBytes <= g.colourCap && stackBytes <= g.stackCap && pathBytes <= g.pathCap) return 0;
     int rc = syncAllStreams();
@@ -1038,8 +1052,6 @@ int chooseKernel(FramePlan& P)
     return 0;
 }
 
-const int kBurstFrames = 24; // frames after an idle pipeline that are launched with burst-sized grids (sizeGrid)
-
 // Work items, chunk size and the number of workgroups of this launch.
 void sizeGrid(FramePlan& P)
 {
@@ -1079,12 +1091,13 @@ void sizeGrid(FramePlan& P)
     if (g.gridDiv > 0) {
         cap = resident / g.gridDiv;
     } else {
-        // fill = how many times the machine the launches in flight ask for together.  200 % is best for a long stream
-        // (64 workgroups per launch at 16 in flight: long steady states, 37.6 vs 34.9 Gray/s); a SHORT burst is dominated
-        // by its end, when the last launches have the machine to themselves -- there 400 % (128 workgroups) wins (31.2 vs
-        // 30.0 Gray/s for 20 frames).  The first frames after the pipeline ran empty are launched as a burst, the rest as
-        // a stream.  100 % when the frame is sharded over ranks (oversubscription buys nothing on small tiles).
-        const int fill = g.gridFill > 0 ? g.gridFill : (g.numParts > 1 ? 100 : (g.framesSinceIdle < kBurstFrames ? 400 : 200));
+        // fill = how many times the machine the launches in flight ask for together: 200 % on a single GPU (64 workgroups per
+        // launch at 16 in flight: long steady states; 100 %: 54.6 vs 55.9 Gray/s), 100 % when the frame is sharded over ranks
+        // (oversubscription buys nothing on small tiles).  Rounds 2-3 gave the first 24 frames after an idle pipeline 400 %:
+        // worth +4.5 % on a burst of exactly 20 frames (whose last launches then fill the machine as it empties), but -8 % on 30
+        // frames and -1.5 % on 100 (profiles/r04/r04_run9.log) and 1.8x the memory traffic per launch -- a constant fitted to
+        // one command line; removed in round 4.
+        const int fill = g.gridFill > 0 ? g.gridFill : (g.numParts > 1 ? 100 : 200);
         // k = how many launches share the machine.  Not just what is in flight right now: a caller that streams frames
         // (enqueue, enqueue, ..., synchronise once) starts every burst with an empty pipeline, and whole-machine grids
         // for the first frames of a burst serialise them (each with its own tail) -- a 20-frame burst ran at 24 instead
@@ -1743,7 +1756,10 @@ int tptDraw(float time, int frameCount, int w, int h, float* backbuffer, int* ou
         if ((rc = enqueueTrace(frameCount, w, h, testFlags, g.dRaysAhead + raySlot, T))) return rc;
     }
     // ---- 2. trace the next frames ahead (a wrong guess costs GPU time only)
-    if (pipelined && stable && T.valid && !servedFromBatch) {
+    // (in the reference's own seed mode the batches above ARE the look-ahead: single frames traced ahead would be 60-90 ms of
+    //  GPU work each, dropped again when the batch is launched -- only a configuration whose batch was refused gets them)
+    const bool rowSerialBatches = g.seedMode == SEED_ROW_SERIAL && !batchRefused && !sharded && !g.mirror && rows > 0;
+    if (pipelined && stable && T.valid && !servedFromBatch && !rowSerialBatches) {
         int rc = traceAhead(frameCount, w, h, testFlags, key, g.lookahead);
         if (rc) return rc;
     }
@@ -2066,7 +2082,6 @@ int tptShardedFinish(int64_t* outTotalRays)
         if (outTotalRays) *outTotalRays = own;
         return 0;
     }
-    const size_t rowBytes = (size_t)S.w * 4 * sizeof(float);
     if (S.rank == 0) {
         for (int r = 0; r < S.nRanks; ++r) {
             unsigned long long v = 0;
@@ -2211,6 +2226,42 @@ int tptTestMatrixFilter(const float* rays, unsigned long long* outMask, int* out
         HIPCHK(hipMemcpy(outT, dt, sizeof(float) * n, hipMemcpyDeviceToHost));
     }
     (void)hipFree(dr); (void)hipFree(dm); (void)hipFree(di); (void)hipFree(dt);
+    return 0;
+}
+
+// The matrix-core filter over the group bounds of the current (grouped) scene against the exact test of every member:
+// outViolations = (ray, member) pairs the reference's discriminant accepts (discr > 0, Maths.cpp:176-178) whose group the
+// filter dropped -- must be 0; outTouched = groups kept per ray (summed), outExact = exact line hits (summed).
+int tptTestGroupFilter(const float* rays, int n, unsigned long long* outViolations, unsigned long long* outTouched, unsigned long long* outExact)
+{
+    if (requireInit()) return -1;
+    if (!rays || n <= 0 || !outViolations) return fail("tptTestGroupFilter: bad arguments");
+    if (g.sceneDirty || (g.curSet < 0 && g.pendingSet < 0)) {
+        int rc = stageScene();
+        if (rc) return rc;
+    }
+    int rc = enqueueSceneUpload(g.stream);
+    if (rc) return rc;
+    KernelArgs a;
+    memset(&a, 0, sizeof(a));
+    a.scene = deviceView();
+    if (a.scene.nGroups <= 0 || a.scene.gmxTiles <= 0) return fail("tptTestGroupFilter: the current scene has no group-bound table (not grouped, a group too loose, or hit-spheres variant 2 / 3)");
+    const int nPad = (n + 63) / 64 * 64;
+    float* dr = nullptr;
+    unsigned long long* dout = nullptr;
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&dr), sizeof(float) * 6 * (size_t)nPad));
+    HIPCHK(hipMalloc(reinterpret_cast<void**>(&dout), sizeof(unsigned long long) * 4));
+    HIPCHK(hipMemsetAsync(dr, 0, sizeof(float) * 6 * (size_t)nPad, g.stream));
+    HIPCHK(hipMemsetAsync(dout, 0, sizeof(unsigned long long) * 4, g.stream));
+    HIPCHK(hipMemcpyAsync(dr, rays, sizeof(float) * 6 * (size_t)n, hipMemcpyHostToDevice, g.stream));
+    HIPCHK(tptLaunchGroupFilterTest(a, dr, n, nPad, dout, g.stream));
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(h, dout, sizeof(h), hipMemcpyDeviceToHost, g.stream));
+    HIPCHK(hipStreamSynchronize(g.stream));
+    *outViolations = h[0];
+    if (outTouched) *outTouched = h[1];
+    if (outExact) *outExact = h[2];
+    (void)hipFree(dr); (void)hipFree(dout);
     return 0;
 }
 

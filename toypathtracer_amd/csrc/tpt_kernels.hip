@@ -399,25 +399,24 @@ __device__ __forceinline__ f4 mk4(float x, float y, float z, float w)
 #ifndef TPT_MATRIX_FILTER
 #define TPT_MATRIX_FILTER 1 // phase 1 of HitSpheres on the matrix cores (v_mfma_f32_32x32x16_f16, f16-split operands) for scenes with a table; 0: packed VALU filter only
 #endif
-#ifndef TPT_P2_DEAL
-// Phase 2 of HitSpheres with the matrix filter: 0 = every lane walks its own candidate mask (4.15 trips per wave for 1.72
-// candidates per ray); n > 0 = n trips in place, then the wave's LEFTOVER (ray, sphere) pairs are dealt out evenly over its
-// lanes through a pair list in LDS and merged per ray with ds_min_u64 on (t bits, sphere id) -- the reference's
-// first-strictly-less rule (Maths.cpp:171-190); see hitSpheresDeal
-#define TPT_P2_DEAL 0
+#ifndef TPT_GROUP_DEAL
+// Grouped traversal of large scenes (the kernel instantiated without LDS scene staging): 1 = the (ray, group) pairs of a wave
+// are dealt out evenly over its lanes through a pair list in LDS (hitSpheresGroupedDeal); 0 = every lane walks the groups its
+// own ray touches (tpt_trace.h hitSpheresGrouped: 10.5 trips per wave at 20 busy lanes for 4.0 groups per ray on the
+// 4096-sphere scene, tools/stats_c5.py, profiles/r04/r04_run4.log)
+#define TPT_GROUP_DEAL 1
 #endif
-#ifndef TPT_P2_DEAL_SHADOW
-#define TPT_P2_DEAL_SHADOW TPT_P2_DEAL /* in-place trips of a shadow ray (2.7 candidates on average instead of 1.7) */
+#ifndef TPT_GROUP_DEAL_EXACT
+#define TPT_GROUP_DEAL_EXACT 1 // the members that pass the member filter are dealt out again for their exact tests (see hitSpheresGroupedDeal)
 #endif
-#ifndef TPT_STACK_NT
-#define TPT_STACK_NT 0 // 1: bounce-stack levels 1-9 (global memory) are written / read with non-temporal accesses
-#endif
+#define TPT_GROUP_DEAL_CAP 192 /* pair-list entries per wave and round (a multiple of 64) */
+#define TPT_GROUP_DEAL_WAVE_BYTES (TPT_GROUP_DEAL_CAP * 4 + 16)
 #define TPT_Q_SPH_FIXED 1024 /* bytes at LDS offset 0 for {centre, r^2} of scenes of <= 64 spheres: DS offsets fold into the instructions */
-#define TPT_Q_DEAL_BYTES (TPT_P2_DEAL ? TPT_Q_WAVES * 144 : 0) /* per wave: 64 x 2 B pair list + the counter */
 #ifndef TPT_Q_PATHS
 // paths per workgroup (<= TPT_Q_P): what the path records in LDS are sized for.  960 with the matrix filter: its 4-KB operand
-// table has to fit beside them for two workgroups per CU (2 x 80 KB); measured no slower than 1024 (profiles/r03/r03_run10.log)
-#define TPT_Q_PATHS (TPT_MATRIX_FILTER ? (TPT_P2_DEAL ? 944 : 960) : TPT_Q_P)
+// table and the fixed 1-KB sphere area have to fit beside them for two workgroups per CU (2 x 80 KB minus the launch code's
+// 256-B margin per workgroup: chooseKernel); 960 measured no slower than 1024 (profiles/r03/r03_run10.log)
+#define TPT_Q_PATHS (TPT_MATRIX_FILTER ? 952 : TPT_Q_P)
 #endif
 #ifndef TPT_Q_FUSE_MIN
 #define TPT_Q_FUSE_MIN 48 // a batch intersects its own rays when at least this many lanes still hold one
@@ -432,16 +431,26 @@ struct QueueCtl {
     unsigned frameRays[32];   // batched launch: rays traced for each frame of the batch by this workgroup (flushed to the global counter every 2^31: see the push)
 };
 
+// The rings (and the pair lists of the grouped traversal) are polled with volatile accesses, and LLVM's address-space inference
+// leaves volatile accesses alone: through a generic pointer they compile to FLAT loads / stores, which reach LDS through the
+// vector-memory path (seen in the ISA of rounds 2-3: flat_load_ushort in the pop and push spins).  Typed as LDS they are ds_ ops.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef volatile unsigned short __attribute__((address_space(3))) * LdsRing;
+typedef volatile unsigned __attribute__((address_space(3))) * LdsList;
+#else
+typedef volatile unsigned short* LdsRing;
+typedef volatile unsigned* LdsList;
+#endif
 // Push every lane's path id to the queue of its class `cls` (Q_FREE..Q_LAMBERT, or -1 for none): one returning LDS atomic
 // per lane reserves the slot (the LDS unit serialises the lanes that hit the same tail word -- its time, not the VALU's:
 // the ballot / popcount / readlane version of this cost ~35 VALU instructions per batch).
 #ifndef TPT_Q_PUSH_BALLOT
-__device__ __forceinline__ void qPushByClass(volatile unsigned short* q, QueueCtl* ctl, int cls, int pathId, int lane)
+__device__ __forceinline__ void qPushByClass(LdsRing q, QueueCtl* ctl, int cls, int pathId, int lane)
 {
     (void)lane;
     if (cls >= 0) {
         const unsigned pos = atomicAdd(&ctl->tail[cls], 1u);
-        volatile unsigned short* slot = q + cls * TPT_Q_P + (pos & (TPT_Q_P - 1));
+        LdsRing slot = q + cls * TPT_Q_P + (pos & (TPT_Q_P - 1));
         // A consumer advances the head BEFORE it reads its slots, and ids can cycle through a ring any number of times
         // while one consumer stalls between those two steps (FREE: pop, no pixel left, push again): the tail may lap a
         // reserved-but-unread slot.  Publish only into a slot whose previous entry has been taken (sentinel restored).
@@ -451,7 +460,7 @@ __device__ __forceinline__ void qPushByClass(volatile unsigned short* q, QueueCt
     }
 }
 #else
-__device__ __forceinline__ void qPushByClass(volatile unsigned short* q, QueueCtl* ctl, int cls, int pathId, int lane)
+__device__ __forceinline__ void qPushByClass(LdsRing q, QueueCtl* ctl, int cls, int pathId, int lane)
 {
     unsigned long long mine = 0ull;
     unsigned myCount = 0;
@@ -470,7 +479,7 @@ __device__ __forceinline__ void qPushByClass(volatile unsigned short* q, QueueCt
         if (cls == c) base = b;
     }
     if (cls >= 0) {
-        volatile unsigned short* slot = q + cls * TPT_Q_P + ((base + (unsigned)__popcll(mine & ((1ull << lane) - 1ull))) & (TPT_Q_P - 1));
+        LdsRing slot = q + cls * TPT_Q_P + ((base + (unsigned)__popcll(mine & ((1ull << lane) - 1ull))) & (TPT_Q_P - 1));
         while (*slot != 0xFFFFu) {
         }
         *slot = (unsigned short)pathId;
@@ -478,16 +487,40 @@ __device__ __forceinline__ void qPushByClass(volatile unsigned short* q, QueueCt
 }
 #endif
 // Pops up to 64 ids (uniform count returned); lanes < count receive a path id.
-__device__ __forceinline__ int qPop(volatile unsigned short* q, unsigned* head, unsigned* tail, int lane, int& pathId)
+// h0 / t0: the head and tail the wave read when it chose this queue -- the first reservation is attempted with them (one LDS
+// round trip less per iteration than reading both again first: -DTPT_Q_POP_SNAPSHOT=0); a stale pair just fails the CAS.
+#ifndef TPT_Q_POP_SNAPSHOT
+#define TPT_Q_POP_SNAPSHOT 1
+#endif
+__device__ __forceinline__ int qPop(LdsRing q, unsigned* head, unsigned* tail, int lane, int& pathId, unsigned h0, unsigned t0)
 {
     unsigned h = 0, n = 0;
     if (lane == 0) {
+        bool first = TPT_Q_POP_SNAPSHOT != 0;
         for (;;) {
-            h = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const unsigned t = __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            const unsigned avail = t - h;
-            n = avail < 64u ? avail : 64u;
-            if (n == 0u) break;
+            unsigned t;
+            if (first) {
+                h = h0;
+                t = t0;
+            } else {
+                h = __hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                t = __hip_atomic_load(tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            // A (head, tail) pair read by two loads may be torn: a tail older than the head it is paired with -- consumers and
+            // producers both moved in between -- makes tail - head wrap to 4 billion, and a CAS that still finds that head would
+            // reserve 64 slots nobody will ever fill (every wave of the workgroup ends up spinning on an unpublished slot: seen once
+            // the snapshot pair was reused, profiles/r04/r04_run11.log).  A pair is only ever used when tail - head is positive as
+            // a SIGNED number: then tail - head <= (tail now) - head, whatever the order of the two loads.
+            const int avail = (int)(t - h);
+            n = avail <= 0 ? 0u : (avail < 64 ? (unsigned)avail : 64u);
+            if (n == 0u) {
+                if (first) { // the snapshot is stale or torn: look again before giving up
+                    first = false;
+                    continue;
+                }
+                break;
+            }
+            first = false;
             if (atomicCAS(head, h, h + n) == h) break;
         }
     }
@@ -506,68 +539,158 @@ __device__ __forceinline__ int qPop(volatile unsigned short* q, unsigned* head, 
     return (int)n;
 }
 
-#if TPT_P2_DEAL
-// Phase 2 of HitSpheres for a whole wave (every lane calls it; lanes without a ray pass cand = 0): the reference's exact test
-// (testSphere, Maths.cpp:171-190) for the candidates the matrix filter left -- `inplace` trips by the lane that owns the ray,
-// then the LEFTOVER candidates of all lanes are dealt out evenly:
-//   * a lane with k leftovers reserves k entries of the wave's pair list with one LDS atomic and writes (its path id, sphere)
-//     pairs; it parks its ray {o, d} and its best hit so far -- the 64-bit key (t bits << 32 | sphere id) -- in planes 0 / 1 of
-//     its own path record, which are dead while the path is held by this wave (they are rewritten when the iteration ends);
-//   * lane j of the wave takes entry j: reads the ray from the owner's record, runs testSphere, and merges a hit into the
-//     owner's key with ds_min_u64 -- smaller t wins, equal t: the lower sphere index, which is what ascending order with a
-//     strict t < hitT gives the reference (t > tMin > 0, so the bit patterns order like the values);
-//   * the owner reads its key back.
-// More than 64 leftovers in a wave: the surplus is tested in place by its owner (rare).  One wave, no barrier: a wave's LDS
-// operations execute in order; wave_barrier only keeps the compiler from moving them.
-__device__ __forceinline__ int hitSpheresDeal(const f4* sph, uint64_t cand, f3 o, f3 d, float& outT, int inplace, volatile unsigned short* list,
-                                              unsigned* listCount, f4* st, int p, int lane)
+
+#if TPT_GROUP_DEAL
+// HitWorld over a GROUPED scene for a whole wave (every lane calls it; lanes without a ray pass go = false): the same tests
+// as tpt_trace.h's hitSpheresGrouped -- big spheres exactly, the groups' bounding spheres through the wave-uniform packed filter,
+// the members of every touched group through the per-member filter, the reference's exact test (Maths.cpp:171-190) for what
+// passes, lowest original index among equal t -- but the (ray, group) pairs are dealt out evenly over the lanes instead of every
+// lane walking its own ray's groups (on the 4096-sphere scene a ray touches 4.0 groups, the busiest lane of a wave 10.5):
+//   * a lane whose ray touches k groups reserves k entries of the wave's pair list with one LDS atomic and writes
+//     (its path id << 16 | group) pairs; its ray {o, d} and its best hit so far -- the 64-bit key (t bits << 32 | sphere id) --
+//     are parked in planes 0 / 1 of its own path record, which are dead while this wave holds the path;
+//   * lane j takes entry j (rounds of 64): reads the ray, filters the 16 members, runs the exact test on what passes and merges
+//     its best hit into the owner's key with ds_min_u64: smaller t wins, equal t: the lower ORIGINAL sphere index -- the
+//     reference's first-strictly-less rule made explicit (t > tMin > 0: the bit patterns order like the values);
+//   * pairs that do not fit the list (TPT_GROUP_DEAL_CAP per round) stay in their lane's mask for the next round.
+// One wave, no barrier: a wave's LDS operations execute in order; wave_barrier only pins the compiler.
+__device__ __forceinline__ int hitSpheresGroupedDeal(const SceneView& sv, bool go, f3 o, f3 d, float& outT, LdsList list, unsigned* listCount,
+                                                     f4* st, int p, int lane)
 {
     float hitT = TPT_MAX_T;
     int id = -1;
-#pragma unroll 1
-    for (int k = 0; k < inplace; ++k) {
-        if (cand) {
-            const int i = __builtin_clzll(cand);
-            cand &= ~(0x8000000000000000ull >> i);
-            testSphere(sph[i], i, o, d, TPT_MIN_T, hitT, id);
+    if (go)
+        for (int b = 0; b < sv.nBig; ++b) testSphereTie(sv.bsph[b], sv.bid[b], o, d, TPT_MIN_T, hitT, id);
+    const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+    const float gx = d.x * TPT_PG_K, gy = d.y * TPT_PG_K, gz = d.z * TPT_PG_K;
+    const v2f dx = {gx, gx}, dy = {gy, gy}, dz = {gz, gz};
+    bool parked = false;
+    // the bounding spheres: on the matrix cores when the scene has a table for them (one 4-KB tile pair per 64 groups, read
+    // through the vector cache: every wave of the CU reads the same 16 KB per 256 groups), else the packed VALU filter
+    const bool boundsOnMatrix = TPT_MATRIX_FILTER && sv.gmxTiles > 0;
+    MatrixRayOps mops;
+    if (boundsOnMatrix) matrixRayOperands(o, d, 1, mops);
+    for (int pb0 = 0; pb0 < sv.nGroupPairs; pb0 += 128) {
+        // wave-uniform filter on the bounding spheres of up to 256 groups: four 64-bit candidate masks per lane
+        uint64_t cm0 = 0, cm1 = 0, cm2 = 0, cm3 = 0;
+        if (boundsOnMatrix) {
+            const int g0 = pb0 * 2, left = sv.nGroups - g0; // groups from here on
+            const uint4* A = reinterpret_cast<const uint4*>(sv.gmatH) + (size_t)(g0 / 64) * (TPT_MXH_TABLE_DWORDS / 4);
+            cm0 = matrixApply(A, 16, left < 64 ? left : 64, mops);
+            if (left > 64) cm1 = matrixApply(A + TPT_MXH_TABLE_DWORDS / 4, 16, left - 64 < 64 ? left - 64 : 64, mops);
+            if (left > 128) cm2 = matrixApply(A + 2 * (TPT_MXH_TABLE_DWORDS / 4), 16, left - 128 < 64 ? left - 128 : 64, mops);
+            if (left > 192) cm3 = matrixApply(A + 3 * (TPT_MXH_TABLE_DWORDS / 4), 16, left - 192 < 64 ? left - 192 : 64, mops);
+        } else {
+            const int left = sv.nGroupPairs - pb0;
+            cm0 = phase1Chunk(pairPtr(sv.gpairs + (size_t)pb0 * 8), left < 32 ? left : 32, ox, oy, oz, dx, dy, dz);
+            if (left > 32) cm1 = phase1Chunk(pairPtr(sv.gpairs + (size_t)(pb0 + 32) * 8), left - 32 < 32 ? left - 32 : 32, ox, oy, oz, dx, dy, dz);
+            if (left > 64) cm2 = phase1Chunk(pairPtr(sv.gpairs + (size_t)(pb0 + 64) * 8), left - 64 < 32 ? left - 64 : 32, ox, oy, oz, dx, dy, dz);
+            if (left > 96) cm3 = phase1Chunk(pairPtr(sv.gpairs + (size_t)(pb0 + 96) * 8), left - 96 < 32 ? left - 96 : 32, ox, oy, oz, dx, dy, dz);
+        }
+        if (!go) cm0 = cm1 = cm2 = cm3 = 0ull;
+        while (__ballot((cm0 | cm1 | cm2 | cm3) != 0ull) != 0ull) { // rounds: until every touched group of every lane has been dealt
+            const unsigned n = (unsigned)(__popcll(cm0) + __popcll(cm1) + __popcll(cm2) + __popcll(cm3));
+            if (lane == 0) *listCount = 0u;
+            __builtin_amdgcn_wave_barrier();
+            if (n != 0u) {
+                unsigned pos = atomicAdd(listCount, n);
+                while (pos < (unsigned)TPT_GROUP_DEAL_CAP) { // write the entries that fit; the rest stay in the masks
+                    const int sel = cm0 ? 0 : cm1 ? 1 : cm2 ? 2 : 3;
+                    const uint64_t w = cm0 ? cm0 : cm1 ? cm1 : cm2 ? cm2 : cm3;
+                    if (!w) break;
+                    const int k = __builtin_clzll(w);
+                    const uint64_t keep = ~(0x8000000000000000ull >> k);
+                    cm0 &= sel == 0 ? keep : ~0ull;
+                    cm1 &= sel == 1 ? keep : ~0ull;
+                    cm2 &= sel == 2 ? keep : ~0ull;
+                    cm3 &= sel == 3 ? keep : ~0ull;
+                    list[pos] = ((unsigned)p << 16) | (unsigned)((pb0 + sel * 32) * 2 + k);
+                    ++pos;
+                }
+                if (!parked) { // (o and d do not change between rounds; the key is kept current by the atomics)
+                    st[p] = mk4(u2f((uint32_t)id), hitT, o.x, o.y); // {key lo = sphere id, key hi = t bits, o.x, o.y}
+                    st[TPT_Q_PATHS + p] = mk4(o.z, d.x, d.y, d.z);
+                    parked = true;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            unsigned total = __hip_atomic_load(listCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            total = total < (unsigned)TPT_GROUP_DEAL_CAP ? total : (unsigned)TPT_GROUP_DEAL_CAP;
+            for (unsigned base = 0; base < total; base += 64u) {
+                const bool have = base + (unsigned)lane < total;
+                unsigned e = 0;
+                if (have) e = list[base + (unsigned)lane];
+                const int po = (int)(e >> 16), g = (int)(e & 0xffffu);
+                uint32_t mm = 0;
+                f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0);
+                const f4* mem = sv.gsph + (size_t)g * TPT_GROUP;
+                if (have) {
+                    const f4 r0 = st[po], r1 = st[TPT_Q_PATHS + po];
+                    ro = mk3(r0.z, r0.w, r1.x);
+                    rd = mk3(r1.y, r1.z, r1.w);
+                    const f3 dk = mk3(rd.x * TPT_P1_K, rd.y * TPT_P1_K, rd.z * TPT_P1_K);
+                    TPT_STAT(ST_SPHERELOOP); // profiling build: group visits
+#pragma unroll 4
+                    for (int j = 0; j < TPT_GROUP; ++j) mm |= (memberFilter(mem[j], ro, dk) ? 1u : 0u) << j;
+                }
+#if TPT_GROUP_DEAL_EXACT
+                // The members that passed -- 0.33 per pair, so a lane-by-lane loop runs 2-3 trips at 8 busy lanes -- are dealt out once
+                // more: (owner's path id << 20 | member slot) entries into the 64 list positions this sub-round has just consumed,
+                // one exact test per lane.  (More than 64 survivors: the surplus is tested in place.)
+                if (lane == 0) listCount[1] = 0u;
+                __builtin_amdgcn_wave_barrier();
+                float ht = TPT_MAX_T;
+                int hid = -1;
+                if (mm) {
+                    unsigned pos = atomicAdd(&listCount[1], (unsigned)__popc(mm));
+                    while (mm) {
+                        const int j = __builtin_ctz(mm);
+                        mm &= mm - 1u;
+                        if (pos < 64u) {
+                            list[base + pos] = ((unsigned)po << 20) | (unsigned)(g * TPT_GROUP + j);
+                        } else {
+                            TPT_STAT(ST_PHASE2);
+                            testSphereTie(mem[j], sv.gid[g * TPT_GROUP + j], ro, rd, TPT_MIN_T, ht, hid);
+                        }
+                        ++pos;
+                    }
+                    if (hid >= 0) atomicMin(reinterpret_cast<unsigned long long*>(&st[po]), ((unsigned long long)f2u(ht) << 32) | (unsigned long long)(uint32_t)hid);
+                }
+                __builtin_amdgcn_wave_barrier();
+                unsigned nSurv = __hip_atomic_load(&listCount[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                nSurv = nSurv < 64u ? nSurv : 64u;
+                if ((unsigned)lane < nSurv) {
+                    const unsigned e2 = list[base + (unsigned)lane];
+                    const int po2 = (int)(e2 >> 20), slot = (int)(e2 & 0xfffffu);
+                    const f4 q0 = st[po2], q1 = st[TPT_Q_PATHS + po2];
+                    float ht2 = TPT_MAX_T;
+                    int hid2 = -1;
+                    TPT_STAT(ST_PHASE2);
+                    testSphereTie(sv.gsph[slot], sv.gid[slot], mk3(q0.z, q0.w, q1.x), mk3(q1.y, q1.z, q1.w), TPT_MIN_T, ht2, hid2);
+                    if (hid2 >= 0) atomicMin(reinterpret_cast<unsigned long long*>(&st[po2]), ((unsigned long long)f2u(ht2) << 32) | (unsigned long long)(uint32_t)hid2);
+                }
+                __builtin_amdgcn_wave_barrier();
+#else
+                if (have) {
+                    float ht = TPT_MAX_T;
+                    int hid = -1;
+                    while (mm) {
+                        const int j = __builtin_ctz(mm);
+                        mm &= mm - 1u;
+                        TPT_STAT(ST_PHASE2);
+                        testSphereTie(mem[j], sv.gid[g * TPT_GROUP + j], ro, rd, TPT_MIN_T, ht, hid);
+                    }
+                    if (hid >= 0) atomicMin(reinterpret_cast<unsigned long long*>(&st[po]), ((unsigned long long)f2u(ht) << 32) | (unsigned long long)(uint32_t)hid);
+                }
+#endif
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
-    if (__ballot(cand != 0ull) != 0ull) {
-        const unsigned n = (unsigned)__popcll(cand);
-        if (lane == 0) *listCount = 0u;
-        __builtin_amdgcn_wave_barrier();
-        if (n != 0u) {
-            unsigned pos = atomicAdd(listCount, n);
-            while (cand) {
-                const int i = __builtin_clzll(cand);
-                cand &= ~(0x8000000000000000ull >> i);
-                if (pos < 64u)
-                    list[pos] = (unsigned short)((p << 6) | i);
-                else
-                    testSphere(sph[i], i, o, d, TPT_MIN_T, hitT, id); // the wave's list is full: in place
-                ++pos;
-            }
-            st[p] = mk4(u2f((uint32_t)id), hitT, o.x, o.y); // {key lo = id, key hi = t bits, o.x, o.y}
-            st[TPT_Q_PATHS + p] = mk4(o.z, d.x, d.y, d.z);
-        }
-        __builtin_amdgcn_wave_barrier();
-        unsigned total = __hip_atomic_load(listCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        total = total < 64u ? total : 64u;
-        if ((unsigned)lane < total) {
-            const unsigned e = list[lane];
-            const int po = (int)(e >> 6), i = (int)(e & 63u);
-            const f4 r0 = st[po], r1 = st[TPT_Q_PATHS + po];
-            float ht = TPT_MAX_T;
-            int hid = -1;
-            testSphere(sph[i], i, mk3(r0.z, r0.w, r1.x), mk3(r1.y, r1.z, r1.w), TPT_MIN_T, ht, hid);
-            if (hid >= 0) atomicMin(reinterpret_cast<unsigned long long*>(&st[po]), ((unsigned long long)f2u(ht) << 32) | (unsigned long long)(uint32_t)hid);
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (n != 0u) {
-            const f4 k = st[p];
-            id = (int)f2u(k.x);
-            hitT = k.y;
-        }
+    if (parked) {
+        const f4 k = st[p];
+        id = (int)f2u(k.x);
+        hitT = k.y;
     }
     outT = hitT;
     return id;
@@ -606,10 +729,11 @@ tptTraceQueueKernel(const KernelArgs a)
     constexpr int kOffQ = kOffSt + TPT_Q_NF4 * TPT_Q_PATHS * 16;
     constexpr int kOffCtl = kOffQ + Q_COUNT * TPT_Q_P * 2;
     constexpr int kOffDeal = kOffCtl + (((int)sizeof(QueueCtl) + 63) & ~63);
-    constexpr int kOffFc = kOffDeal + TPT_Q_DEAL_BYTES;
+    constexpr int kDealBytes = (!LDS_SCENE && TPT_GROUP_DEAL) ? TPT_Q_WAVES * TPT_GROUP_DEAL_WAVE_BYTES : 0; // pair lists of the grouped traversal
+    constexpr int kOffFc = kOffDeal + kDealBytes;
     constexpr int kOffScene = kOffFc + (((int)sizeof(FrameConsts) + 15) & ~15);
     f4* st = reinterpret_cast<f4*>(smem + kOffSt);
-    volatile unsigned short* q = reinterpret_cast<volatile unsigned short*>(smem + kOffQ);
+    LdsRing q = (LdsRing)(smem + kOffQ);
     QueueCtl* ctl = reinterpret_cast<QueueCtl*>(smem + kOffCtl);
     // the frame constants the camera code reads (22 camera floats, 1/w, 1/h): in LDS, read where a sample starts, instead of
     // ~30 SGPRs held (and spilled) across the whole loop
@@ -673,9 +797,10 @@ tptTraceQueueKernel(const KernelArgs a)
     SceneView svM = sv; // what phase 2 behind the matrix filter reads: {centre, r^2} at their compile-time LDS address
     svM.sph4 = ldsSphFixed;
 #endif
-#if TPT_P2_DEAL
-    volatile unsigned short* dealList = reinterpret_cast<volatile unsigned short*>(smem + kOffDeal + (tid >> 6) * 144);
-    unsigned* dealCount = reinterpret_cast<unsigned*>(smem + kOffDeal + (tid >> 6) * 144 + 128);
+#if TPT_GROUP_DEAL
+    LdsList dealList = (LdsList)(smem + kOffDeal + (tid >> 6) * TPT_GROUP_DEAL_WAVE_BYTES);
+    unsigned* dealCount = reinterpret_cast<unsigned*>(smem + kOffDeal + (tid >> 6) * TPT_GROUP_DEAL_WAVE_BYTES + TPT_GROUP_DEAL_CAP * 4);
+    const bool groupDeal = !LDS_SCENE && sv.nGroups > 0 && sv.nGroups <= 65536; // (16 bits of group index, 20 of member slot, in a list entry)
 #endif
     f4* colSum = st + 2 * TPT_Q_PATHS;                        // plane 2: per-path colour sums + pixel coordinates
     int chunkNext = 0, chunkEnd = 0; // this wave's private pixel pool
@@ -706,10 +831,12 @@ tptTraceQueueKernel(const KernelArgs a)
     for (;;) {
         TPT_TSTAMP(tsTop);
         // ---- what is waiting?  lanes 0..5 read one queue each, broadcast through readlane
-        unsigned myAvail = 0;
-        if (lane < Q_COUNT)
-            myAvail = __hip_atomic_load(&ctl->tail[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) -
-                      __hip_atomic_load(&ctl->head[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        unsigned myAvail = 0, myHead = 0, myTail = 0;
+        if (lane < Q_COUNT) {
+            myTail = __hip_atomic_load(&ctl->tail[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            myHead = __hip_atomic_load(&ctl->head[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            myAvail = myTail - myHead;
+        }
         unsigned avail[Q_COUNT];
 #pragma unroll
         for (int c = 0; c < Q_COUNT; ++c) avail[c] = (unsigned)__builtin_amdgcn_readlane((int)myAvail, c);
@@ -750,7 +877,8 @@ tptTraceQueueKernel(const KernelArgs a)
             continue;
         }
         int p = 0;
-        const int n = qPop(q + pick * TPT_Q_P, &ctl->head[pick], &ctl->tail[pick], lane, p);
+        const int n = qPop(q + pick * TPT_Q_P, &ctl->head[pick], &ctl->tail[pick], lane, p, (unsigned)__builtin_amdgcn_readlane((int)myHead, pick),
+                           (unsigned)__builtin_amdgcn_readlane((int)myTail, pick));
         if (n == 0) continue;
 #if defined(TPT_STATS)
         qBatches++;
@@ -773,7 +901,7 @@ tptTraceQueueKernel(const KernelArgs a)
         bool toFree = false; // this lane's path goes back to the FREE queue
         bool toEnd = false;  // Metal whose scattered ray points into the surface: the path ends (END class), nothing to intersect
         QStack stack;
-        stack.l0 = st + 3 * TPT_Q_PATHS + p; // level 0 in the path record
+        stack.l0 = (LdsF4Ptr)(st + 3 * TPT_Q_PATHS + p); // level 0 in the path record
         stack.spill = a.stackBuf + ((size_t)blockIdx.x * TPT_Q_PATHS + p);
         stack.stride = a.stackStride;
         QLambert lam;
@@ -950,25 +1078,28 @@ tptTraceQueueKernel(const KernelArgs a)
                 uint64_t cand = 0ull;
                 if (LDS_SCENE && useMatrix) cand = phase1MatrixH(ldsA, mxR1, sv.nSpheres, ro, d2);
 #endif
-#if TPT_P2_DEAL
+#if TPT_GROUP_DEAL
                 int dealId = -1;
                 float dealT = TPT_MAX_T;
-                if (LDS_SCENE && useMatrix) // (wave-uniform: every lane takes part, lanes without a ray as helpers only)
-                    dealId = hitSpheresDeal(ldsSphFixed, go ? cand : 0ull, ro, d2, dealT, shadow ? TPT_P2_DEAL_SHADOW : TPT_P2_DEAL, dealList, dealCount, st, p, lane);
+                if (!LDS_SCENE && groupDeal) // (wave-uniform: every lane takes part, lanes without a ray as helpers only)
+                    dealId = hitSpheresGroupedDeal(sv, go, ro, d2, dealT, dealList, dealCount, st, p, lane);
 #endif
                 if (go) {
                     TPT_STAT(ST_STEP);
                     float t;
-#if TPT_P2_DEAL
-                    int id = dealId;
-                    t = dealT;
-                    if (!(LDS_SCENE && useMatrix)) id = hitSpheres<LDS_SCENE ? HS_TWO_PHASE : HS_TWO_PHASE_GROUPS>(sv, ro, d2, TPT_MIN_T, TPT_MAX_T, t);
-#elif TPT_MATRIX_FILTER
-                    const int id = (LDS_SCENE && useMatrix) ? hitSpheresCandidates(svM, cand, ro, d2, TPT_MIN_T, TPT_MAX_T, t)
-                                                            : hitSpheres<LDS_SCENE ? HS_TWO_PHASE : HS_TWO_PHASE_GROUPS>(sv, ro, d2, TPT_MIN_T, TPT_MAX_T, t);
-#else
-                    const int id = hitSpheres<LDS_SCENE ? HS_TWO_PHASE : HS_TWO_PHASE_GROUPS>(sv, ro, d2, TPT_MIN_T, TPT_MAX_T, t);
+                    int id;
+#if TPT_GROUP_DEAL
+                    if (!LDS_SCENE && groupDeal) {
+                        id = dealId;
+                        t = dealT;
+                    } else
 #endif
+#if TPT_MATRIX_FILTER
+                    if (LDS_SCENE && useMatrix)
+                        id = hitSpheresCandidates(svM, cand, ro, d2, TPT_MIN_T, TPT_MAX_T, t);
+                    else
+#endif
+                        id = hitSpheres<LDS_SCENE ? HS_TWO_PHASE : HS_TWO_PHASE_GROUPS>(sv, ro, d2, TPT_MIN_T, TPT_MAX_T, t);
                     if (BATCH) iterRays++; else myRays++;
                     if (shadow) {
                         if (id == lightId) qLightShade(l1, d2, lam);
@@ -1133,6 +1264,47 @@ __global__ void __launch_bounds__(64) tptMatrixFilterTestKernel(const KernelArgs
     }
 }
 
+// the matrix-core filter over the group bounds against the exact test of every member: one wave per 64 rays (rays beyond n are
+// padding: a valid far-away ray whose results are ignored); out[0] = violations, out[1] = groups kept, out[2] = exact line hits
+__global__ void __launch_bounds__(64) tptGroupFilterTestKernel(const KernelArgs a, const float* __restrict__ rays, int n, unsigned long long* __restrict__ out)
+{
+    const SceneView& sv = a.scene;
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    const bool real = i < n;
+    f3 o = mk3(0.0f, 1.0e4f, 0.0f), d = mk3(0.0f, 1.0f, 0.0f);
+    if (real) {
+        o = mk3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]);
+        d = mk3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
+    }
+    MatrixRayOps mops;
+    matrixRayOperands(o, d, 1, mops);
+    unsigned long long bad = 0, kept = 0, exact = 0;
+    for (int t = 0; t < sv.gmxTiles; ++t) {
+        const int left = sv.nGroups - t * 64;
+        const uint64_t m = matrixApply(reinterpret_cast<const uint4*>(sv.gmatH) + (size_t)t * (TPT_MXH_TABLE_DWORDS / 4), 16, left < 64 ? left : 64, mops);
+        if (!real) continue;
+        kept += (unsigned long long)__popcll(m);
+        for (int q = 0; q < 64 && q < left; ++q) {
+            const bool keptBit = (m >> (63 - q)) & 1ull;
+            const f4* mem = sv.gsph + (size_t)(t * 64 + q) * TPT_GROUP;
+            for (int j = 0; j < TPT_GROUP; ++j) {
+                const f4 s = mem[j];
+                // the reference's discriminant, Maths.cpp:171-178 (padding members carry r^2 = -inf: never positive)
+                const float coX = s.x - o.x, coY = s.y - o.y, coZ = s.z - o.z;
+                const float nb = coX * d.x + coY * d.y + coZ * d.z;
+                const float c = coX * coX + coY * coY + coZ * coZ - s.w;
+                const float discr = nb * nb - c;
+                if (discr > 0) {
+                    ++exact;
+                    if (!keptBit) ++bad;
+                }
+            }
+        }
+    }
+    if (bad) atomicAdd(&out[0], bad);
+    atomicAdd(&out[1], kept);
+    atomicAdd(&out[2], exact);
+}
 #endif // TPT_TEST_HOOKS
 
 } // namespace tpt
@@ -1218,13 +1390,23 @@ int tptTraceOccupancy(int hs, int fold, bool ldsScene, size_t lds)
     TPT_DISPATCH(occupancyOne, lds);
 }
 
+// Two workgroups per CU is what the path-queue kernel is tuned for; the launch code (chooseKernel) drops the LDS scene --
+// and with it the matrix-core filter: 58 -> 41 Gray/s -- as soon as 2 x (LDS + 256-B margin) exceeds 160 KB.  The built-in
+// 46-sphere scene with 2 lights must fit: checked at compile time, because a few hundred bytes too many are silent at run time.
+namespace {
+constexpr size_t kQueueLdsFixedPart = (size_t)TPT_Q_NF4 * TPT_Q_PATHS * 16 + (size_t)Q_COUNT * TPT_Q_P * 2 + ((sizeof(tpt::QueueCtl) + 63) & ~(size_t)63) +
+                                      ((sizeof(tpt::FrameConsts) + 15) & ~(size_t)15);
+constexpr size_t kDefaultSceneLds = TPT_Q_SPH_FIXED + ((46 * 4 + 15) & ~15) + 46 * 48 + 2 * 32 + (TPT_MATRIX_FILTER ? TPT_MXH_TABLE_DWORDS * 4 + 64 : 0);
+static_assert(2 * (kQueueLdsFixedPart + kDefaultSceneLds + 256) <= 160 * 1024, "the default scene no longer fits two path-queue workgroups per CU: shrink TPT_Q_PATHS");
+}
 size_t tptQueueLdsBytes(const KernelArgs& a, bool ldsScene)
 {
     const int nPad = a.scene.nPairs * 2;
     size_t bytes = 0;
     if (ldsScene) bytes += TPT_Q_SPH_FIXED + ((size_t)nPad * 16 <= TPT_Q_SPH_FIXED ? 0 : (size_t)nPad * 16) + (((size_t)nPad * 4 + 15) & ~(size_t)15) + (size_t)a.scene.nSpheres * 48;
     bytes += (size_t)a.scene.nLights * 32;
-    bytes += (size_t)TPT_Q_NF4 * TPT_Q_PATHS * 16 + (size_t)Q_COUNT * TPT_Q_P * 2 + ((sizeof(QueueCtl) + 63) & ~(size_t)63) + ((sizeof(FrameConsts) + 15) & ~(size_t)15) + TPT_Q_DEAL_BYTES;
+    bytes += (size_t)TPT_Q_NF4 * TPT_Q_PATHS * 16 + (size_t)Q_COUNT * TPT_Q_P * 2 + ((sizeof(QueueCtl) + 63) & ~(size_t)63) + ((sizeof(FrameConsts) + 15) & ~(size_t)15);
+    if (!ldsScene && TPT_GROUP_DEAL) bytes += (size_t)TPT_Q_WAVES * TPT_GROUP_DEAL_WAVE_BYTES;
 #if TPT_MATRIX_FILTER
     if (ldsScene && a.scene.mxR1 >= 0) bytes += TPT_MXH_TABLE_DWORDS * sizeof(uint32_t) + 64;
 #endif
@@ -1322,6 +1504,11 @@ hipError_t tptLaunchMathExhaustive(int op, unsigned lo, unsigned hi, unsigned lo
 hipError_t tptLaunchMatrixFilterTest(const KernelArgs& a, const float* rays, unsigned long long* outMask, int* outId, float* outT, int n, hipStream_t stream)
 {
     hipLaunchKernelGGL(tptMatrixFilterTestKernel, dim3(n / 64), dim3(64), 0, stream, a, rays, outMask, outId, outT, n);
+    return hipGetLastError();
+}
+hipError_t tptLaunchGroupFilterTest(const KernelArgs& a, const float* rays, int n, int nPad, unsigned long long* out4, hipStream_t stream)
+{
+    hipLaunchKernelGGL(tptGroupFilterTestKernel, dim3(nPad / 64), dim3(64), 0, stream, a, rays, n, out4);
     return hipGetLastError();
 }
 hipError_t tptLaunchHitTest(const KernelArgs& a, int hs, const float* rays, int* outId, float* outT, int n, hipStream_t stream)

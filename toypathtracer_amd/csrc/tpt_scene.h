@@ -127,17 +127,20 @@ struct PackedScene {
     int nGroups = 0, nGroupPairs = 0, nBig = 0;
     std::vector<uint32_t> amatH; // [2][2][64][4] A operands of the matrix-core filter (phase1MatrixH); empty: not available
     int mxR1 = -1;
+    std::vector<uint32_t> gmatH; // grouped scenes: [tiles of 64 groups][2][2][64][4] A operands for the group bounds; empty: not available
+    int gmxTiles = 0;
     int flags = 0;               // SCENE_* bits (tpt_trace.h)
 };
 
 // a_k of one sphere for the matrix-core filter (tpt_trace.h, phase1MatrixH): binary64, rounded once; a_9 carries the
 // sphere side of the slack, m_s = 2^-13 |c|^2 + 2^-14 r^2 + 2^-20
-inline void matrixSphereSide(float fcx, float fcy, float fcz, float fr2, float* a)
+// (slackShift 1: the group-bound table, twice the slack -- see buildGroupMatrixTable)
+inline void matrixSphereSide(float fcx, float fcy, float fcz, float fr2, float* a, int slackShift = 0)
 {
     const double cx = fcx, cy = fcy, cz = fcz, r2 = fr2;
-    const double cc = cx * cx + cy * cy + cz * cz;
+    const double cc = cx * cx + cy * cy + cz * cz, k = slackShift ? 2.0 : 1.0;
     const double v[TPT_MX_K] = {cx * cx, cy * cy, cz * cz, 2 * cx * cy, 2 * cx * cz, 2 * cy * cz, 2 * cx, 2 * cy, 2 * cz,
-                                (r2 - cc) + cc / 8192.0 + r2 / 16384.0 + 1.0 / 1048576.0, 1.0};
+                                (r2 - cc) + k * cc / 8192.0 + k * r2 / 16384.0 + 1.0 / 1048576.0, 1.0};
     for (int k = 0; k < TPT_MX_K; ++k) a[k] = (float)v[k];
 }
 
@@ -146,6 +149,46 @@ inline void matrixSphereSide(float fcx, float fcy, float fcz, float fr2, float* 
 // amatH[((mt * 2 + j) * 64 + lane) * 4 + w] holds slots 16 j + 8 (lane / 32) + 2 w, + 1 of the sphere in row lane % 32 of
 // sphere tile mt.  Scenes of up to 64 spheres whose a_k all fit binary16 (|a_k| < 60000); otherwise no table (mxR1 = -1)
 // and the packed VALU filter runs.
+// one 64-entry tile pair (4 KB = 1024 dwords at T): padding rows first, then entry q = 0 .. n - 1 from a[q][0..10]
+inline void matrixPut(uint32_t* T, int mt, int row, int slot, uint32_t h)
+{
+    const int j = slot / 16, within = slot % 16, lane = row + 32 * (within / 8), w = (within % 8) / 2;
+    uint32_t& d = T[(size_t)((mt * 2 + j) * 64 + lane) * 4 + w];
+    d = (slot & 1) ? ((d & 0x0000ffffu) | (h << 16)) : ((d & 0xffff0000u) | h);
+}
+inline void matrixPadRows(uint32_t* T)
+{
+    // padding rows: a9_hi = -inf (slot 29, whose B value is 1), everything else 0: the sum is -inf, sign set, never a candidate
+    for (int mt = 0; mt < 2; ++mt)
+        for (int row = 0; row < 32; ++row) matrixPut(T, mt, row, 29, 0xfc00u);
+}
+inline bool matrixPutEntry(uint32_t* T, int q, int R1, const float* a) // false: binary16 cannot carry this entry
+{
+    int mt, row;
+    matrixSlot(q, R1, mt, row);
+    uint32_t hi[10], lo[10];
+    for (int k = 0; k < 10; ++k) {
+        if (!(fabsf(a[k]) < 60000.0f)) return false; // (also NaN)
+        hi[k] = f16rtz(a[k]);
+        lo[k] = f16rtz(a[k] - f16val(hi[k]));
+    }
+    const uint32_t one = 0x3c00u;
+    for (int t = 0; t < TPT_MXH_TERMS; ++t) {
+        matrixPut(T, mt, row, 2 * t, hi[t]);
+        matrixPut(T, mt, row, 2 * t + 1, hi[t]);
+    }
+    for (int u = 0; u < 4; ++u) {
+        matrixPut(T, mt, row, 18 + 2 * u, lo[2 * u]);
+        matrixPut(T, mt, row, 19 + 2 * u, lo[2 * u + 1]);
+    }
+    matrixPut(T, mt, row, 26, lo[8]);
+    matrixPut(T, mt, row, 27, one);
+    matrixPut(T, mt, row, 28, one);
+    matrixPut(T, mt, row, 29, hi[9]);
+    matrixPut(T, mt, row, 30, lo[9]);
+    matrixPut(T, mt, row, 31, 0u);
+    return true;
+}
 inline void buildMatrixTable(const std::vector<SpherePOD>& S, PackedScene& P)
 {
     P.amatH.clear();
@@ -155,43 +198,42 @@ inline void buildMatrixTable(const std::vector<SpherePOD>& S, PackedScene& P)
     int R1 = 0;
     if (n > 32) R1 = ((n - 32 + 1) / 2 + 3) / 4 * 4; // rows per half of tile 1, multiple of 4: capacity 2 (16 + R1) >= n
     std::vector<uint32_t> T(TPT_MXH_TABLE_DWORDS, 0u);
-    auto put = [&](int mt, int row, int slot, uint32_t h) {
-        const int j = slot / 16, within = slot % 16, lane = row + 32 * (within / 8), w = (within % 8) / 2;
-        uint32_t& d = T[(size_t)((mt * 2 + j) * 64 + lane) * 4 + w];
-        d = (slot & 1) ? ((d & 0x0000ffffu) | (h << 16)) : ((d & 0xffff0000u) | h);
-    };
-    // padding rows: a9_hi = -inf (slot 29, whose B value is 1), everything else 0: the sum is -inf, sign set, never a candidate
-    for (int mt = 0; mt < 2; ++mt)
-        for (int row = 0; row < 32; ++row) put(mt, row, 29, 0xfc00u);
+    matrixPadRows(T.data());
     for (int p = 0; p < n; ++p) {
-        int mt, row;
-        matrixSlot(p, R1, mt, row);
         float a[TPT_MX_K];
         matrixSphereSide(S[p].cx, S[p].cy, S[p].cz, S[p].radius * S[p].radius, a); // r^2 as the exact test sees it (Test.cpp:329)
-        uint32_t hi[10], lo[10];
-        for (int k = 0; k < 10; ++k) {
-            if (!(fabsf(a[k]) < 60000.0f)) return; // (also NaN) binary16 cannot carry this sphere
-            hi[k] = f16rtz(a[k]);
-            lo[k] = f16rtz(a[k] - f16val(hi[k]));
-        }
-        const uint32_t one = 0x3c00u;
-        for (int t = 0; t < TPT_MXH_TERMS; ++t) {
-            put(mt, row, 2 * t, hi[t]);
-            put(mt, row, 2 * t + 1, hi[t]);
-        }
-        for (int u = 0; u < 4; ++u) {
-            put(mt, row, 18 + 2 * u, lo[2 * u]);
-            put(mt, row, 19 + 2 * u, lo[2 * u + 1]);
-        }
-        put(mt, row, 26, lo[8]);
-        put(mt, row, 27, one);
-        put(mt, row, 28, one);
-        put(mt, row, 29, hi[9]);
-        put(mt, row, 30, lo[9]);
-        put(mt, row, 31, 0u);
+        if (!matrixPutEntry(T.data(), p, R1, a)) return; // binary16 cannot carry this sphere
     }
     P.amatH.swap(T);
     P.mxR1 = R1;
+}
+
+// The same filter over the BOUNDING SPHERES of a grouped scene (hitSpheresGroupedDeal): one 4-KB tile pair per 64 groups, full
+// tiles (R1 = 16: group q of a tile at mask bit 63 - q, the order phase1Chunk delivers).  A group bound has to pass whenever the
+// reference accepts one of its members, which costs slack on top of the filter's own error (tpt_trace.h, comment at
+// TPT_PG_K): the member's line distance exceeds the bound by up to 26 u (S + R^2)(1 + rho), rho = max |c - C| / r over the
+// members, S = |C - o|^2 <= 2 (|C|^2 + |o|^2); with the matrix form's own 490 u (|C|^2 + |o|^2) + 114 u R^2 (phase1MatrixH) that is
+//   [52 (1 + rho) + 490] u (|C|^2 + |o|^2) + [26 (1 + rho) + 114] u R^2  <=  2206 u (...) + 972 u R^2   for rho <= 32,
+// against the doubled slack m = 4096 u (|C|^2 + |o|^2) + 2048 u R^2 + 16 u of this table (slackShift 1 on both sides): a factor
+// 1.85 to spare.  Scenes with a looser group (rho > 32), a bound binary16 cannot carry or more than 65536 groups get no table
+// and the packed VALU filter.
+inline void buildGroupMatrixTable(PackedScene& P, const std::vector<float>& C3, const std::vector<double>& R, double rhoMax)
+{
+    P.gmatH.clear();
+    P.gmxTiles = 0;
+    const int nGroups = (int)R.size();
+    if (nGroups < 1 || nGroups > 65536 || !(rhoMax <= 32.0)) return;
+    const int tiles = (nGroups + 63) / 64;
+    std::vector<uint32_t> T((size_t)tiles * TPT_MXH_TABLE_DWORDS, 0u);
+    for (int t = 0; t < tiles; ++t) matrixPadRows(T.data() + (size_t)t * TPT_MXH_TABLE_DWORDS);
+    for (int g = 0; g < nGroups; ++g) {
+        float a[TPT_MX_K];
+        const float r2 = (float)(R[g] * R[g] * (1.0 + 1.0e-6)); // (rounded up: the bound must not shrink)
+        matrixSphereSide(C3[(size_t)g * 3], C3[(size_t)g * 3 + 1], C3[(size_t)g * 3 + 2], r2, a, 1);
+        if (!matrixPutEntry(T.data() + (size_t)(g / 64) * TPT_MXH_TABLE_DWORDS, g % 64, 16, a)) return;
+    }
+    P.gmatH.swap(T);
+    P.gmxTiles = tiles;
 }
 
 // Large scenes: compact groups of <= TPT_GROUP small spheres (median splits) with bounding spheres, big spheres kept apart.
@@ -199,8 +241,8 @@ inline void buildMatrixTable(const std::vector<SpherePOD>& S, PackedScene& P)
 // (tpt_trace.h, hitSpheresGrouped).
 inline void buildGroups(const std::vector<SpherePOD>& S, PackedScene& P)
 {
-    P.gpairs.clear(); P.gsph.clear(); P.gid.clear(); P.bsph.clear(); P.bid.clear();
-    P.nGroups = P.nGroupPairs = P.nBig = 0;
+    P.gpairs.clear(); P.gsph.clear(); P.gid.clear(); P.bsph.clear(); P.bid.clear(); P.gmatH.clear();
+    P.nGroups = P.nGroupPairs = P.nBig = 0; P.gmxTiles = 0;
     const int n = (int)S.size();
     if (n < TPT_GROUP_MIN_SPHERES) return;
     std::vector<float> radii(n);
@@ -249,6 +291,7 @@ inline void buildGroups(const std::vector<SpherePOD>& S, PackedScene& P)
     const float negInf = u2f(0xff800000u), posInf = u2f(0x7f800000u);
     struct GroupRec { float C[3]; double R; std::vector<int> mem; };
     std::vector<GroupRec> groups;
+    double rhoMax = 0;
     for (size_t l = 0; l < leaves.size(); ++l) {
         GroupRec G;
         for (int k = leaves[l].first; k < leaves[l].second; ++k) G.mem.push_back(order[k]);
@@ -268,6 +311,7 @@ inline void buildGroups(const std::vector<SpherePOD>& S, PackedScene& P)
             continue;
         }
         G.R = R * 1.00001;
+        rhoMax = std::max(rhoMax, rho);
         groups.push_back(G);
     }
     if ((int)big.size() > 64 || groups.empty()) return;
@@ -303,6 +347,15 @@ inline void buildGroups(const std::vector<SpherePOD>& S, PackedScene& P)
         P.bid.push_back(i);
     }
     P.nGroups = nGroups; P.nGroupPairs = nGroupPairs; P.nBig = (int)big.size();
+    {
+        std::vector<float> C3((size_t)nGroups * 3);
+        std::vector<double> Rg((size_t)nGroups);
+        for (int g = 0; g < nGroups; ++g) {
+            for (int a = 0; a < 3; ++a) C3[(size_t)g * 3 + a] = groups[g].C[a];
+            Rg[g] = groups[g].R;
+        }
+        buildGroupMatrixTable(P, C3, Rg, rhoMax);
+    }
 }
 
 // UpdateTest's scene half (Test.cpp:321-339): derived data, SoA, emissive list -- in kernel layout.
@@ -384,6 +437,8 @@ inline SceneView viewOf(const PackedScene& P)
     sv.nBig = P.nBig;
     sv.amatH = P.amatH.empty() ? nullptr : P.amatH.data();
     sv.mxR1 = P.mxR1;
+    sv.gmatH = P.gmatH.empty() ? nullptr : P.gmatH.data();
+    sv.gmxTiles = P.gmxTiles;
     sv.flags = P.flags;
     return sv;
 }

@@ -78,6 +78,10 @@ struct SceneView {
     // second sphere tile that hold spheres (0, 4, ..., 16); mxR1 < 0: no table.
     const uint32_t* amatH;
     int mxR1;
+    // the same for the bounding spheres of a grouped scene: gmatH = [gmxTiles][2][2][64][4] dwords, one tile pair per 64 groups
+    // (buildGroupMatrixTable); gmxTiles == 0: no table, the packed VALU filter runs over gpairs
+    const uint32_t* gmatH;
+    int gmxTiles;
     int flags; // SCENE_* bits (packScene)
 };
 enum { SCENE_LIGHT_R2_DIV_SAFE = 1 }; // every light's radius^2 lies in [2^-60, 2^60]: Scatter's r^2 / d^2 may take tdivSafeNum (tpt_math.h)
@@ -350,7 +354,7 @@ TPT_HD int hitSpheresTwoPhase(const SceneView& sv, f3 o, f3 d, float tMin, float
 #define TPT_MXH_TERMS 9 /* product terms a_t b_t, t = 0..8; b_9 = 1 and a_10 = 1 are the two special terms */
 #define TPT_MXH_SLOTS 32
 #define TPT_MXH_TABLE_DWORDS (2 * 2 * 64 * 4) /* [sphere tile][k step][lane][4]: the A operands as the lanes read them */
-TPT_HD void matrixRaySide(f3 o, f3 d, float* b)
+TPT_HD void matrixRaySide(f3 o, f3 d, float* b, int slackShift = 0) // slackShift 1: the group-bound table's doubled slack (2^-12 |o|^2)
 {
     b[0] = d.x * d.x; b[1] = d.y * d.y; b[2] = d.z * d.z;
     b[3] = d.x * d.y; b[4] = d.x * d.z; b[5] = d.y * d.z;
@@ -358,7 +362,7 @@ TPT_HD void matrixRaySide(f3 o, f3 d, float* b)
     b[6] = fma1(-od, d.x, o.x); b[7] = fma1(-od, d.y, o.y); b[8] = fma1(-od, d.z, o.z);
     const float oo = fma1(o.z, o.z, fma1(o.y, o.y, o.x * o.x));
     b[9] = 1.0f;
-    b[10] = fma1(od, od, -(oo * 0.9998779296875f)); // 1 - 2^-13
+    b[10] = fma1(od, od, -(oo * (slackShift ? 0.999755859375f : 0.9998779296875f))); // 1 - 2^-13 (groups: 1 - 2^-12)
 }
 // rays the binary16 operands can carry: |o|^2 < 60000 (so |e|, |q| fit) and a finite direction of about unit length
 TPT_HD bool matrixRayInRange(f3 o, const float* b)
@@ -427,10 +431,10 @@ TPT_HD float matrixTableSlot(const uint32_t* amatH, int mt, int row, int slot)
 // after the other (the MFMA's own order and internal width are the hardware's: within the bound above of each other, so the
 // two masks may differ where the sum is within ~100 u T of zero -- both are conservative).  outSum / outAbs (optional, per
 // sphere): the exact slot sum and sum of magnitudes in binary64, for the tests of the error model.
-TPT_HD uint64_t phase1MatrixHRef(const uint32_t* amatH, int R1, int nSpheres, f3 o, f3 d, double* outSum = nullptr, double* outAbs = nullptr)
+TPT_HD uint64_t phase1MatrixHRef(const uint32_t* amatH, int R1, int nSpheres, f3 o, f3 d, double* outSum = nullptr, double* outAbs = nullptr, int slackShift = 0)
 {
     float b[TPT_MX_K], slot[TPT_MXH_SLOTS];
-    matrixRaySide(o, d, b);
+    matrixRaySide(o, d, b, slackShift);
     matrixRaySlots(b, slot);
     const bool ok = matrixRayInRange(o, b);
     uint64_t cand = 0;
@@ -451,8 +455,16 @@ TPT_HD uint64_t phase1MatrixHRef(const uint32_t* amatH, int R1, int nSpheres, f3
     }
     return cand;
 }
+// The ray side of the filter as MFMA B operands: what the lane's ray contributes to ray tile 0 / 1 of the two k steps.
+struct MatrixRayOps {
+    uint32_t B0[2][4], B1[2][4];
+    bool ok; // the ray is in binary16 range (else: every sphere stays a candidate)
+};
 #if defined(__HIPCC__) && !defined(__HIP_DEVICE_COMPILE__)
-__device__ uint64_t phase1MatrixH(const uint32_t* ldsA, int R1, int nSpheres, f3 o, f3 d); // (host pass of a .hip file: declaration only)
+// (host pass of a .hip file: declarations only)
+__device__ uint64_t phase1MatrixH(const uint32_t* ldsA, int R1, int nSpheres, f3 o, f3 d);
+__device__ void matrixRayOperands(f3 o, f3 d, int slackShift, MatrixRayOps& R);
+__device__ uint64_t matrixApply(const uint4* A, int R1, int nEntries, const MatrixRayOps& R);
 #endif
 #if defined(__HIP_DEVICE_COMPILE__)
 typedef float v16f __attribute__((ext_vector_type(16)));
@@ -465,14 +477,11 @@ __device__ __forceinline__ uint32_t pkh(float a, float b) // {binary16(a), binar
     __builtin_memcpy(&u, &h, 4);
     return u;
 }
-// Candidate mask (sphere p at bit 63 - p) of the ray in this lane.  Must be called by ALL 64 lanes of the wave (lanes
-// without a ray ignore the result; a lane's operands reach its own column only, so whatever it feeds cannot disturb another
-// ray).  ldsA: the scene's A-operand table in LDS, [sphere tile][k step][lane] uint4.
-__device__ __forceinline__ uint64_t phase1MatrixH(const uint32_t* ldsA, int R1, int nSpheres, f3 o, f3 d)
+__device__ __forceinline__ void matrixRayOperands(f3 o, f3 d, int slackShift, MatrixRayOps& R)
 {
     float b[TPT_MX_K];
-    matrixRaySide(o, d, b);
-    const bool ok = matrixRayInRange(o, b);
+    matrixRaySide(o, d, b, slackShift);
+    R.ok = matrixRayInRange(o, b);
     uint32_t V[16];
     float hi[TPT_MXH_TERMS];
 #pragma unroll
@@ -488,17 +497,22 @@ __device__ __forceinline__ uint64_t phase1MatrixH(const uint32_t* ldsA, int R1, 
     V[15] = 0x00003c00u; // {1, 0}
     // B operands: MFMA j of ray tile 0 / 1 reads slots 16 j .. 16 j + 7 from lanes 0..31 and 16 j + 8 .. 16 j + 15 from lanes
     // 32..63 -- of the SAME ray: one half-swap per register pair hands every lane's upper slots to its partner lane
-    uint32_t B0[2][4], B1[2][4];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             auto sw = __builtin_amdgcn_permlane32_swap(V[8 * j + r], V[8 * j + 4 + r], false, false);
-            B0[j][r] = sw[0];
-            B1[j][r] = sw[1];
+            R.B0[j][r] = sw[0];
+            R.B1[j][r] = sw[1];
         }
+}
+// Candidate mask (entry p at bit 63 - p) of the ray in this lane against ONE table of up to 64 entries (spheres, or the
+// bounding spheres of 64 groups).  Must be called by ALL 64 lanes of the wave (lanes without a ray ignore the result; a lane's
+// operands reach its own column only, so whatever it feeds cannot disturb another ray).  A: the table's A operands,
+// [sphere tile][k step][lane] uint4, in LDS or global memory.
+__device__ __forceinline__ uint64_t matrixApply(const uint4* A, int R1, int nEntries, const MatrixRayOps& R)
+{
     const int lane = (int)(threadIdx.x & 63u);
-    const uint4* A = reinterpret_cast<const uint4*>(ldsA);
     uint32_t W0 = 0, W1 = 0; // sign bits of this lane's accumulator rows, ray tile 0 / 1
     auto asH = [](const uint32_t* p) {
         v8h h;
@@ -511,8 +525,8 @@ __device__ __forceinline__ uint64_t phase1MatrixH(const uint32_t* ldsA, int R1, 
         for (int j = 0; j < 2; ++j) {
             const uint4 a4 = A[j * 64 + lane];
             const uint32_t aw[4] = {a4.x, a4.y, a4.z, a4.w};
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(asH(aw), asH(B0[j]), c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(asH(aw), asH(B1[j]), c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(asH(aw), asH(R.B0[j]), c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(asH(aw), asH(R.B1[j]), c1, 0, 0, 0);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -526,8 +540,8 @@ __device__ __forceinline__ uint64_t phase1MatrixH(const uint32_t* ldsA, int R1, 
         for (int j = 0; j < 2; ++j) {
             const uint4 a4 = A[(2 + j) * 64 + lane];
             const uint32_t aw[4] = {a4.x, a4.y, a4.z, a4.w};
-            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(asH(aw), asH(B0[j]), c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(asH(aw), asH(B1[j]), c1, 0, 0, 0);
+            c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(asH(aw), asH(R.B0[j]), c0, 0, 0, 0);
+            c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(asH(aw), asH(R.B1[j]), c1, 0, 0, 0);
         }
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
@@ -544,10 +558,16 @@ __device__ __forceinline__ uint64_t phase1MatrixH(const uint32_t* ldsA, int R1, 
     // rays 32..63 likewise in tile 1: one swap gives every lane both row groups of its own ray
     auto sw = __builtin_amdgcn_permlane32_swap(W0, W1, false, false);
     const uint32_t G0 = sw[0], G1 = sw[1];
-    const int n = 16 + R1; // spheres per row group
+    const int n = 16 + R1; // entries per row group
     const uint64_t rejected = ((uint64_t)G0 << (64 - n)) | ((uint64_t)G1 << (64 - 2 * n));
-    const uint64_t valid = ~0ull << (64 - nSpheres); // (padding rows end at -inf, but a NaN ray must not keep them either)
-    return ok ? (~rejected & valid) : valid;
+    const uint64_t valid = ~0ull << (64 - nEntries); // (padding rows end at -inf, but a NaN ray must not keep them either)
+    return R.ok ? (~rejected & valid) : valid;
+}
+__device__ __forceinline__ uint64_t phase1MatrixH(const uint32_t* ldsA, int R1, int nSpheres, f3 o, f3 d)
+{
+    MatrixRayOps R;
+    matrixRayOperands(o, d, 0, R);
+    return matrixApply(reinterpret_cast<const uint4*>(ldsA), R1, nSpheres, R);
 }
 #endif
 // phase 2 over a candidate mask (sphere p at bit 63 - p): the reference's arithmetic, ascending index
@@ -1043,31 +1063,18 @@ TPT_HD bool laneStep(Lane& L, const SceneView& sv, const FrameConsts& fc, const 
 // merging is left -- each function reads what its class needs and returns the bounce.  (lanePost stays the code of the
 // lane-refill fallback kernel; tests/lane_emu.cpp runs both against the oracle.)
 // Bounce stack of a path in the queue kernel: level 0 in the path record (LDS), levels 1..9 in global memory.
+// (on the device level 0 is addressed as LDS explicitly: a store through a pointer that is LDS for level 0 and global memory
+//  otherwise compiles to FLAT instructions, which take the vector-memory path even when they land in LDS)
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef f4 __attribute__((address_space(3))) * LdsF4Ptr;
+#else
+typedef f4* LdsF4Ptr;
+#endif
 struct QStack {
-    f4* l0;
+    LdsF4Ptr l0;
     f4* spill;  // level k >= 1 at spill[(k - 1) * stride]
     int stride;
 };
-// (-DTPT_STACK_NT=1, experiment: the spilled levels are written once and read once, much later -- non-temporal accesses keep
-//  them from displacing the half-written colour lines in the L2s)
-#if defined(__HIP_DEVICE_COMPILE__) && defined(TPT_STACK_NT) && TPT_STACK_NT
-typedef float tptV4 __attribute__((ext_vector_type(4)));
-TPT_HD void spillStore(f4* p, f4 v)
-{
-    tptV4 x = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(x, reinterpret_cast<tptV4*>(p));
-}
-TPT_HD f4 spillLoad(const f4* p)
-{
-    const tptV4 x = __builtin_nontemporal_load(reinterpret_cast<const tptV4*>(p));
-    f4 v;
-    v.x = x[0]; v.y = x[1]; v.z = x[2]; v.w = x[3];
-    return v;
-}
-#else
-TPT_HD void spillStore(f4* p, f4 v) { *p = v; }
-TPT_HD f4 spillLoad(const f4* p) { return *p; }
-#endif
 TPT_HD void qStackPush(const QStack& s, int level, f3 e, int attId)
 {
     f4 v;
@@ -1075,7 +1082,7 @@ TPT_HD void qStackPush(const QStack& s, int level, f3 e, int attId)
     if (level == 0)
         *s.l0 = v;
     else
-        spillStore(&s.spill[(level - 1) * s.stride], v);
+        s.spill[(level - 1) * s.stride] = v;
 }
 // hit normal, Maths.cpp:196-197
 TPT_HD f3 qNormal(const SceneView& sv, int id, f3 pos)
@@ -1115,7 +1122,7 @@ TPT_HD f3 qFold(const SceneView& sv, f3 term, int depth, const QStack& s)
         for (int k = 0; k < 5; ++k) {
             ent[k].x = ent[k].y = ent[k].z = ent[k].w = 0.0f;
             const int lvl = g5 * 5 + k;
-            if (lvl < depth) ent[k] = lvl == 0 ? *s.l0 : spillLoad(&s.spill[(lvl - 1) * s.stride]);
+            if (lvl < depth) ent[k] = lvl == 0 ? *s.l0 : s.spill[(lvl - 1) * s.stride];
         }
 #pragma unroll
         for (int k = 4; k >= 0; --k) {

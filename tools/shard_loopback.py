@@ -8,7 +8,7 @@ import torch
 from toypathtracer_amd import api
 
 api.InitializeTest()
-api.set_stream_batching(os.environ.get("TPT_STREAM_BATCH", "0") == "1")  # several frames per launch behind a frame-by-frame caller's back (opt-in)
+api.set_stream_batching(os.environ.get("TPT_STREAM_BATCH", "1") == "1")  # several frames per launch behind a frame-by-frame caller's back (the library's default; TPT_STREAM_BATCH=0: off)
 w, h = [int(v) for v in os.environ.get("TPT_EMU_SIZE", "1280x720").split("x")]
 frames, warm = int(os.environ.get("TPT_EMU_FRAMES", "300")), 40
 batch = int(os.environ.get("TPT_EMU_BATCH", "1"))  # frames per launch and per exchange (tptDrawShardedBatch)

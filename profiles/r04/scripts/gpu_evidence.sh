@@ -12,8 +12,8 @@ echo "== steady state"; timeout 200 python bench.py --no-cpu-baseline --no-extra
 for n in 30 100; do echo "== steps $n"; timeout 200 python bench.py --no-cpu-baseline --no-extras --steps $n --warmup 5 2>/dev/null | tail -1 | tee $E/bench_c2_steps$n.json | summ; done
 echo "== c3 (steady)"; timeout 200 python bench.py --no-cpu-baseline --no-extras --parity-frames 0 --workload c3 --steps 40 --warmup 20 2>/dev/null | tail -1 | tee $E/bench_c3.json | summ
 echo "== c3, one frame, parity leg"; timeout 300 python bench.py --no-cpu-baseline --no-extras --workload c3 --prime 0 --warmup 0 --steps 1 2>/dev/null | tail -1 | tee $E/bench_c3_one_frame_parity.json | summ
-echo "== c3 through the C-ABI exchange at N = 1 (real one-rank RCCL communicator), one frame, parity leg"; timeout 300 python bench.py --no-cpu-baseline --no-extras --workload c3 --exchange cabi --prime 0 --warmup 0 --steps 1 2>/dev/null | tail -1 | tee $E/bench_c3_cabi_one_frame_parity.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['exchange'], d['rccl_ranks'], d.get('parity_ok'), d.get('image_fnv'))"
-echo "== c5 through the C-ABI exchange at N = 1"; timeout 300 python bench.py --no-cpu-baseline --no-extras --workload c5 --exchange cabi --steps 20 --warmup 10 2>/dev/null | tail -1 | tee $E/bench_c5_cabi.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['exchange'], d['rccl_ranks'], d.get('image_fnv'))"
+echo "== c3 through the C-ABI exchange at N = 1 (real one-rank RCCL communicator), one frame, parity leg"; timeout 300 python bench.py --no-cpu-baseline --no-extras --workload c3 --exchange cabi --prime 0 --warmup 0 --steps 1 2>/dev/null | grep '^{"metric"' | tail -1 | tee $E/bench_c3_cabi_one_frame_parity.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['exchange'], d['rccl_ranks'], d.get('parity_ok'), d.get('image_fnv'))"
+echo "== c5 through the C-ABI exchange at N = 1"; timeout 300 python bench.py --no-cpu-baseline --no-extras --workload c5 --exchange cabi --steps 20 --warmup 10 --parity-frames 0 2>/dev/null | grep '^{"metric"' | tail -1 | tee $E/bench_c5_cabi.json | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['exchange'], d['rccl_ranks'], d.get('image_fnv'))"
 echo "== c5"; timeout 200 python bench.py --no-cpu-baseline --no-extras --parity-frames 0 --workload c5 --steps 40 --warmup 20 2>/dev/null | tail -1 | tee $E/bench_c5.json | summ
 echo "== c1"; timeout 200 python bench.py --no-cpu-baseline --no-extras --workload c1 --steps 200 --warmup 20 --parity-frames 0 2>/dev/null | tail -1 | tee $E/bench_c1.json | summ
 echo "== c2 packed VALU filter (--hit-spheres 3)"; timeout 200 python bench.py --no-cpu-baseline --no-extras --hit-spheres 3 --parity-frames 0 2>/dev/null | tail -1 | tee $E/bench_c2_valu_filter.json | summ

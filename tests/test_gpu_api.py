@@ -179,7 +179,7 @@ def test_drawtest_lookahead_changes_nothing(tpt_defaults, oracle, lookahead):
 def test_drawtest_in_the_reference_seed_mode_is_served_from_batched_lookahead(tpt_defaults, oracle):
     """tptSetSeedMode(0) + plain synchronous DrawTest calls -- the literal drop-in with the reference's own pixels: from the third
     consecutive frame of one configuration on the library traces that frame and the 31 after it as ONE launch (rows x frames
-    lanes, a ray counter per frame), and the batch after that once the first has been hit.  Every frame's bytes and ray count
+    lanes, a ray counter per frame), and the batch after that right behind it.  Every frame's bytes and ray count
     equal the oracle's ROW_SERIAL render, across the batch boundary (frames 33 -> 34), after a jump in frameCount, a restart
     at 0 and a different size in between."""
     from common import oracle_frames

@@ -1686,9 +1686,8 @@ int tptDraw(float time, int frameCount, int w, int h, float* backbuffer, int* ou
         // ---- 1r. the reference's own seed mode: a frame alone is `rows` lanes of work, so the frames AHEAD are traced as one
         //          launch (rows x frames lanes) and served one by one.  A batch is 32 frames of GPU work for one delivered
         //          frame, so it is only launched for a caller that has shown its pattern -- the third consecutive frame of one
-        //          configuration (a one-shot DrawTest, or a host that jumps about, takes the plain path below) -- and the batch
-        //          after it only once the first one has been hit.  A batch the pipeline refuses (frame wider than 8192, over 4 GiB
-        //          of colour planes, not enough device memory) is retried at half the size, down to 2 frames; if nothing fits
+        //          configuration (a one-shot DrawTest, or a host that jumps about, takes the plain path below).  A batch the pipeline
+        //          refuses (frame wider than 8192, over 4 GiB of colour planes, not enough device memory) is retried at half the size, down to 2 frames; if nothing fits
         //          the configuration is served frame by frame: DrawTest never fails because of the look-ahead.
         auto matches = [&](const Context::RowSerialBatch& B) {
             return B.used && B.w == w && B.h == h && B.flags == testFlags && B.key == key && frameCount == B.firstFrame + B.next;
@@ -1725,7 +1724,10 @@ int tptDraw(float time, int frameCount, int w, int h, float* backbuffer, int* ou
         }
         Context::RowSerialBatch& B = g.rsb[0];
         if (B.used) {
-            if (B.next >= 1 && !g.rsb[1].used && !(HC.refusedKey == key && HC.refusedW == w && HC.refusedH == h)) {
+            // (the batch after this one is launched at once: holding it back until the first hit -- the batch above only completes
+            //  when its slowest row has, 60-90 ms -- serialises the batches and costs the sequential caller 2.7x: 1.6 instead of
+            //  4.3 Gray/s, profiles/r04/r04_evidence.log; the caller has shown three consecutive frames by now)
+            if (!g.rsb[1].used && !(HC.refusedKey == key && HC.refusedW == w && HC.refusedH == h)) {
                 int rc = launch(1, B.firstFrame + B.n);
                 if (rc) return rc;
             }

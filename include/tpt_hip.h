@@ -225,7 +225,7 @@ TPT_API int tptKernelTimingEnd(float* outSumMilliseconds, int* outLaunches);
 
 /* hitSpheres: 0 = two-phase (default: a conservative filter + the reference's exact test for what passes.  The filter runs
  * on the matrix cores for scenes of <= 64 spheres that binary16 operands can carry, as packed FP32 on the VALU otherwise;
- * scenes of 256 spheres or more are traversed through compact groups of <= 16 spheres with bounding spheres -- same hits,
+ * scenes of 256 spheres or more are traversed through compact groups of <= 8 spheres with bounding spheres -- same hits,
  * same tie-break, ~4x faster on the 4096-sphere scene), 1 = simple loop (exact test for every sphere), 2 = two-phase
  * without grouping (brute force over all spheres, the reference's cost model), 3 = two-phase with the packed VALU filter
  * everywhere (no matrix-core table).  persistent: 3 = path queues in LDS (default; per-pixel seeds, recursive fold, two-phase

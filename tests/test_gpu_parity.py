@@ -137,7 +137,7 @@ def test_custom_scene_camera_stress(tpt_defaults, oracle):
     cam = oracle.camera(STRESS_CAMERA["look_from"], STRESS_CAMERA["look_at"], (0, 1, 0), STRESS_CAMERA["vfov"], w / h,
                         STRESS_CAMERA["aperture"], STRESS_CAMERA["focus_dist"])
     ro, bo, pero = oracle_frames(oracle, w, h, spp, 2, spheres=s, mats=m, cam=cam, seed_mode=SEED_PER_PIXEL)
-    assert per == pero and bb.tobytes() == bo.tobytes()   # default: grouped traversal (compact groups of <= 16 spheres)
+    assert per == pero and bb.tobytes() == bo.tobytes()   # default: grouped traversal (compact groups of <= 8 spheres)
     for hs, persist in ((2, 3), (2, 1), (0, 1), (1, 3)):  # flat two-phase, lane-refill kernel, all-exact loop
         tpt.set_kernel_variant(hs, persist, -1)
         rays2, bb2, per2 = gpu_frames(tpt, w, h, 2)

@@ -121,7 +121,7 @@ def test_two_phase_filter_is_conservative_on_grazing_rays(emu, oracle):
 
 @pytest.mark.parametrize("n", [256, 1000, 4096, 20000])
 def test_grouped_hit_world_equals_brute_force(emu, oracle, n):
-    """Large scenes are traversed through compact groups of <= 16 spheres with bounding spheres: a
+    """Large scenes are traversed through compact groups of <= 8 spheres with bounding spheres: a
     small render of the stress scene must equal the oracle's brute force bit for bit, for the grouped path (hs 0), the
     all-exact loop (hs 1) and the flat two-phase loop (hs 2)."""
     from toypathtracer_amd.scenes import STRESS_CAMERA, stress_scene
@@ -135,7 +135,7 @@ def test_grouped_hit_world_equals_brute_force(emu, oracle, n):
     emu.emu_group_info.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     emu.emu_group_info.restype = None
     emu.emu_group_info(s.ctypes.data, m.ctypes.data, n, info.ctypes.data)
-    assert info[0] >= (n - info[2] + 15) // 16 and 1 <= info[2] <= 64  # grouped: ground + lights big, the rest in <= 16s
+    assert info[0] >= (n - info[2] + 7) // 8 and 1 <= info[2] <= 64  # grouped: ground + lights big, the rest in <= 8s
     for hs in (0, 1, 2):
         re, be = emu_frames(emu, s, m, cam, w, h, spp, 1, FLAG_PROGRESSIVE, 1, hs, 0)
         assert re == ro and be.tobytes() == bo.tobytes(), hs

@@ -549,7 +549,7 @@ __device__ __forceinline__ int qPop(LdsRing q, unsigned* head, unsigned* tail, i
 //   * a lane whose ray touches k groups reserves k entries of the wave's pair list with one LDS atomic and writes
 //     (its path id << 16 | group) pairs; its ray {o, d} and its best hit so far -- the 64-bit key (t bits << 32 | sphere id) --
 //     are parked in planes 0 / 1 of its own path record, which are dead while this wave holds the path;
-//   * lane j takes entry j (rounds of 64): reads the ray, filters the 16 members, runs the exact test on what passes and merges
+//   * lane j takes entry j (rounds of 64): reads the ray, filters the group's members, runs the exact test on what passes and merges
 //     its best hit into the owner's key with ds_min_u64: smaller t wins, equal t: the lower ORIGINAL sphere index -- the
 //     reference's first-strictly-less rule made explicit (t > tMin > 0: the bit patterns order like the values);
 //   * pairs that do not fit the list (TPT_GROUP_DEAL_CAP per round) stay in their lane's mask for the next round.
@@ -559,8 +559,18 @@ __device__ __forceinline__ int hitSpheresGroupedDeal(const SceneView& sv, bool g
 {
     float hitT = TPT_MAX_T;
     int id = -1;
-    if (go)
-        for (int b = 0; b < sv.nBig; ++b) testSphereTie(sv.bsph[b], sv.bid[b], o, d, TPT_MIN_T, hitT, id);
+    if (go) {
+        // the big spheres (ground, lights, dissolved groups: at most 64): the per-sphere conservative filter first (memberFilter = phase 1's
+        // arithmetic, 12 instructions), the exact test (45) only for what passes -- every ray used to run all of them exactly
+        const f3 dk1 = mk3(d.x * TPT_P1_K, d.y * TPT_P1_K, d.z * TPT_P1_K);
+        uint64_t bm = 0ull;
+        for (int b = 0; b < sv.nBig; ++b) bm |= (uint64_t)(memberFilter(sv.bsph[b], o, dk1) ? 1u : 0u) << b;
+        while (bm) {
+            const int b = __builtin_ctzll(bm);
+            bm &= bm - 1ull;
+            testSphereTie(sv.bsph[b], sv.bid[b], o, d, TPT_MIN_T, hitT, id);
+        }
+    }
     const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
     const float gx = d.x * TPT_PG_K, gy = d.y * TPT_PG_K, gz = d.z * TPT_PG_K;
     const v2f dx = {gx, gx}, dy = {gy, gy}, dz = {gz, gz};

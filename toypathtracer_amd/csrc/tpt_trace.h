@@ -86,7 +86,8 @@ struct SceneView {
 };
 enum { SCENE_LIGHT_R2_DIV_SAFE = 1 }; // every light's radius^2 lies in [2^-60, 2^60]: Scatter's r^2 / d^2 may take tdivSafeNum (tpt_math.h)
 #ifndef TPT_GROUP
-#define TPT_GROUP 16 /* members per group, <= 32 */
+#define TPT_GROUP 8 /* members per group, <= 32.  8 since round 4: with the bounds on the matrix cores small groups are cheap to reject and cheaper
+                       to visit -- 4096-sphere scene: 7.9 / 7.7 / 7.8 / 7.8 / 7.05 / 3.6 Gray/s at 4 / 6 / 8 / 12 / 16 / 32 (profiles/r04/r04_run15-16.log) */
 #endif
 #define TPT_GROUP_MIN_SPHERES 256
 

@@ -504,7 +504,10 @@ def main():
         if scene == "default" and not args.animate and args.parity_frames > 0:
             out.update(image_parity(image, rays_all_frames, width, height, spp, total_frames, args.parity_frames, args.parity_samples))
         else:
-            out.update(parity_checked=False, parity_note="oracle leg runs for the static default scene only (this workload's parity: tests/test_gpu_parity.py)")
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            from oracle_lib import fnv1a
+            out.update(image_fnv="%08x" % fnv1a(np.ascontiguousarray(image.detach().cpu().numpy(), np.float32)), parity_checked=False,
+                       parity_note="oracle leg runs for the static default scene only (this workload's parity: tests/test_gpu_parity.py); image_fnv lets two runs of the same frames be compared")
         extras = set() if args.no_extras else set(x for x in args.extras.split(",") if x)
         if world == 1 and exchange != "cabi" and extras:
             # the same workload through the reference's own contract (host backbuffer, synchronous) and in its own seed mode

@@ -409,6 +409,9 @@ __device__ __forceinline__ f4 mk4(float x, float y, float z, float w)
 #ifndef TPT_GROUP_DEAL_EXACT
 #define TPT_GROUP_DEAL_EXACT 1 // the members that pass the member filter are dealt out again for their exact tests (see hitSpheresGroupedDeal)
 #endif
+#ifndef TPT_MEMBER_UNROLL
+#define TPT_MEMBER_UNROLL 4 // member records requested together in the member filter of a (ray, group) pair
+#endif
 #define TPT_GROUP_DEAL_CAP 192 /* pair-list entries per wave and round (a multiple of 64) */
 #define TPT_GROUP_DEAL_WAVE_BYTES (TPT_GROUP_DEAL_CAP * 4 + 16)
 #define TPT_Q_SPH_FIXED 1024 /* bytes at LDS offset 0 for {centre, r^2} of scenes of <= 64 spheres: DS offsets fold into the instructions */
@@ -640,7 +643,7 @@ __device__ __forceinline__ int hitSpheresGroupedDeal(const SceneView& sv, bool g
                     rd = mk3(r1.y, r1.z, r1.w);
                     const f3 dk = mk3(rd.x * TPT_P1_K, rd.y * TPT_P1_K, rd.z * TPT_P1_K);
                     TPT_STAT(ST_SPHERELOOP); // profiling build: group visits
-#pragma unroll 4
+#pragma unroll TPT_MEMBER_UNROLL
                     for (int j = 0; j < TPT_GROUP; ++j) mm |= (memberFilter(mem[j], ro, dk) ? 1u : 0u) << j;
                 }
 #if TPT_GROUP_DEAL_EXACT

@@ -515,7 +515,10 @@ int probeHardwareQueues()
 // kernels of the ordered chain behind them (blend, snapshot, assemble, display) then wait for a workgroup slot to come free --
 // 6 us of work took 52-137 us (profiles/r03).  With TPT_RESERVE_CUS = n > 0 the trace streams are created with a CU mask
 // (hipExtStreamCreateWithCUMask) that leaves n CUs -- spread evenly over the XCDs: bit i of the mask is CU i / 8 of XCD i % 8,
-// tools/probes/cumask_probe.hip -- to everything else; grids are sized for the CUs that remain.
+// tools/probes/cumask_probe.hip -- to everything else; grids are sized for the CUs that remain.  (Measured in round 4: it does not
+// shorten the blend chain and costs 5-9 % of the trace rate; off by default.  Streams created this way are BLOCKING
+// streams -- the only kind hipExtStreamCreateWithCUMask makes -- so with the knob on, default-stream work of the host also orders
+// against the trace kernels.)
 int createTraceStreams()
 {
     int reserve = 0;

@@ -153,7 +153,9 @@ TPT_HD float tdivByPi(float a)
 #if defined(__HIP_DEVICE_COMPILE__)
     float q = tdivByPiFast(a);
     // +0 and [2^-100, 2^126) take the fast form; negative, tiny, huge and non-finite arguments the IEEE expansion
-    if (__builtin_expect(f2u(a) - 1u >= 0x7e800000u - 1u || (f2u(a) != 0u && f2u(a) < 0x0d800000u), 0)) q = a / TPT_PI;
+    const uint32_t bits = f2u(a);
+    const bool fast = bits == 0u || bits - 0x0d800000u < 0x7e800000u - 0x0d800000u;
+    if (__builtin_expect(!fast, 0)) q = a / TPT_PI;
     return q;
 #else
     return a / TPT_PI;

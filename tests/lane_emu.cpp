@@ -89,6 +89,100 @@ int64_t emu_render_ex(const void* spheres, const void* mats, int count, const vo
     return rays;
 }
 
+// The path-queue kernel's class code (tpt_trace.h: qCamera, qLambertBegin, qLightRay, qLightShade, qLambertE, qMetal, qDielectric,
+// qEndTerm, qFold, qStackPush) driven sequentially, one path at a time, in the order tptTraceQueueKernel applies it to a path:
+// intersect, classify, class code, whole light loop of a Lambert hit in place, a Metal whose scattered ray points into the surface
+// ends with the record as it stands.  PER_PIXEL seeds, recursive fold (what that kernel implements).  hs as emu_render.
+int64_t emu_render_queue_classes(const void* spheres, const void* mats, int count, const void* cam, int w, int h, int spp, int frame,
+                                 unsigned flags, int hs, float* backbuffer)
+{
+    std::vector<SpherePOD> S((const SpherePOD*)spheres, (const SpherePOD*)spheres + count);
+    std::vector<MaterialPOD> M((const MaterialPOD*)mats, (const MaterialPOD*)mats + count);
+    PackedScene P;
+    packScene(S, M, P);
+    SceneView sv = viewOf(P);
+    if (hs == 2) sv.nGroups = 0;
+    if (hs == 3) sv.mxR1 = -1;
+    CameraPOD c;
+    memcpy(&c, cam, sizeof(c));
+    const FrameConsts fc = makeFrameConsts(c, w, h, spp, frame, flags, SEED_PER_PIXEL, g_emuConfig, g_emuSmoothing);
+    auto hit = [&](f3 o, f3 d, float& t) {
+        if (hs == HS_SIMPLE) return hitSpheres<HS_SIMPLE>(sv, o, d, TPT_MIN_T, TPT_MAX_T, t);
+        if (hs == 0 && sv.mxR1 >= 0) return hitSpheres<HS_MATRIX>(sv, o, d, TPT_MIN_T, TPT_MAX_T, t);
+        return hitSpheres<HS_TWO_PHASE_GROUPS>(sv, o, d, TPT_MIN_T, TPT_MAX_T, t);
+    };
+    const bool fastDiv = (sv.flags & SCENE_LIGHT_R2_DIV_SAFE) != 0;
+    f4 level0, spill[TPT_MAX_DEPTH];
+    QStack stack;
+    stack.l0 = &level0;
+    stack.spill = spill;
+    stack.stride = 1;
+    int64_t rays = 0;
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            uint32_t rng = pixelSeed(SEED_PER_PIXEL, x, y, frame);
+            f3 col = mk3(0, 0, 0), ro, rd;
+            for (int sample = 0; sample < spp; ++sample) {
+                qCamera(fc, x, y, rng, ro, rd);
+                int depth = 0, recId = -1;
+                bool doMatE = true;
+                for (;;) {
+                    float t;
+                    const int hitId = hit(ro, rd, t);
+                    ++rays;
+                    int cls = -1; // -1: END
+                    if (hitId >= 0 && depth < TPT_MAX_DEPTH) cls = (int)f2u(sv.mats[hitId * 3].w);
+                    if (hitId >= 0) ro = ro + rd * t;
+                    recId = hitId;
+                    bool ended = cls != MAT_LAMBERT && cls != MAT_METAL && cls != MAT_DIELECTRIC;
+                    if (cls == MAT_DIELECTRIC) {
+                        f3 e;
+                        rd = qDielectric(sv, fc, ro, rd, recId, doMatE, rng, e);
+                        qStackPush(stack, depth, e, -1);
+                        depth++;
+                        doMatE = true;
+                    } else if (cls == MAT_METAL) {
+                        f3 e, nd;
+                        if (qMetal(sv, fc, ro, rd, recId, doMatE, rng, e, nd)) {
+                            qStackPush(stack, depth, e, recId);
+                            depth++;
+                            doMatE = true;
+                            rd = nd;
+                        } else {
+                            ended = true; // Test.cpp:218-221: the record as it stands goes to the END class
+                        }
+                    } else if (cls == MAT_LAMBERT) {
+                        QLambert lam;
+                        qLambertBegin(sv, ro, rd, recId, rng, lam);
+                        const int nShadow = (fc.config & CFG_LIGHT_SAMPLING) ? sv.nLights : 0;
+                        for (int j = 0; j < nShadow; ++j) {
+                            const f4 l1 = sv.lights[j * 2 + 1];
+                            const int lightId = (int)f2u(l1.w);
+                            if (lightId == recId) continue; // Test.cpp:100
+                            const f3 d2 = qLightRay(sv.lights[j * 2], ro, rng, lam.cosAMax, fastDiv);
+                            float ts;
+                            const int id = hit(ro, d2, ts);
+                            ++rays;
+                            if (id == lightId) qLightShade(l1, d2, lam);
+                        }
+                        qStackPush(stack, depth, qLambertE(sv, recId, doMatE, lam), recId);
+                        depth++;
+                        doMatE = !(fc.config & CFG_LIGHT_SAMPLING);
+                        rd = lam.sdir;
+                    }
+                    if (ended) {
+                        col = col + qFold(sv, qEndTerm(sv, fc, rd, recId), depth, stack);
+                        break;
+                    }
+                }
+            }
+            float* px = backbuffer + ((size_t)y * w + x) * 4;
+            const f3 out = blendPixel(ld3(px), col * fc.invSpp, fc.lerpFac);
+            px[0] = out.x; px[1] = out.y; px[2] = out.z;
+        }
+    return rays;
+}
+
 // default scene / camera as the product builds them (compared with the reference's GetSceneDesc)
 int emu_default_scene(void* spheres, void* mats, int capacity)
 {

@@ -313,3 +313,54 @@ def test_group_bound_matrix_filter_keeps_every_group_with_an_accepted_member(emu
     emu.emu_group_matrix_check(s.ctypes.data, m.ctypes.data, n, rays.ctypes.data, len(rays), out.ctypes.data)
     assert out[3] > 0 and out[2] > len(rays) and out[0] == 0, out
     assert out[1] / len(rays) < 40  # (and the filter filters: a few groups per ray, not hundreds)
+
+
+def _queue_frames(emu, s, m, cam, w, h, spp, frames, flags, hs):
+    import ctypes as C
+    fn = emu.emu_render_queue_classes
+    fn.restype = C.c_int64
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p] + [C.c_int] * 4 + [C.c_uint, C.c_int, C.c_void_p]
+    bb = np.zeros((h, w, 4), np.float32)
+    rays = 0
+    for f in range(frames):
+        rays += fn(s.ctypes.data, m.ctypes.data, len(s), cam.ctypes.data, w, h, spp, f, flags, hs, bb.ctypes.data)
+    return rays, bb
+
+
+@pytest.mark.parametrize("hs", [0, 1, 3], ids=["matrix_filter_restatement", "simple", "valu_filter"])
+def test_queue_kernel_class_code_bit_exact(emu, oracle, hs):
+    """The path-queue kernel's class code -- one straight-line function per material class (qCamera, qLambertBegin, qLightRay,
+    qLightShade, qLambertE, qMetal, qDielectric, qEndTerm, qFold, qStackPush; per-material 1 / ri and schlick's r0^2 from the scene
+    record) -- driven on the CPU in the order the kernel applies it to a path (tests/lane_emu.cpp: emu_render_queue_classes):
+    bytes and ray counts equal the oracle's, PER_PIXEL seeds, recursive fold."""
+    w, h, spp, frames = 160, 96, 4, 2
+    s, m = oracle.default_scene()
+    cam = oracle.default_camera(w, h)
+    ro, bo, _ = oracle_frames(oracle, w, h, spp, frames, seed_mode=1, fold_mode=0)
+    rq, bq = _queue_frames(emu, s, m, cam, w, h, spp, frames, FLAG_PROGRESSIVE, hs)
+    assert rq == ro and bq.tobytes() == bo.tobytes()
+
+
+def test_queue_kernel_class_code_on_a_grouped_scene_and_with_config_switches(emu, oracle):
+    """The same on a 300-sphere scene (grouped traversal, metals and dielectrics in number) and with the reference's compile-time
+    switches as run-time ones (no light sampling; Mitsuba comparison mode)."""
+    import ctypes as C
+    from toypathtracer_amd.scenes import stress_scene
+    emu.emu_set_config.argtypes = [C.c_int, C.c_float, C.c_int]
+    emu.emu_set_config.restype = None
+    s, m = stress_scene(300, 18)
+    w, h = 96, 54
+    cam = oracle.camera((0, 3, 9), (0, 0, 0), (0, 1, 0), 60.0, w / h, 0.02, 9.0)
+    ro, bo = oracle.render(s, m, cam, w, h, 2, 0, seed_mode=1)
+    rq, bq = _queue_frames(emu, s, m, cam, w, h, 2, 1, FLAG_PROGRESSIVE, 0)
+    assert rq == ro and bq.tobytes() == bo.tobytes()
+    s, m = oracle.default_scene()
+    cam = oracle.default_camera(w, h)
+    for ls, mitsuba in ((0, 0), (1, 1)):
+        emu.emu_set_config(ls, 0.9, mitsuba)
+        try:
+            ro, bo = oracle.render(s, m, cam, w, h, 4, 0, seed_mode=1, light_sampling=bool(ls), mitsuba_compare=bool(mitsuba))
+            rq, bq = _queue_frames(emu, s, m, cam, w, h, 4, 1, FLAG_PROGRESSIVE, 0)
+            assert rq == ro and bq.tobytes() == bo.tobytes(), (ls, mitsuba)
+        finally:
+            emu.emu_set_config(1, 0.9, 0)

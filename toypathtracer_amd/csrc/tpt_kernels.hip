@@ -447,7 +447,6 @@ typedef volatile unsigned* LdsList;
 // Push every lane's path id to the queue of its class `cls` (Q_FREE..Q_LAMBERT, or -1 for none): one returning LDS atomic
 // per lane reserves the slot (the LDS unit serialises the lanes that hit the same tail word -- its time, not the VALU's:
 // the ballot / popcount / readlane version of this cost ~35 VALU instructions per batch).
-#ifndef TPT_Q_PUSH_BALLOT
 __device__ __forceinline__ void qPushByClass(LdsRing q, QueueCtl* ctl, int cls, int pathId, int lane)
 {
     (void)lane;
@@ -462,33 +461,6 @@ __device__ __forceinline__ void qPushByClass(LdsRing q, QueueCtl* ctl, int cls, 
         *slot = (unsigned short)pathId;
     }
 }
-#else
-__device__ __forceinline__ void qPushByClass(LdsRing q, QueueCtl* ctl, int cls, int pathId, int lane)
-{
-    unsigned long long mine = 0ull;
-    unsigned myCount = 0;
-#pragma unroll
-    for (int c = 0; c < Q_COUNT; ++c) {
-        const unsigned long long m = __ballot(cls == c);
-        if (cls == c) mine = m;
-        if (lane == c) myCount = (unsigned)__popcll(m);
-    }
-    unsigned pos = 0;
-    if (lane < Q_COUNT && myCount != 0u) pos = atomicAdd(&ctl->tail[lane], myCount);
-    unsigned base = 0;
-#pragma unroll
-    for (int c = 0; c < Q_COUNT; ++c) {
-        const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)pos, c);
-        if (cls == c) base = b;
-    }
-    if (cls >= 0) {
-        LdsRing slot = q + cls * TPT_Q_P + ((base + (unsigned)__popcll(mine & ((1ull << lane) - 1ull))) & (TPT_Q_P - 1));
-        while (*slot != 0xFFFFu) {
-        }
-        *slot = (unsigned short)pathId;
-    }
-}
-#endif
 // Pops up to 64 ids (uniform count returned); lanes < count receive a path id.
 // h0 / t0: the head and tail the wave read when it chose this queue -- the first reservation is attempted with them (one LDS
 // round trip less per iteration than reading both again first: -DTPT_Q_POP_SNAPSHOT=0); a stale pair just fails the CAS.

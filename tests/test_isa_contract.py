@@ -1,0 +1,117 @@
+"""What DESIGN.md says about the gfx950 code of the path-queue kernels, checked on the code object INSIDE the shipped library
+(no GPU needed: the fat binary is unbundled and disassembled with the ROCm LLVM tools).  Each assertion is a property that cost
+a profiling session to find when it was lost:
+
+  * the LDS rings / pair lists / stack level 0 are DS operations -- a volatile access through a generic pointer compiles to a
+    FLAT load, which reaches LDS through the vector-memory path (rounds 2-3: flat_load_ushort in the pop and push spins);
+  * phase 1 of HitSpheres runs on the matrix cores (v_mfma_f32_32x32x16_f16), 8 of them for the <= 64-sphere table;
+  * 120 VGPRs: four waves per SIMD, i.e. two 8-wave workgroups per CU, and room left for the resolve kernel's waves;
+  * register spills of the headline kernel stay where they were measured (4 VGPRs, 20 B of scratch);
+  * the hot path holds no IEEE division expansion beyond the cold fallbacks of the short forms (tpt_math.h).
+"""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from oracle_lib import ROOT
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+BUNDLER = os.path.join(LLVM, "clang-offload-bundler")
+OBJDUMP = os.path.join(LLVM, "llvm-objdump")
+READELF = os.path.join(LLVM, "llvm-readelf")
+TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
+
+pytestmark = pytest.mark.skipif(not all(os.path.exists(p) for p in (BUNDLER, OBJDUMP, READELF)) or shutil.which("objcopy") is None,
+                                reason="ROCm LLVM tools not installed")
+
+QUEUE = "_ZN3tpt19tptTraceQueueKernelILb%dELb%dEEEvNS_10KernelArgsE"  # <LDS_SCENE, BATCH>
+
+
+@pytest.fixture(scope="module")
+def code_object(tmp_path_factory):
+    from toypathtracer_amd import api
+    d = tmp_path_factory.mktemp("isa")
+    fat, co = str(d / "fat.bin"), str(d / "kernels.co")
+    subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", api.library_path(), fat])
+    targets = subprocess.check_output([BUNDLER, "--list", "--type=o", "--input=" + fat]).decode().split()
+    assert [t for t in targets if t.startswith("hipv4-amdgcn")] == [TARGET], "the library carries gfx950 code only: %r" % targets
+    subprocess.check_call([BUNDLER, "--unbundle", "--type=o", "--targets=" + TARGET, "--input=" + fat, "--output=" + co])
+    dis = subprocess.check_output([OBJDUMP, "-d", co]).decode()
+    notes = subprocess.check_output([READELF, "--notes", co]).decode()
+    bodies = {}
+    for m in re.finditer(r"^[0-9a-f]+ <(\w+)>:\n(.*?)(?=^[0-9a-f]+ <\w+>:|\Z)", dis, flags=re.S | re.M):
+        # one instruction per line: "\t<mnemonic> operands  // address: encoding"
+        bodies[m.group(1)] = [ln.split("//")[0].split() for ln in m.group(2).splitlines() if ln.startswith("\t")]
+    meta = {}
+    for blk in re.split(r"\n\s+- (?=\.agpr_count)", notes)[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        meta[name] = {k: int(v) for k, v in re.findall(r"\.(\w+):\s+(\d+)\s*$", blk, flags=re.M)}
+    return bodies, meta
+
+
+def count(body, pattern):
+    rx = re.compile(pattern)
+    return sum(1 for ins in body if ins and rx.match(ins[0]))
+
+
+def test_every_kernel_of_the_library_is_there(code_object):
+    bodies, meta = code_object
+    names = set(meta)
+    for lds in (0, 1):
+        for batch in (0, 1):
+            assert QUEUE % (lds, batch) in names
+    assert sum(1 for n in names if "tptTraceKernel" in n) == 8      # the lane-refill fallback: HS x PERSIST x LDS
+    for n in ("tptResolveKernel", "tptResolveMirrorKernel", "tptResolveBatchKernel", "tptAssembleKernel", "tptDisplayKernel", "tptChunkOrderKernel"):
+        assert any(n in k for k in names), n
+    assert not any("Test" in k for k in names), "unit-test kernels belong to the hooks build only"
+    assert set(bodies) >= names
+
+
+def test_queue_kernels_keep_lds_traffic_on_ds_instructions(code_object):
+    bodies, _ = code_object
+    for lds in (0, 1):
+        for batch in (0, 1):
+            body = bodies[QUEUE % (lds, batch)]
+            assert count(body, r"flat_") == 0, "a FLAT instruction in %s: an LDS pointer lost its address space" % (QUEUE % (lds, batch))
+            assert count(body, r"ds_(read|load)") >= 30 and count(body, r"ds_(write|store)") >= 15
+            assert count(body, r"buffer_") == 0
+
+
+def test_phase_one_runs_on_the_matrix_cores(code_object):
+    bodies, _ = code_object
+    for batch in (0, 1):
+        # <= 64 spheres: two sphere tiles x two k steps x two ray tiles
+        assert count(bodies[QUEUE % (1, batch)], r"v_mfma_f32_32x32x16_f16") == 8
+        # grouped scenes: four 64-group tables per round of the bound filter
+        assert count(bodies[QUEUE % (0, batch)], r"v_mfma_f32_32x32x16_f16") == 32
+    for name, body in bodies.items():
+        assert count(body, r"v_mfma") == count(body, r"v_mfma_f32_32x32x16_f16"), name
+
+
+def test_register_budget_of_the_queue_kernels(code_object):
+    _, meta = code_object
+    for lds in (0, 1):
+        for batch in (0, 1):
+            m = meta[QUEUE % (lds, batch)]
+            assert m["vgpr_count"] <= 128, "more than 128 VGPRs: three waves per SIMD, one workgroup per CU"
+            assert m["agpr_count"] == 0
+            assert m["max_flat_workgroup_size"] == 512 and m["wavefront_size"] == 64
+    head = meta[QUEUE % (1, 0)]
+    assert head["vgpr_spill_count"] <= 4 and head["private_segment_fixed_size"] <= 20, head
+    assert meta[QUEUE % (1, 1)]["vgpr_spill_count"] <= 4
+    # the grouped-scene kernels hold four candidate masks and the dealing state on top: spills measured, bounded here
+    for batch in (0, 1):
+        assert meta[QUEUE % (0, batch)]["vgpr_spill_count"] <= 32 and meta[QUEUE % (0, batch)]["private_segment_fixed_size"] <= 128
+
+
+def test_divisions_of_the_hot_path_are_the_short_forms(code_object):
+    bodies, _ = code_object
+    for lds in (0, 1):
+        body = bodies[QUEUE % (lds, 0)]
+        # what is left are the cold fallbacks: tdivSafeNum / tdivByPi / trsqrt2 out of their proven ranges, the dielectric's
+        # and the camera's few general quotients (v_div_fixup closes one IEEE expansion each)
+        assert count(body, r"v_div_fixup_f32") <= 10, count(body, r"v_div_fixup_f32")
+        assert count(body, r"v_\w+_f64") <= 61  # sin / cos / pow5 in binary64 (glibc's algorithms), nothing else

@@ -6,6 +6,14 @@
 #define TPT_BLOCK 64         // threads per workgroup: one wave, so a finished wave frees its LDS/VGPRs at once
 #endif
 #define TPT_CHUNK_PIXELS 256 // pixels a persistent wave pulls per atomic (4 tiles of 8x8)
+// Experiment (off: the default build's code is unchanged, tools/build_variant.sh -DTPT_LATE_JOIN=1 turns it on): launches of the
+// path-queue kernel carry joinMult times the workgroups the fill rule asks for; a workgroup beyond the base grid joins only if at
+// least joinPct % of its launch's chunk pool is still unclaimed when it starts, else it exits at once.  On a machine full of
+// earlier launches the surplus arrives late and leaves; on an empty one (the start of a burst of frames) it arrives at once and
+// the launch spreads over twice the slots.  DESIGN 3.3.
+#ifndef TPT_LATE_JOIN
+#define TPT_LATE_JOIN 0
+#endif
 
 namespace tpt {
 
@@ -39,6 +47,9 @@ struct KernelArgs {
     unsigned* work;                  // [0] next chunk, [1] finished waves (persistent variants)
     unsigned long long* rayCounter;  // monotonic total of rays traced by this context
     int rayCounterStride;            // batched row-serial launch: frame j of the batch counts into rayCounter[j * stride] (0: one counter)
+#if TPT_LATE_JOIN
+    int joinBase, joinPct;           // workgroups [0, joinBase) always run; the others only while >= joinPct % of the pool is unclaimed (0: all run)
+#endif
 };
 
 } // namespace tpt

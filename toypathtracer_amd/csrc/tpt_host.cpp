@@ -233,6 +233,9 @@ struct Context {
     f4* dColour[kMaxSlots] = {};
     int hwQueues = 0, overlapCap = kMaxOverlap; // measured at tptInitialize (probeHardwareQueues)
     int slotFactor = 2;                         // colour slots per trace stream (env TPT_SLOT_FACTOR; enqueueTrace)
+#if TPT_LATE_JOIN
+    int joinPct = 0, joinMult = 2;              // experiment (tpt_device.h): env TPT_JOIN_PCT / TPT_JOIN_MULT
+#endif
     int hostPace = 1;                           // env TPT_HOST_PACE=0: let the host run ahead of the pipeline (enqueueTrace)
     int shardCapOverride = 0;                   // env TPT_SHARD_CAP: frames in flight for tiles sharded over > 2 parts (default 8)
     int shardOverlapCap = kMaxOverlap;          // 8 while the frame is sharded over more than two parts (tptSetRowShard)
@@ -638,6 +641,10 @@ int tptInitialize(void)
     if (const char* e6 = getenv("TPT_GRID_FILL")) g.gridFill = atoi(e6);
     if (const char* e7 = getenv("TPT_HOST_PACE")) g.hostPace = atoi(e7);
     if (const char* e9 = getenv("TPT_SLOT_FACTOR")) g.slotFactor = atoi(e9) >= 2 ? 2 : 1;
+#if TPT_LATE_JOIN
+    if (const char* ej = getenv("TPT_JOIN_PCT")) g.joinPct = atoi(ej) < 0 ? 0 : (atoi(ej) > 100 ? 100 : atoi(ej));
+    if (const char* em = getenv("TPT_JOIN_MULT")) g.joinMult = atoi(em) < 1 ? 1 : (atoi(em) > 8 ? 8 : atoi(em));
+#endif
     if (const char* e8 = getenv("TPT_SHARD_CAP")) g.shardCapOverride = atoi(e8);
     if (const char* e5 = getenv("TPT_GRID_DIV")) g.gridDiv = atoi(e5) > 0 ? atoi(e5) : 0;
     if (const char* e2 = getenv("TPT_CHUNK")) g.chunkOverride = atoi(e2);
@@ -1124,6 +1131,14 @@ void sizeGrid(FramePlan& P)
     if (cap < 1) cap = 1;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
+#if TPT_LATE_JOIN
+    a.joinBase = blocks;
+    a.joinPct = P.queued && !P.rowSerial ? g.joinPct : 0;
+    if (a.joinPct > 0) {
+        blocks *= g.joinMult;
+        if (blocks > resident) blocks = resident;
+    }
+#endif
     P.blocks = blocks;
     a.totalWaves = (unsigned)(blocks * wavesPerBlock);
 }

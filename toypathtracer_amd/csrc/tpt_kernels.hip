@@ -741,6 +741,25 @@ tptTraceQueueKernel(const KernelArgs a)
 #endif
 
     const int tid = threadIdx.x, lane = tid & 63;
+#if TPT_LATE_JOIN
+    if (a.joinPct > 0 && (int)blockIdx.x >= a.joinBase) { // (workgroup-uniform: one thread looks, the barrier shares what it saw)
+        unsigned* seen = reinterpret_cast<unsigned*>(smem);
+        if (tid == 0) *seen = __hip_atomic_load(&a.work[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const long long left = (long long)a.numChunks - (long long)*seen;
+        __syncthreads();
+        if (left * 100 < (long long)a.numChunks * a.joinPct) { // too little left to pay for this workgroup's ramp and drain
+            if (lane == 0) {
+                const unsigned done = atomicAdd(&a.work[1], 1u) + 1u; // (the last wave of the launch re-arms the counters: see the end of the kernel)
+                if (done == a.totalWaves) {
+                    a.work[0] = 0u;
+                    a.work[1] = 0u;
+                }
+            }
+            return;
+        }
+    }
+#endif
     SceneView sv = a.scene;
     if (LDS_SCENE) {
         for (int i = tid; i < nPad; i += TPT_Q_T) {

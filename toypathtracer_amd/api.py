@@ -50,14 +50,19 @@ CXX_ABI_SYMBOLS = [
 ]
 
 
+def _lib_dir():
+    # TPT_LIB_DIR: a directory holding another build of BOTH libraries (csrc/build.sh with TPT_OUT_DIR / TPT_EXTRA_FLAGS)
+    return os.environ.get("TPT_LIB_DIR") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib")
+
+
 def library_path():
     # TPT_LIB selects an alternative BUILD OF THE SAME HIP LIBRARY (e.g. the -DTPT_STATS profiling build)
-    return os.environ.get("TPT_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtoypathtracer_hip.so")
+    return os.environ.get("TPT_LIB") or os.path.join(_lib_dir(), "libtoypathtracer_hip.so")
 
 
 def hooks_library_path():
     # (a profiling build selected with TPT_LIB carries the hooks itself: tools/build_variant.sh passes -DTPT_TEST_HOOKS)
-    return os.environ.get("TPT_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtoypathtracer_hip_hooks.so")
+    return os.environ.get("TPT_LIB") or os.path.join(_lib_dir(), "libtoypathtracer_hip_hooks.so")
 
 
 def _bind(path, hooks):

@@ -14,6 +14,16 @@
 #ifndef TPT_LATE_JOIN
 #define TPT_LATE_JOIN 0
 #endif
+// Experiment 2 (off by default, -DTPT_TAIL_HELPERS=1): when the caller BLOCKS (tptSynchronize, tptTimerEnd, tptShardedFinish) while
+// path-queue launches are still in flight, every such launch gets a second grid of workgroups on a spare stream that takes chunks
+// from the same pool -- the last launches of a burst otherwise finish on a half-empty machine (the anatomy of the
+// driver's command).  The launch's counter block (KernelArgs::work) carries the hand-shake: [2] helper workgroups registered,
+// [3] serial of the last launch that CLOSED on this block.  A helper registers, then looks: closed (or a later launch's block) ->
+// it leaves without touching anything; the launch's last wave closes, then waits for the registered helpers before it re-arms the
+// counters and lets the kernel end (so "launch complete" still means "frame complete" for the blend behind it).
+#ifndef TPT_TAIL_HELPERS
+#define TPT_TAIL_HELPERS 0
+#endif
 
 namespace tpt {
 
@@ -47,6 +57,11 @@ struct KernelArgs {
     unsigned* work;                  // [0] next chunk, [1] finished waves (persistent variants)
     unsigned long long* rayCounter;  // monotonic total of rays traced by this context
     int rayCounterStride;            // batched row-serial launch: frame j of the batch counts into rayCounter[j * stride] (0: one counter)
+#if TPT_TAIL_HELPERS
+    unsigned gen;                    // serial of this launch (1, 2, ...; 0: takes no helpers)
+    int helperBase;                  // 0: the launch itself; > 0: its helper grid, whose workgroup b plays workgroup helperBase + b (stack columns)
+    int helperPct;                   // a helper workgroup joins only while at least this % of the pool is unclaimed
+#endif
 #if TPT_LATE_JOIN
     int joinBase, joinPct;           // workgroups [0, joinBase) always run; the others only while >= joinPct % of the pool is unclaimed (0: all run)
 #endif

@@ -236,6 +236,21 @@ struct Context {
 #if TPT_LATE_JOIN
     int joinPct = 0, joinMult = 2;              // experiment (tpt_device.h): env TPT_JOIN_PCT / TPT_JOIN_MULT
 #endif
+#if TPT_TAIL_HELPERS
+    // experiment 2 (tpt_device.h): helper grids for the launches still in flight when the caller blocks
+    static const int kHelperStreams = 4;
+    hipStream_t helperStream[kHelperStreams] = {};
+    hipEvent_t evPre[kMaxSlots] = {};           // recorded on the slot's stream right before its trace launch: what a helper grid has to wait for
+    struct HelperRec {
+        KernelArgs a;
+        bool ldsScene = false, valid = false, helped = false;
+        int blocks = 0, maxBlocks = 0;
+        size_t lds = 0;
+    } hrec[kMaxSlots];
+    unsigned launchGen = 0;
+    int helpersOn = 1, helperPct = 3, helperMax = 8; // env TPT_TAIL_HELPERS (0: off), TPT_HELPER_PCT, TPT_HELPER_MAX (launches helped per wait)
+    long long helperLaunches = 0;
+#endif
     int hostPace = 1;                           // env TPT_HOST_PACE=0: let the host run ahead of the pipeline (enqueueTrace)
     int shardCapOverride = 0;                   // env TPT_SHARD_CAP: frames in flight for tiles sharded over > 2 parts (default 8)
     int shardOverlapCap = kMaxOverlap;          // 8 while the frame is sharded over more than two parts (tptSetRowShard)
@@ -641,6 +656,17 @@ int tptInitialize(void)
     if (const char* e6 = getenv("TPT_GRID_FILL")) g.gridFill = atoi(e6);
     if (const char* e7 = getenv("TPT_HOST_PACE")) g.hostPace = atoi(e7);
     if (const char* e9 = getenv("TPT_SLOT_FACTOR")) g.slotFactor = atoi(e9) >= 2 ? 2 : 1;
+#if TPT_TAIL_HELPERS
+    if (const char* eh = getenv("TPT_TAIL_HELPERS")) g.helpersOn = atoi(eh) != 0;
+    if (const char* eh = getenv("TPT_HELPER_PCT")) g.helperPct = atoi(eh) < 0 ? 0 : (atoi(eh) > 100 ? 100 : atoi(eh));
+    if (const char* eh = getenv("TPT_HELPER_MAX")) g.helperMax = atoi(eh) < 1 ? 1 : (atoi(eh) > Context::kMaxSlots ? Context::kMaxSlots : atoi(eh));
+    for (int k = 0; k < Context::kHelperStreams; ++k) HIPCHK(hipStreamCreateWithFlags(&g.helperStream[k], hipStreamNonBlocking));
+    for (int k = 0; k < Context::kMaxSlots; ++k) {
+        HIPCHK(hipEventCreateWithFlags(&g.evPre[k], kOrderingEvent));
+        g.hrec[k].valid = false;
+    }
+    g.launchGen = 0;
+#endif
 #if TPT_LATE_JOIN
     if (const char* ej = getenv("TPT_JOIN_PCT")) g.joinPct = atoi(ej) < 0 ? 0 : (atoi(ej) > 100 ? 100 : atoi(ej));
     if (const char* em = getenv("TPT_JOIN_MULT")) g.joinMult = atoi(em) < 1 ? 1 : (atoi(em) > 8 ? 8 : atoi(em));
@@ -670,6 +696,17 @@ int tptShutdown(void)
     (void)tptCommDestroy();
     (void)hipStreamSynchronize(g.stream);
     (void)hipDeviceSynchronize();
+#if TPT_TAIL_HELPERS
+    for (int k = 0; k < Context::kHelperStreams; ++k) {
+        if (g.helperStream[k]) (void)hipStreamDestroy(g.helperStream[k]);
+        g.helperStream[k] = nullptr;
+    }
+    for (int k = 0; k < Context::kMaxSlots; ++k) {
+        if (g.evPre[k]) (void)hipEventDestroy(g.evPre[k]);
+        g.evPre[k] = nullptr;
+        g.hrec[k].valid = false;
+    }
+#endif
     for (int k = 0; k < Context::kSceneSets; ++k) {
         Context::SceneSet& S = g.sets[k];
         (void)hipFree(S.dev);
@@ -1175,6 +1212,10 @@ int ensureFrameBuffers(FramePlan& P, int w)
     if (needStack) {
         a.stackBuf = g.dStack[slot % P.nOverlap];
         a.stackStride = P.queued ? P.blocks * tptQueuePathsPerBlock() : P.blocks * P.threadsPerBlock;
+#if TPT_TAIL_HELPERS
+        // the columns of a helper grid (workgroups blocks .. 2 * blocks - 1 at most) lie behind the launch's own: one stride for both
+        if (P.queued) a.stackStride = (2 * P.blocks < maxBlocks ? 2 * P.blocks : maxBlocks) * tptQueuePathsPerBlock();
+#endif
     }
     a.pathBuf = nullptr;
     return 0;
@@ -1183,9 +1224,49 @@ int ensureFrameBuffers(FramePlan& P, int w)
 int syncAllStreams()
 {
     for (int k = 0; k < Context::kMaxOverlap; ++k) HIPCHK(hipStreamSynchronize(g.traceStream[k]));
+#if TPT_TAIL_HELPERS
+    for (int k = 0; k < Context::kHelperStreams; ++k) HIPCHK(hipStreamSynchronize(g.helperStream[k]));
+    for (int k = 0; k < Context::kMaxSlots; ++k) g.hrec[k].valid = false; // (nothing is in flight any more)
+#endif
     HIPCHK(hipStreamSynchronize(g.stream));
     return 0;
 }
+
+#if TPT_TAIL_HELPERS
+// The caller is about to block: give the launches that have not finished a second grid each (tpt_device.h).  The newest launches
+// first -- they have the most left -- and at most helperMax of them; a launch is helped once.  hipEventQuery is a hint only: a launch
+// that finishes a microsecond later closes its counter block and the helpers leave at once.
+int launchTailHelpers()
+{
+    if (!g.helpersOn) return 0;
+    int order[Context::kMaxSlots], n = 0;
+    for (int s = 0; s < Context::kMaxSlots; ++s) {
+        Context::HelperRec& R = g.hrec[s];
+        if (!R.valid || R.helped) continue;
+        if (hipEventQuery(g.evTrace[s]) == hipSuccess) { R.valid = false; continue; }
+        (void)hipGetLastError();
+        order[n++] = s;
+    }
+    if (n < 2) return 0; // (a caller that waits for every frame has nothing to rebalance)
+    for (int i = 1; i < n; ++i) // newest first
+        for (int j = i; j > 0 && (int)(g.hrec[order[j]].a.gen - g.hrec[order[j - 1]].a.gen) > 0; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
+    for (int i = 0; i < n && i < g.helperMax; ++i) {
+        Context::HelperRec& R = g.hrec[order[i]];
+        R.helped = true;
+        int extra = R.maxBlocks - R.blocks;
+        if (extra > R.blocks) extra = R.blocks;
+        if (extra < 1) continue;
+        KernelArgs h = R.a;
+        h.helperBase = R.blocks;
+        h.helperPct = g.helperPct;
+        hipStream_t hs = g.helperStream[i % Context::kHelperStreams];
+        HIPCHK(hipStreamWaitEvent(hs, g.evPre[order[i]], 0));
+        HIPCHK(tptLaunchTraceQueue(h, R.ldsScene, extra, R.lds, hs));
+        g.helperLaunches++;
+    }
+    return 0;
+}
+#endif
 
 // Cost-ordered work distribution of the lane-refill kernel: statistics and order tables for this chunk count.
 int prepareChunkOrder(FramePlan& P)
@@ -1359,6 +1440,18 @@ int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long
     if ((rc = enqueueSceneUpload(ts))) return rc; // behind the wait above: nobody reads the set being replaced any more
     if ((rc = enqueueChunkOrder(P, ts))) return rc;
     if (frameRays && frameRays != g.dRays) HIPCHK(hipMemsetAsync(frameRays, 0, sizeof(unsigned long long) * (size_t)(rayStride > 0 ? batch : 1), ts));
+#if TPT_TAIL_HELPERS
+    const bool helpable = g.helpersOn && P.queued && pipelined && batch == 1 && !P.rowSerial;
+    a.helperBase = 0;
+    a.helperPct = 0;
+    a.gen = 0u;
+    g.hrec[slot].valid = false;
+    if (helpable) {
+        if (++g.launchGen == 0u) g.launchGen = 1u;
+        a.gen = g.launchGen;
+        HIPCHK(hipEventRecord(g.evPre[slot], ts)); // the set upload and the slot's previous users are behind this point
+    }
+#endif
     const bool timeIt = g.kernelTiming && g.ktUsed < g.ktStart.size();
     if (timeIt) HIPCHK(hipEventRecord(g.ktStart[g.ktUsed], ts));
     if (P.queued)
@@ -1370,6 +1463,13 @@ int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long
         g.ktUsed++;
     }
     if (pipelined) HIPCHK(hipEventRecord(g.evTrace[slot], ts));
+#if TPT_TAIL_HELPERS
+    if (helpable) {
+        Context::HelperRec& R = g.hrec[slot];
+        R.a = a; R.ldsScene = P.ldsScene; R.blocks = P.blocks; R.maxBlocks = maxGridBlocks(P); R.lds = P.lds;
+        R.helped = false; R.valid = true;
+    }
+#endif
     T.slot = slot;
     T.nPixels = a.nLocalRows * w;
     T.pipelined = pipelined;
@@ -1551,6 +1651,9 @@ int tptSetRayCounter(void* deviceU64)
 int tptSynchronize(void)
 {
     if (requireInit()) return -1;
+#if TPT_TAIL_HELPERS
+    if (int rc = launchTailHelpers()) return rc;
+#endif
     HIPCHK(hipStreamSynchronize(g.stream));
     return 0;
 }
@@ -1565,6 +1668,9 @@ int tptTimerEnd(float* outMs)
 {
     if (requireInit()) return -1;
     HIPCHK(hipEventRecord(g.ev1, g.stream));
+#if TPT_TAIL_HELPERS
+    if (int rc = launchTailHelpers()) return rc;
+#endif
     HIPCHK(hipEventSynchronize(g.ev1));
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, g.ev0, g.ev1));
@@ -2092,6 +2198,9 @@ int tptShardedFinish(int64_t* outTotalRays)
     if (requireInit()) return -1;
     Context::Shard& S = g.shard;
     if (!S.active) return fail("tptShardedFinish: call tptCommInit first");
+#if TPT_TAIL_HELPERS
+    if (int rc = launchTailHelpers()) return rc;
+#endif
     HIPCHK(hipStreamSynchronize(g.stream));
     HIPCHK(hipStreamSynchronize(S.commStream));
     long long total = 0;

@@ -741,6 +741,27 @@ tptTraceQueueKernel(const KernelArgs a)
 #endif
 
     const int tid = threadIdx.x, lane = tid & 63;
+#if TPT_TAIL_HELPERS
+    const bool helper = a.helperBase > 0;
+    if (helper) { // (workgroup-uniform: one thread registers and looks, the barrier shares what it saw)
+        unsigned* seen = reinterpret_cast<unsigned*>(smem);
+        if (tid == 0) {
+            __hip_atomic_fetch_add(&a.work[2], 1u, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_AGENT); // register ...
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+            const unsigned closed = __hip_atomic_load(&a.work[3], __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_AGENT); // ... then look
+            const unsigned taken = __hip_atomic_load(&a.work[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long left = (long long)a.numChunks - (long long)taken;
+            // closed >= gen (serials only grow; compared as a signed difference): the launch has finished, or the block serves a later one
+            const bool join = (int)(closed - a.gen) < 0 && left > 0 && left * 100 >= (long long)a.numChunks * a.helperPct;
+            if (!join) __hip_atomic_fetch_sub(&a.work[2], 1u, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_AGENT);
+            *seen = join ? 1u : 0u;
+        }
+        __syncthreads();
+        const unsigned join = *seen;
+        __syncthreads();
+        if (!join) return;
+    }
+#endif
 #if TPT_LATE_JOIN
     if (a.joinPct > 0 && (int)blockIdx.x >= a.joinBase) { // (workgroup-uniform: one thread looks, the barrier shares what it saw)
         unsigned* seen = reinterpret_cast<unsigned*>(smem);
@@ -906,7 +927,11 @@ tptTraceQueueKernel(const KernelArgs a)
         bool toEnd = false;  // Metal whose scattered ray points into the surface: the path ends (END class), nothing to intersect
         QStack stack;
         stack.l0 = (LdsF4Ptr)(st + 3 * TPT_Q_PATHS + p); // level 0 in the path record
+#if TPT_TAIL_HELPERS
+        stack.spill = a.stackBuf + ((size_t)(blockIdx.x + (unsigned)a.helperBase) * TPT_Q_PATHS + p);
+#else
         stack.spill = a.stackBuf + ((size_t)blockIdx.x * TPT_Q_PATHS + p);
+#endif
         stack.stride = a.stackStride;
         QLambert lam;
         lam.sdir = lam.nl = lam.albedo = lam.lightE = mk3(0, 0, 0);
@@ -1160,10 +1185,33 @@ tptTraceQueueKernel(const KernelArgs a)
         __syncthreads();
         if (tid < a.batchFrames && ctl->frameRays[tid] != 0u) atomicAdd(a.rayCounter + (size_t)tid * a.rayCounterStride, (unsigned long long)ctl->frameRays[tid]);
     }
+#if TPT_TAIL_HELPERS
+    if (helper) {
+        // this workgroup's pixels are stored and its rays counted: leave the launch (release: the stores reach memory first)
+        if (lane == 0 && !BATCH) atomicAdd(a.rayCounter, (unsigned long long)waveRays);
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_fetch_sub(&a.work[2], 1u, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+#endif
     if (lane == 0) {
         if (!BATCH) atomicAdd(a.rayCounter, (unsigned long long)waveRays);
         unsigned done = atomicAdd(&a.work[1], 1u) + 1u;
         if (done == a.totalWaves) {
+#if TPT_TAIL_HELPERS
+            if (a.gen != 0u) {
+                // close, THEN look for registered helpers (they register, then look for "closed": one side always sees the other);
+                // they are resident workgroups finishing the chunks they took -- bounded; the cap only keeps a bug from hanging the GPU
+                __hip_atomic_store(&a.work[3], a.gen, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+                for (unsigned spins = 0; spins < 60000u && __hip_atomic_load(&a.work[2], __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_AGENT) != 0u; ++spins)
+                    __builtin_amdgcn_s_sleep(127);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+#endif
             a.work[0] = 0u;
             a.work[1] = 0u;
         }

@@ -248,6 +248,7 @@ struct Context {
         size_t lds = 0;
     } hrec[kMaxSlots];
     unsigned launchGen = 0;
+    int helperStride = 1;
     int helpersOn = 1, helperPct = 3, helperMax = 8; // env TPT_TAIL_HELPERS (0: off), TPT_HELPER_PCT, TPT_HELPER_MAX (launches helped per wait)
     long long helperLaunches = 0;
 #endif
@@ -660,8 +661,8 @@ int tptInitialize(void)
     if (const char* eh = getenv("TPT_TAIL_HELPERS")) g.helpersOn = atoi(eh) != 0;
     if (const char* eh = getenv("TPT_HELPER_PCT")) g.helperPct = atoi(eh) < 0 ? 0 : (atoi(eh) > 100 ? 100 : atoi(eh));
     if (const char* eh = getenv("TPT_HELPER_MAX")) g.helperMax = atoi(eh) < 1 ? 1 : (atoi(eh) > Context::kMaxSlots ? Context::kMaxSlots : atoi(eh));
-    for (int k = 0; k < Context::kHelperStreams; ++k) HIPCHK(hipStreamCreateWithFlags(&g.helperStream[k], hipStreamNonBlocking));
-    for (int k = 0; k < Context::kMaxSlots; ++k) {
+    if (const char* eh = getenv("TPT_HELPER_STRIDE")) g.helperStride = atoi(eh) != 0; // (diagnostic: 0 keeps the plain stack stride; only with the helpers off)
+    for (int k = 0; k < Context::kMaxSlots; ++k) { // (the helper streams are created by the first wait that needs them)
         HIPCHK(hipEventCreateWithFlags(&g.evPre[k], kOrderingEvent));
         g.hrec[k].valid = false;
     }
@@ -1214,7 +1215,7 @@ int ensureFrameBuffers(FramePlan& P, int w)
         a.stackStride = P.queued ? P.blocks * tptQueuePathsPerBlock() : P.blocks * P.threadsPerBlock;
 #if TPT_TAIL_HELPERS
         // the columns of a helper grid (workgroups blocks .. 2 * blocks - 1 at most) lie behind the launch's own: one stride for both
-        if (P.queued) a.stackStride = (2 * P.blocks < maxBlocks ? 2 * P.blocks : maxBlocks) * tptQueuePathsPerBlock();
+        if (P.queued && (g.helpersOn || g.helperStride) && g.helperStride) a.stackStride = (2 * P.blocks < maxBlocks ? 2 * P.blocks : maxBlocks) * tptQueuePathsPerBlock();
 #endif
     }
     a.pathBuf = nullptr;
@@ -1225,7 +1226,8 @@ int syncAllStreams()
 {
     for (int k = 0; k < Context::kMaxOverlap; ++k) HIPCHK(hipStreamSynchronize(g.traceStream[k]));
 #if TPT_TAIL_HELPERS
-    for (int k = 0; k < Context::kHelperStreams; ++k) HIPCHK(hipStreamSynchronize(g.helperStream[k]));
+    for (int k = 0; k < Context::kHelperStreams; ++k)
+        if (g.helperStream[k]) HIPCHK(hipStreamSynchronize(g.helperStream[k]));
     for (int k = 0; k < Context::kMaxSlots; ++k) g.hrec[k].valid = false; // (nothing is in flight any more)
 #endif
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -1259,6 +1261,7 @@ int launchTailHelpers()
         KernelArgs h = R.a;
         h.helperBase = R.blocks;
         h.helperPct = g.helperPct;
+        if (!g.helperStream[i % Context::kHelperStreams]) HIPCHK(hipStreamCreateWithFlags(&g.helperStream[i % Context::kHelperStreams], hipStreamNonBlocking));
         hipStream_t hs = g.helperStream[i % Context::kHelperStreams];
         HIPCHK(hipStreamWaitEvent(hs, g.evPre[order[i]], 0));
         HIPCHK(tptLaunchTraceQueue(h, R.ldsScene, extra, R.lds, hs));
@@ -1441,7 +1444,7 @@ int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long
     if ((rc = enqueueChunkOrder(P, ts))) return rc;
     if (frameRays && frameRays != g.dRays) HIPCHK(hipMemsetAsync(frameRays, 0, sizeof(unsigned long long) * (size_t)(rayStride > 0 ? batch : 1), ts));
 #if TPT_TAIL_HELPERS
-    const bool helpable = g.helpersOn && P.queued && pipelined && batch == 1 && !P.rowSerial;
+    const bool helpable = g.helpersOn && g.helperStride && P.queued && pipelined && batch == 1 && !P.rowSerial;
     a.helperBase = 0;
     a.helperPct = 0;
     a.gen = 0u;

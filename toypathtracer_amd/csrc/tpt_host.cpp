@@ -244,6 +244,7 @@ struct Context {
     struct HelperRec {
         KernelArgs a;
         bool ldsScene = false, valid = false, helped = false;
+        hipStream_t ts = nullptr;
         int blocks = 0, maxBlocks = 0;
         size_t lds = 0;
     } hrec[kMaxSlots];
@@ -660,7 +661,7 @@ int tptInitialize(void)
 #if TPT_TAIL_HELPERS
     if (const char* eh = getenv("TPT_TAIL_HELPERS")) g.helpersOn = atoi(eh) != 0;
     if (const char* eh = getenv("TPT_HELPER_PCT")) g.helperPct = atoi(eh) < 0 ? 0 : (atoi(eh) > 100 ? 100 : atoi(eh));
-    if (const char* eh = getenv("TPT_HELPER_MAX")) g.helperMax = atoi(eh) < 1 ? 1 : (atoi(eh) > Context::kMaxSlots ? Context::kMaxSlots : atoi(eh));
+    if (const char* eh = getenv("TPT_HELPER_MAX")) g.helperMax = atoi(eh) < 0 ? 0 : (atoi(eh) > Context::kMaxSlots ? Context::kMaxSlots : atoi(eh));
     if (const char* eh = getenv("TPT_HELPER_STRIDE")) g.helperStride = atoi(eh) != 0; // (diagnostic: 0 keeps the plain stack stride; only with the helpers off)
     for (int k = 0; k < Context::kMaxSlots; ++k) { // (the helper streams are created by the first wait that needs them)
         HIPCHK(hipEventCreateWithFlags(&g.evPre[k], kOrderingEvent));
@@ -1252,7 +1253,10 @@ int launchTailHelpers()
     if (n < 2) return 0; // (a caller that waits for every frame has nothing to rebalance)
     for (int i = 1; i < n; ++i) // newest first
         for (int j = i; j > 0 && (int)(g.hrec[order[j]].a.gen - g.hrec[order[j - 1]].a.gen) > 0; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
-    for (int i = 0; i < n && i < g.helperMax; ++i) {
+    // The k-th newest launch is helped from the stream of the k-th OLDEST one: that stream is the next to fall idle, which is when
+    // the machine starts to empty.  (Streams of their own were tried first: four more streams in the process cost the whole
+    // pipeline a factor 2.4 -- the runtime's hardware queues are a shared, small pool; profiles/r04/r04_run21.log, r04_run22.log.)
+    for (int i = 0; i < n / 2 && i < g.helperMax; ++i) {
         Context::HelperRec& R = g.hrec[order[i]];
         R.helped = true;
         int extra = R.maxBlocks - R.blocks;
@@ -1261,8 +1265,7 @@ int launchTailHelpers()
         KernelArgs h = R.a;
         h.helperBase = R.blocks;
         h.helperPct = g.helperPct;
-        if (!g.helperStream[i % Context::kHelperStreams]) HIPCHK(hipStreamCreateWithFlags(&g.helperStream[i % Context::kHelperStreams], hipStreamNonBlocking));
-        hipStream_t hs = g.helperStream[i % Context::kHelperStreams];
+        hipStream_t hs = g.hrec[order[n - 1 - i]].ts;
         HIPCHK(hipStreamWaitEvent(hs, g.evPre[order[i]], 0));
         HIPCHK(tptLaunchTraceQueue(h, R.ldsScene, extra, R.lds, hs));
         g.helperLaunches++;
@@ -1470,7 +1473,7 @@ int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long
     if (helpable) {
         Context::HelperRec& R = g.hrec[slot];
         R.a = a; R.ldsScene = P.ldsScene; R.blocks = P.blocks; R.maxBlocks = maxGridBlocks(P); R.lds = P.lds;
-        R.helped = false; R.valid = true;
+        R.helped = false; R.valid = true; R.ts = ts;
     }
 #endif
     T.slot = slot;

@@ -444,6 +444,15 @@ typedef volatile unsigned __attribute__((address_space(3))) * LdsList;
 typedef volatile unsigned short* LdsRing;
 typedef volatile unsigned* LdsList;
 #endif
+#if TPT_TAIL_HELPERS
+// 0, but only once `v` has arrived: orders a second atomic behind the RETURN of a first one without a fence (tpt_device.h)
+__device__ __forceinline__ unsigned dependentZero(unsigned v)
+{
+    unsigned z;
+    asm volatile("v_and_b32_e32 %0, 0, %1" : "=v"(z) : "v"(v));
+    return z;
+}
+#endif
 // Push every lane's path id to the queue of its class `cls` (Q_FREE..Q_LAMBERT, or -1 for none): one returning LDS atomic
 // per lane reserves the slot (the LDS unit serialises the lanes that hit the same tail word -- its time, not the VALU's:
 // the ballot / popcount / readlane version of this cost ~35 VALU instructions per batch).
@@ -746,14 +755,16 @@ tptTraceQueueKernel(const KernelArgs a)
     if (helper) { // (workgroup-uniform: one thread registers and looks, the barrier shares what it saw)
         unsigned* seen = reinterpret_cast<unsigned*>(smem);
         if (tid == 0) {
-            __hip_atomic_fetch_add(&a.work[2], 1u, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_AGENT); // register ...
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-            const unsigned closed = __hip_atomic_load(&a.work[3], __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_AGENT); // ... then look
+            // register, THEN look (the launch's last wave closes, THEN looks for registrations).  Both sides use returning atomics --
+            // performed at the device's coherence point -- and feed the first one's result into the second (a dependency the hardware
+            // has to honour): no cache write-back / invalidate as a seq_cst fence at agent scope would cost every helper workgroup
+            const unsigned was = __hip_atomic_fetch_add(&a.work[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned closed = __hip_atomic_fetch_or(&a.work[3], dependentZero(was), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned taken = __hip_atomic_load(&a.work[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const long long left = (long long)a.numChunks - (long long)taken;
             // closed >= gen (serials only grow; compared as a signed difference): the launch has finished, or the block serves a later one
             const bool join = (int)(closed - a.gen) < 0 && left > 0 && left * 100 >= (long long)a.numChunks * a.helperPct;
-            if (!join) __hip_atomic_fetch_sub(&a.work[2], 1u, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_AGENT);
+            if (!join) __hip_atomic_fetch_sub(&a.work[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             *seen = join ? 1u : 0u;
         }
         __syncthreads();
@@ -1205,11 +1216,12 @@ tptTraceQueueKernel(const KernelArgs a)
             if (a.gen != 0u) {
                 // close, THEN look for registered helpers (they register, then look for "closed": one side always sees the other);
                 // they are resident workgroups finishing the chunks they took -- bounded; the cap only keeps a bug from hanging the GPU
-                __hip_atomic_store(&a.work[3], a.gen, __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
-                for (unsigned spins = 0; spins < 60000u && __hip_atomic_load(&a.work[2], __ATOMIC_SEQ_CST, __HIP_MEMORY_SCOPE_AGENT) != 0u; ++spins)
+                const unsigned prev = __hip_atomic_exchange(&a.work[3], a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                unsigned busy = __hip_atomic_fetch_or(&a.work[2], dependentZero(prev), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (unsigned spins = 0; spins < 60000u && busy != 0u; ++spins) {
                     __builtin_amdgcn_s_sleep(127);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                    busy = __hip_atomic_fetch_or(&a.work[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
             }
 #endif
             a.work[0] = 0u;

@@ -1245,19 +1245,31 @@ int launchTailHelpers()
     int order[Context::kMaxSlots], n = 0;
     for (int s = 0; s < Context::kMaxSlots; ++s) {
         Context::HelperRec& R = g.hrec[s];
-        if (!R.valid || R.helped) continue;
+        if (!R.valid) continue;
         if (hipEventQuery(g.evTrace[s]) == hipSuccess) { R.valid = false; continue; }
         (void)hipGetLastError();
-        order[n++] = s;
+        order[n++] = s; // every launch still in flight, helped already or not
     }
     if (n < 2) return 0; // (a caller that waits for every frame has nothing to rebalance)
     for (int i = 1; i < n; ++i) // newest first
         for (int j = i; j > 0 && (int)(g.hrec[order[j]].a.gen - g.hrec[order[j - 1]].a.gen) > 0; --j) { const int t = order[j]; order[j] = order[j - 1]; order[j - 1] = t; }
-    // The k-th newest launch is helped from the stream of the k-th OLDEST one: that stream is the next to fall idle, which is when
-    // the machine starts to empty.  (Streams of their own were tried first: four more streams in the process cost the whole
-    // pipeline a factor 2.4 -- the runtime's hardware queues are a shared, small pool; profiles/r04/r04_run21.log, r04_run22.log.)
-    for (int i = 0; i < n / 2 && i < g.helperMax; ++i) {
+    // The k-th newest launch is helped from the stream of the k-th OLDEST launch that has nothing queued behind it: that stream is
+    // the next to fall idle for good -- a burst longer than the 16 streams has its last launches queued behind its first ones, and a
+    // helper placed there would start when everything is over (profiles/r04/r04_run23.log).  The helper may well start before the
+    // launch it helps (it only waits for what that launch waits for): the pool is simply part-consumed when the launch arrives.
+    // (Streams of their own were tried first: four more streams in the process cost the whole pipeline a factor 2.4 -- the
+    // runtime's hardware queues are a small shared pool; r04_run21.log, r04_run22.log.)
+    hipStream_t freeSoon[Context::kMaxSlots];
+    int nFree = 0;
+    for (int i = n - 1; i >= 0; --i) { // oldest first
+        hipStream_t ts = g.hrec[order[i]].ts;
+        int queued = 0;
+        for (int j = 0; j < n; ++j) queued += g.hrec[order[j]].ts == ts ? 1 : 0;
+        if (queued == 1) freeSoon[nFree++] = ts;
+    }
+    for (int i = 0; i < n / 2 && i < g.helperMax && i < nFree; ++i) {
         Context::HelperRec& R = g.hrec[order[i]];
+        if (R.helped) continue;
         R.helped = true;
         int extra = R.maxBlocks - R.blocks;
         if (extra > R.blocks) extra = R.blocks;
@@ -1265,7 +1277,8 @@ int launchTailHelpers()
         KernelArgs h = R.a;
         h.helperBase = R.blocks;
         h.helperPct = g.helperPct;
-        hipStream_t hs = g.hrec[order[n - 1 - i]].ts;
+        hipStream_t hs = freeSoon[i];
+        if (hs == R.ts) continue; // (its own stream: it would run after the launch it is meant to help)
         HIPCHK(hipStreamWaitEvent(hs, g.evPre[order[i]], 0));
         HIPCHK(tptLaunchTraceQueue(h, R.ldsScene, extra, R.lds, hs));
         g.helperLaunches++;

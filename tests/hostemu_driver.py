@@ -1,0 +1,300 @@
+"""TEST INFRASTRUCTURE: scenarios that drive csrc/tpt_host.cpp -- compiled against tests/hostemu's stand-in for the HIP runtime and
+host restatements of the kernels -- through the same ctypes mirror the GPU tests use, and hold every image and ray count against the
+oracle.  Run by tests/test_host_logic.py in a subprocess with TPT_LIB=tests/_build/libtpt_hostemu.so and HOSTEMU_POLICY=eager|lazy|
+random:<seed>; prints one line per scenario.  The scenarios are the GPU suite's (tests/test_gpu_api.py, test_gpu_parity.py) at sizes a
+CPU renders in a fraction of a second."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+from common import oracle_frames  # noqa: E402
+from oracle_lib import FLAG_ANIMATE, FLAG_PROGRESSIVE, SEED_PER_PIXEL, SEED_ROW_SERIAL, Oracle  # noqa: E402
+
+assert "hostemu" in os.environ.get("TPT_LIB", ""), "this driver is for the host-emulation build only"
+from toypathtracer_amd import api as tpt  # noqa: E402
+
+o = Oracle.get()
+W, H, SPP = 64, 40, 2
+
+
+def ptr(a):
+    return a.ctypes.data
+
+
+def same(got, want, what):
+    if got.tobytes() != want.tobytes():
+        bad = np.argwhere(got.view(np.uint32) != want.view(np.uint32))
+        raise AssertionError("%s: %d words differ, first at %s" % (what, len(bad), bad[0] if len(bad) else None))
+
+
+def reset():
+    tpt.set_samples_per_pixel(SPP)
+    tpt.set_seed_mode(SEED_PER_PIXEL)
+    tpt.set_fold_mode(0)
+    tpt.set_kernel_variant(0, 3, -1)
+    tpt.set_config()
+    tpt.set_scene()
+    tpt.set_camera()
+    tpt.set_frame_overlap(16)
+    tpt.set_row_shard(0, 1, 0)
+    tpt.set_host_lookahead(2)
+    tpt.set_host_buffer_mode(0)
+    tpt.set_stream_batching(1)
+    tpt.set_tile_mirror(0)
+    tpt.set_ray_counter(0)
+    tpt.synchronize()
+
+
+def streaming(frames=12, w=W, h=H, flags=FLAG_PROGRESSIVE, batching=True, **variant):
+    """enqueue, enqueue, ..., one synchronise: image and ray total"""
+    reset()
+    tpt.set_stream_batching(1 if batching else 0)
+    if variant:
+        tpt.set_kernel_variant(**variant)
+    tile = np.zeros((h, w, 4), np.float32)
+    r0 = tpt.ray_counter_read()
+    for f in range(frames):
+        tpt.UpdateTest(f / 60.0, f, w, h, flags)
+        tpt.draw_device(f / 60.0, f, w, h, ptr(tile), flags)
+    tpt.synchronize()
+    rays = tpt.ray_counter_read() - r0
+    if flags & FLAG_ANIMATE:
+        return  # (the animated scene is held against the oracle frame by frame in scenario `animated`)
+    total, want, _ = oracle_frames(o, w, h, SPP, frames, seed_mode=SEED_PER_PIXEL)
+    same(tile, want, "streaming %dx%d %s" % (w, h, variant))
+    assert rays == total, (rays, total)
+
+
+def synchronous_device_caller(frames=10):
+    """a synchronise after every frame: from the third frame on the next ones are traced ahead"""
+    reset()
+    tile = np.zeros((H, W, 4), np.float32)
+    total, want, per_frame = oracle_frames(o, W, H, SPP, frames, seed_mode=SEED_PER_PIXEL)
+    hits0 = tpt.lookahead_hits()
+    last = tpt.ray_counter_read()
+    for f in range(frames):
+        tpt.UpdateTest(0.0, f, W, H, FLAG_PROGRESSIVE)
+        tpt.draw_device(0.0, f, W, H, ptr(tile), FLAG_PROGRESSIVE)
+        tpt.synchronize()
+        now = tpt.ray_counter_read()
+        assert now - last == per_frame[f], (f, now - last, per_frame[f])
+        last = now
+    same(tile, want, "synchronous device caller")
+    return tpt.lookahead_hits() - hits0
+
+
+def drawtest_host(frames=8, seed_mode=SEED_PER_PIXEL, lookahead=2, w=W, h=H):
+    """the reference's own contract: DrawTest(host float*) returns when the frame is in the buffer, with its ray count"""
+    reset()
+    tpt.set_seed_mode(seed_mode)
+    tpt.set_host_lookahead(lookahead)
+    bb = np.zeros((h, w, 4), np.float32)
+    total, want, per_frame = oracle_frames(o, w, h, SPP, frames, seed_mode=seed_mode)
+    for f in range(frames):
+        tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+        rays = tpt.DrawTest(0.0, f, w, h, bb, FLAG_PROGRESSIVE)
+        assert rays == per_frame[f], (f, rays, per_frame[f])
+    same(bb, want, "DrawTest seed mode %d lookahead %d" % (seed_mode, lookahead))
+
+
+def lookahead_dropped_by_state_changes():
+    """frames traced ahead on a guess are thrown away when anything they depend on changes"""
+    reset()
+    bb = np.zeros((H, W, 4), np.float32)
+    for f in range(4):
+        tpt.UpdateTest(0.0, f, W, H, FLAG_PROGRESSIVE)
+        tpt.DrawTest(0.0, f, W, H, bb, FLAG_PROGRESSIVE)
+    tpt.set_samples_per_pixel(1)  # the frames traced ahead used 2 spp
+    s, m = o.default_scene()
+    cam = o.default_camera(W, H)
+    want = bb.copy()
+    for f in range(4, 7):
+        tpt.UpdateTest(0.0, f, W, H, FLAG_PROGRESSIVE)
+        rays = tpt.DrawTest(0.0, f, W, H, bb, FLAG_PROGRESSIVE)
+        r, _ = o.render(s, m, cam, W, H, 1, f, FLAG_PROGRESSIVE, backbuffer=want, seed_mode=SEED_PER_PIXEL)
+        assert rays == r, (f, rays, r)
+    same(bb, want, "look-ahead after a change of spp")
+    # a repeated frame number is not "the next frame" either
+    tpt.UpdateTest(0.0, 6, W, H, FLAG_PROGRESSIVE)
+    rays = tpt.DrawTest(0.0, 6, W, H, bb, FLAG_PROGRESSIVE)
+    r, _ = o.render(s, m, cam, W, H, 1, 6, FLAG_PROGRESSIVE, backbuffer=want, seed_mode=SEED_PER_PIXEL)
+    assert rays == r
+    same(bb, want, "look-ahead after a repeated frame")
+
+
+def batches(sizes=(3, 1, 4), seed_mode=SEED_PER_PIXEL):
+    """tptDrawDeviceBatch: the same bits as one call per frame"""
+    reset()
+    tpt.set_seed_mode(seed_mode)
+    tile = np.zeros((H, W, 4), np.float32)
+    f = 0
+    r0 = tpt.ray_counter_read()
+    for k in sizes:
+        tpt.UpdateTest(0.0, f, W, H, FLAG_PROGRESSIVE)
+        tpt.draw_device_batch(0.0, f, k, W, H, ptr(tile), FLAG_PROGRESSIVE)
+        f += k
+    tpt.synchronize()
+    total, want, _ = oracle_frames(o, W, H, SPP, f, seed_mode=seed_mode)
+    same(tile, want, "batches %s seed mode %d" % (sizes, seed_mode))
+    assert tpt.ray_counter_read() - r0 == total
+
+
+def stream_batching(frames=21, w=32, h=24):
+    """small frames of a streaming caller are traced several per launch behind its back; every frame is still delivered"""
+    reset()
+    tile = np.zeros((h, w, 4), np.float32)
+    total, want, per_frame = oracle_frames(o, w, h, SPP, frames, seed_mode=SEED_PER_PIXEL)
+    r0 = tpt.ray_counter_read()
+    for f in range(frames):
+        tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+        tpt.draw_device(0.0, f, w, h, ptr(tile), FLAG_PROGRESSIVE)
+    tpt.synchronize()
+    same(tile, want, "stream batching")
+    assert tpt.ray_counter_read() - r0 == total
+    return tpt.launch_info()
+
+
+def animated(frames=6):
+    """kFlagAnimate: UpdateTest moves a sphere every frame; every frame needs its own scene set in flight"""
+    reset()
+    tile = np.zeros((H, W, 4), np.float32)
+    flags = FLAG_PROGRESSIVE | FLAG_ANIMATE
+    s, m = o.default_scene()
+    cam = o.default_camera(W, H)
+    want = np.zeros((H, W, 4), np.float32)
+    total = 0
+    r0 = tpt.ray_counter_read()
+    for f in range(frames):
+        t = f / 60.0
+        tpt.UpdateTest(t, f, W, H, flags)
+        tpt.draw_device(t, f, W, H, ptr(tile), flags)
+        o.animate(s, t)
+        r, _ = o.render(s, m, cam, W, H, SPP, f, flags, backbuffer=want, seed_mode=SEED_PER_PIXEL)
+        total += r
+    tpt.synchronize()
+    same(tile, want, "animated scene")
+    assert tpt.ray_counter_read() - r0 == total
+
+
+def resizes():
+    """frame shapes that grow, shrink and grow again while frames are in flight (buffer re-allocation drains the pipeline first)"""
+    reset()
+    for (w, h, frames) in [(32, 24, 5), (96, 64, 4), (40, 40, 6), (96, 64, 3)]:
+        tile = np.zeros((h, w, 4), np.float32)
+        for f in range(frames):
+            tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+            tpt.draw_device(0.0, f, w, h, ptr(tile), FLAG_PROGRESSIVE)
+        tpt.synchronize()
+        _, want, _ = oracle_frames(o, w, h, SPP, frames, seed_mode=SEED_PER_PIXEL)
+        same(tile, want, "resize to %dx%d" % (w, h))
+
+
+def sharded_loopback(n=4, frames=10, w=80, h=56, stripe=8):
+    """rank 0 of n on a loopback communicator: its stripes equal the 1-GPU render, the other ranks' rows stay zero"""
+    reset()
+    tpt.comm_init_loopback(n, stripe)
+    try:
+        img = np.zeros((h, w, 4), np.float32)
+        for f in range(frames):
+            tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+            tpt.draw_sharded(0.0, f, w, h, ptr(img), FLAG_PROGRESSIVE)
+        tpt.sharded_finish()
+    finally:
+        tpt.comm_destroy()
+    _, want, _ = oracle_frames(o, w, h, SPP, frames, seed_mode=SEED_PER_PIXEL)
+    mine = (np.arange(h) // stripe) % n == 0
+    same(img[mine], want[mine], "sharded loopback n=%d" % n)
+    assert not img[~mine].any()
+
+
+def sharded_batches(n=4, w=80, h=56, stripe=8, sizes=(3, 1, 4)):
+    """tptDrawShardedBatch: rank 0's stripes after batches of 3 + 1 + 4 frames equal the 1-GPU render of 8 frames"""
+    reset()
+    tpt.comm_init_loopback(n, stripe)
+    try:
+        img = np.zeros((h, w, 4), np.float32)
+        f = 0
+        for k in sizes:
+            tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+            tpt.draw_sharded_batch(0.0, f, k, w, h, ptr(img), FLAG_PROGRESSIVE)
+            f += k
+        tpt.sharded_finish()
+    finally:
+        tpt.comm_destroy()
+    _, want, _ = oracle_frames(o, w, h, SPP, f, seed_mode=SEED_PER_PIXEL)
+    mine = (np.arange(h) // stripe) % n == 0
+    same(img[mine], want[mine], "sharded batches")
+    assert not img[~mine].any()
+
+
+def custom_scene_and_camera():
+    """tptSetScene / tptSetCamera between frames of a stream: the frames before see the old scene, the ones after the new one"""
+    reset()
+    from toypathtracer_amd.scenes import stress_scene
+    tile = np.zeros((H, W, 4), np.float32)
+    want = np.zeros((H, W, 4), np.float32)
+    s0, m0 = o.default_scene()
+    cam0 = o.default_camera(W, H)
+    s1, m1 = stress_scene(300, 18)
+    cam1 = o.camera((0, 3, 9), (0, 0, 0), (0, 1, 0), 50.0, W / H, 0.0, 9.0)
+    for f in range(6):
+        if f == 3:
+            tpt.set_scene(s1, m1)
+            tpt.set_camera((0, 3, 9), (0, 0, 0), 50.0, 0.0, 9.0)
+        tpt.UpdateTest(0.0, f, W, H, FLAG_PROGRESSIVE)
+        tpt.draw_device(0.0, f, W, H, ptr(tile), FLAG_PROGRESSIVE)
+        s, m, cam = (s0, m0, cam0) if f < 3 else (s1, m1, cam1)
+        o.render(s, m, cam, W, H, SPP, f, FLAG_PROGRESSIVE, backbuffer=want, seed_mode=SEED_PER_PIXEL)
+    tpt.synchronize()
+    same(tile, want, "scene and camera change in a stream")
+
+
+SCENARIOS = [
+    ("streaming", lambda: streaming()),
+    ("streaming, one launch per frame", lambda: streaming(frames=20, batching=False)),
+    ("streaming 20 frames twice, one launch per frame", lambda: (streaming(frames=20, batching=False), streaming(frames=20, w=48, h=32, batching=False))[0]),
+    ("streaming 44 frames (every slot reused), one launch per frame", lambda: streaming(frames=44, w=32, h=24, batching=False)),
+    ("streaming, lane-refill kernel", lambda: streaming(frames=6, hit_spheres=0, persistent=1, lds_scene=-1)),
+    ("streaming, animate flag", lambda: streaming(frames=5, flags=FLAG_PROGRESSIVE | FLAG_ANIMATE)),
+    ("synchronous device caller", synchronous_device_caller),
+    ("DrawTest host pointer", lambda: drawtest_host()),
+    ("DrawTest host pointer, no look-ahead", lambda: drawtest_host(frames=4, lookahead=0)),
+    ("DrawTest reference seed mode (row-serial batches)", lambda: drawtest_host(frames=40, seed_mode=SEED_ROW_SERIAL, w=24, h=12)),
+    ("look-ahead dropped by state changes", lookahead_dropped_by_state_changes),
+    ("batches", lambda: batches()),
+    ("batches, reference seed mode", lambda: batches((2, 5), SEED_ROW_SERIAL)),
+    ("stream batching", stream_batching),
+    ("animated", animated),
+    ("resizes", resizes),
+    ("sharded loopback n=2", lambda: sharded_loopback(2)),
+    ("sharded loopback n=4", lambda: sharded_loopback(4)),
+    ("sharded batches", sharded_batches),
+    ("custom scene and camera", custom_scene_and_camera),
+]
+
+if __name__ == "__main__":
+    only = sys.argv[1:]
+    tpt.InitializeTest()
+    failed = 0
+    for name, fn in SCENARIOS:
+        if only and not any(k in name for k in only):
+            continue
+        try:
+            extra = fn()
+            print("OK   %s%s" % (name, "" if extra is None else "  %s" % (extra,)), flush=True)
+        except Exception as e:  # noqa: BLE001
+            failed += 1
+            print("FAIL %s: %s: %s" % (name, type(e).__name__, e), flush=True)
+    tpt.ShutdownTest()
+    stats = (C.c_longlong * 2)()
+    C.CDLL(os.environ["TPT_LIB"]).hostemu_stats(stats)
+    h = (C.c_longlong * 3)()
+    C.CDLL(os.environ["TPT_LIB"]).hostemu_helper_stats(h)
+    print("operations executed %d, hipFree calls %d, policy %s; helper grids: %d found their launch closed, %d the pool dry, %d took chunks"
+          % (stats[0], stats[1], os.environ.get("HOSTEMU_POLICY", "eager"), h[0], h[1], h[2]))
+    sys.exit(1 if failed else 0)

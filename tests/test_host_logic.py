@@ -1,0 +1,105 @@
+"""The HOST side of the library on the CPU: csrc/tpt_host.cpp -- unmodified -- compiled against tests/hostemu (a stand-in for the HIP
+runtime calls it makes: streams as queues of closures, events, "device" memory with poison-on-free; the kernels' launch functions
+restated on the lane headers) and driven through the ctypes mirror by tests/hostemu_driver.py, whose scenarios are the GPU suite's at CPU
+sizes: streaming and synchronous callers, look-ahead, DrawTest on host pointers in both seed modes, batches, stream batching, animated
+scenes, resizes, the sharded loopback exchange, scene / camera changes in a stream.  Every image and ray count is held against the oracle.
+
+Each scenario list runs under several schedules of the emulated device: eager (everything executes when it is enqueued), lazy (only
+what a wait needs, at the latest legal moment -- a buffer freed, re-armed or overwritten while queued work still uses it turns into wrong
+pixels or a hard stop), and seeded random interleavings.  The -DTPT_TAIL_HELPERS=1 experiment (csrc/tpt_device.h) runs too, on a
+"device" of two CUs so that its helper grids are actually launched; the emulated launch checks the state of the counter block it meets.
+
+TEST INFRASTRUCTURE: nothing here is reachable from the product (toypathtracer_amd/ has no CPU path and never loads these libraries)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from oracle_lib import ROOT
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BUILD = os.path.join(HERE, "_build")
+SOURCES = [os.path.join(ROOT, "toypathtracer_amd", "csrc", "tpt_host.cpp"), os.path.join(HERE, "hostemu", "hostemu_kernels.cpp"),
+           os.path.join(HERE, "hostemu", "hip_shim.cpp")]
+
+
+def build(name, extra, host_source=None):
+    out = os.path.join(BUILD, name)
+    os.makedirs(BUILD, exist_ok=True)
+    deps = SOURCES + [os.path.join(ROOT, "toypathtracer_amd", "csrc", h) for h in os.listdir(os.path.join(ROOT, "toypathtracer_amd", "csrc")) if h.endswith(".h")]
+    deps += [os.path.join(HERE, "hostemu", "hip", "hip_runtime.h"), os.path.join(HERE, "hostemu", "rccl", "rccl.h")]
+    if os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(d) for d in deps):
+        return out
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wno-unknown-pragmas",
+           "-include", "hip/hip_runtime.h", "-I", os.path.join(HERE, "hostemu"), "-I", os.path.join(ROOT, "toypathtracer_amd", "csrc")]
+    subprocess.check_call(cmd + extra + ([host_source] + SOURCES[1:] if host_source else SOURCES) + ["-o", out, "-ldl", "-lpthread"])
+    return out
+
+
+@pytest.fixture(scope="module")
+def runs():
+    """all schedules at once, one process each (a run is ~30 s of oracle and emulation)"""
+    plain = build("libtpt_hostemu.so", [])
+    helpers = build("libtpt_hostemu_helpers.so", ["-DTPT_TAIL_HELPERS=1"])
+    jobs = {}
+    # A mutant of the host code for the harness's own sanity: the stream wait that keeps a colour slot's next trace launch behind
+    # the slot's previous blend is taken out (the host's pacing loop, which normally hides such a slip, is off in that run).
+    src = open(SOURCES[0]).read()
+    wait = "        HIPCHK(hipStreamWaitEvent(ts, g.evResolve[slot], 0)); // colour buffer free again"
+    assert src.count(wait) == 1, "the mutation site moved: update tests/test_host_logic.py"
+    mutant_src = os.path.join(BUILD, "tpt_host_mutant.cpp")
+    os.makedirs(BUILD, exist_ok=True)
+    text = src.replace(wait, "        // MUTANT (tests/test_host_logic.py): no wait for the slot's previous blend").replace('#include "../../include/', '#include "%s/include/' % ROOT)
+    if not os.path.exists(mutant_src) or open(mutant_src).read() != text:
+        open(mutant_src, "w").write(text)
+    mutant = build("libtpt_hostemu_mutant.so", [], host_source=mutant_src)
+    for key, lib, policy, cus, extra_env, args in [
+            ("eager", plain, "eager", None, {}, []), ("lazy", plain, "lazy", None, {}, []), ("random", plain, "random:1", None, {}, []),
+            ("lazy, no host pacing", plain, "lazy", None, {"TPT_HOST_PACE": "0"}, []),
+            ("helpers lazy", helpers, "lazy", "2", {}, []), ("helpers random", helpers, "random:2", "2", {}, []),
+            ("mutant", mutant, "lazy", None, {"TPT_HOST_PACE": "0"}, ["streaming 44"])]:
+        env = dict(os.environ, TPT_LIB=lib, HOSTEMU_POLICY=policy, **extra_env)
+        env.pop("TPT_LIB_DIR", None)
+        if cus:
+            env["HOSTEMU_CUS"] = cus
+        jobs[key] = subprocess.Popen([sys.executable, os.path.join(HERE, "hostemu_driver.py")] + args, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    out = {}
+    for key, p in jobs.items():
+        text = p.communicate(timeout=900)[0].decode()
+        out[key] = (p.returncode, text)
+    return out
+
+
+@pytest.mark.parametrize("schedule", ["eager", "lazy", "random", "lazy, no host pacing"])
+def test_host_logic_against_the_oracle(runs, schedule):
+    rc, text = runs[schedule]
+    lines = [ln for ln in text.splitlines() if ln.startswith(("OK", "FAIL"))]
+    assert rc == 0 and len(lines) >= 20 and all(ln.startswith("OK") for ln in lines), text[-3000:]
+    assert "synchronous device caller  " in text  # (look-ahead hits reported)
+
+
+@pytest.mark.parametrize("schedule", ["helpers lazy", "helpers random"])
+def test_tail_helper_build_against_the_oracle(runs, schedule):
+    rc, text = runs[schedule]
+    lines = [ln for ln in text.splitlines() if ln.startswith(("OK", "FAIL"))]
+    assert rc == 0 and len(lines) >= 20 and all(ln.startswith("OK") for ln in lines), text[-3000:]
+    import re
+    m = re.search(r"helper grids: (\d+) found their launch closed, (\d+) the pool dry, (\d+) took chunks", text)
+    assert m and int(m.group(1)) + int(m.group(3)) > 0, "no helper grid was launched: the scenario no longer exercises the experiment"
+
+
+def test_the_harness_catches_a_missing_stream_wait(runs):
+    """the mutant above renders wrong pixels under the lazy schedule as soon as colour slots are reused"""
+    rc, text = runs["mutant"]
+    assert rc != 0 and "FAIL streaming 44 frames" in text and "words differ" in text, text[-2000:]
+
+
+def test_the_emulation_is_test_infrastructure_only():
+    """nothing under toypathtracer_amd/, include/, examples/ or bench.py names the emulation"""
+    for base, _, files in os.walk(ROOT):
+        if any(part in base for part in (os.sep + "tests", os.sep + ".git", os.sep + "profiles", os.sep + "gpurun_out", os.sep + "tools")):
+            continue
+        for f in files:
+            if f.endswith((".py", ".cpp", ".h", ".hip", ".sh")):
+                assert "hostemu" not in open(os.path.join(base, f), errors="ignore").read(), os.path.join(base, f)

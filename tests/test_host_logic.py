@@ -95,6 +95,34 @@ def test_the_harness_catches_a_missing_stream_wait(runs):
     assert rc != 0 and "FAIL streaming 44 frames" in text and "words differ" in text, text[-2000:]
 
 
+@pytest.mark.parametrize("n", [2, 3, 8])
+def test_the_librarys_own_multi_gpu_path_with_n_processes(n, tmp_path):
+    """tptCommInit / tptDrawSharded / tptDrawShardedBatch / tptShardedFinish with MORE THAN ONE rank: one process per rank on the
+    emulation build, tests/hostemu/fake_rccl.cpp answering the library's dlopen of librccl.so.1 (ranks meet in a directory, ncclGather
+    = rccl.h's semantics as a unit of work on the emulated stream).  72 x 52 pixels in stripes of 8 rows: 6.5 stripes, dealt unevenly,
+    the last one partial, and with 8 ranks one rank owns nothing.  Rank 0 holds the assembled image and the sum of the ranks' ray
+    counters -- which ride in the gathered tiles -- against the oracle's 1-GPU render, byte for byte; every rank runs under a different
+    random schedule.  (What stays untested without a multi-GPU box is RCCL and xGMI themselves, not this code.)"""
+    lib = build("libtpt_hostemu.so", [])
+    fake_dir = os.path.join(BUILD, "fakerccl")
+    os.makedirs(fake_dir, exist_ok=True)
+    fake = os.path.join(fake_dir, "librccl.so.1")
+    src = os.path.join(HERE, "hostemu", "fake_rccl.cpp")
+    if not os.path.exists(fake) or os.path.getmtime(fake) < os.path.getmtime(src):
+        subprocess.check_call(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-include", "hip/hip_runtime.h", "-I", os.path.join(HERE, "hostemu"), src, "-o", fake, "-ldl"])
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, TPT_LIB=lib, FAKE_RCCL_DIR=str(tmp_path), HOSTEMU_POLICY="random:%d" % (r + 1) if r else "lazy",
+                   LD_LIBRARY_PATH=fake_dir + os.pathsep + os.environ.get("LD_LIBRARY_PATH", ""))
+        env.pop("TPT_LIB_DIR", None)
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "hostemu_rank.py"), str(r), str(n), str(tmp_path)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    for r, (p, text) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and ("OK rank %d of %d" % (r, n)) in text, "rank %d:\n%s" % (r, text[-2000:])
+    assert "equal the oracle's" in outs[0]
+
+
 def test_the_emulation_is_test_infrastructure_only():
     """nothing under toypathtracer_amd/, include/, examples/ or bench.py names the emulation"""
     for base, _, files in os.walk(ROOT):

@@ -254,6 +254,71 @@ def custom_scene_and_camera():
     same(tile, want, "scene and camera change in a stream")
 
 
+def display_counter_and_mirror():
+    """tptDisplayRGBA8 (Cpp/Emscripten/main.cpp:63-79), a caller-owned ray counter, the tile mirror with its counter snapshot"""
+    reset()
+    tile = np.zeros((H, W, 4), np.float32)
+    mirror = np.zeros((H, W, 4), np.float32)
+    counter = np.zeros(1, np.int64)
+    snapshot = np.zeros(2, np.int64)
+    tpt.set_ray_counter(ptr(counter))
+    tpt.set_stream_batching(0)
+    total, want, _ = oracle_frames(o, W, H, SPP, 5, seed_mode=SEED_PER_PIXEL)
+    for f in range(5):
+        tpt.UpdateTest(0.0, f, W, H, FLAG_PROGRESSIVE)
+        tpt.set_tile_mirror(ptr(mirror), ptr(snapshot))
+        tpt.draw_device(0.0, f, W, H, ptr(tile), FLAG_PROGRESSIVE)
+    rgba = np.zeros((H, W, 4), np.uint8)
+    tpt.display_rgba8(ptr(tile), W, H, ptr(rgba))
+    tpt.synchronize()
+    same(tile, want, "tile")
+    same(mirror, want, "mirror of the tile")
+    assert counter[0] == total and snapshot[0] == total, (counter[0], snapshot[0], total)
+    ref = np.empty((H, W, 4), np.uint8)
+    ref[..., :3] = np.minimum(np.sqrt(want[::-1, :, :3]) * np.float32(255), np.float32(255.0)).astype(np.uint8)
+    ref[..., 3] = 255
+    assert np.array_equal(rgba, ref)
+    tpt.set_tile_mirror(0)
+    tpt.set_ray_counter(0)
+
+
+def errors_and_reinitialisation():
+    """bad arguments fail with a message and change nothing; draw before update fails; shutdown + initialise starts clean"""
+    reset()
+    tile = np.zeros((H, W, 4), np.float32)
+    for bad in (lambda: tpt.draw_device(0.0, 0, 0, H, ptr(tile), FLAG_PROGRESSIVE), lambda: tpt.draw_device(0.0, 0, W, H, 0, FLAG_PROGRESSIVE),
+                lambda: tpt.set_samples_per_pixel(0), lambda: tpt.set_kernel_variant(7, 3, -1), lambda: tpt.draw_device_batch(0.0, 0, 0, W, H, ptr(tile), FLAG_PROGRESSIVE)):
+        try:
+            bad()
+        except tpt.TptError:
+            continue
+        raise AssertionError("a bad call was accepted")
+    tpt.ShutdownTest()
+    tpt.InitializeTest()
+    tpt.set_samples_per_pixel(SPP)
+    try:
+        tpt.draw_device(0.0, 0, W, H, ptr(tile), FLAG_PROGRESSIVE)
+        raise AssertionError("draw before update was accepted")
+    except tpt.TptError:
+        pass
+    streaming(frames=3)
+
+
+def row_serial_streaming(frames=4, w=24, h=12):
+    """the reference's own seed mode through the device-tile path, one launch per frame (the lane-refill kernel, one lane per row)"""
+    reset()
+    tpt.set_seed_mode(SEED_ROW_SERIAL)
+    tile = np.zeros((h, w, 4), np.float32)
+    r0 = tpt.ray_counter_read()
+    for f in range(frames):
+        tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+        tpt.draw_device(0.0, f, w, h, ptr(tile), FLAG_PROGRESSIVE)
+    tpt.synchronize()
+    total, want, _ = oracle_frames(o, w, h, SPP, frames, seed_mode=SEED_ROW_SERIAL)
+    same(tile, want, "row-serial seeds, streaming")
+    assert tpt.ray_counter_read() - r0 == total
+
+
 SCENARIOS = [
     ("streaming", lambda: streaming()),
     ("streaming, one launch per frame", lambda: streaming(frames=20, batching=False)),
@@ -275,6 +340,9 @@ SCENARIOS = [
     ("sharded loopback n=4", lambda: sharded_loopback(4)),
     ("sharded batches", sharded_batches),
     ("custom scene and camera", custom_scene_and_camera),
+    ("display, caller's ray counter, tile mirror", display_counter_and_mirror),
+    ("reference seed mode, streaming", row_serial_streaming),
+    ("errors and re-initialisation", errors_and_reinitialisation),
 ]
 
 if __name__ == "__main__":

@@ -319,6 +319,75 @@ def row_serial_streaming(frames=4, w=24, h=12):
     assert tpt.ray_counter_read() - r0 == total
 
 
+def fuzz(seed, episodes=24):
+    """A seeded random walk over the API: every episode picks a frame shape, sample count, seed mode, kernel variant, pipeline depth,
+    look-ahead, stream batching, a calling pattern (stream, synchronise every frame, DrawTest on a host pointer, batches) and a number of
+    frames, renders them from frame 0 into a fresh buffer WITHOUT re-initialising the library in between -- whatever the previous
+    episode left in flight, traced ahead, batched or allocated is the next one's starting state -- and holds image and rays against the oracle."""
+    rng = np.random.default_rng(seed)
+    tpt.set_scene()
+    tpt.set_camera()
+    s, m = o.default_scene()
+    log = []
+    for ep in range(episodes):
+        w, h = [(24, 12), (32, 24), (40, 40), (64, 40), (72, 52)][rng.integers(0, 5)]
+        spp = int(rng.integers(1, 4))
+        seed_mode = SEED_ROW_SERIAL if rng.random() < 0.25 else SEED_PER_PIXEL
+        pattern = ["stream", "sync", "drawtest", "batches"][rng.integers(0, 4)]
+        frames = int(rng.integers(1, 13))
+        if seed_mode == SEED_ROW_SERIAL and pattern == "drawtest":
+            frames = int(rng.integers(1, 40))
+        persistent = 3 if rng.random() < 0.8 else 1
+        if pattern == "batches" and seed_mode == SEED_PER_PIXEL:
+            persistent = 3  # (per-pixel batches need the path-queue kernel: anything else is refused, by design)
+        overlap = int([16, 16, 8, 2, 1][rng.integers(0, 5)])
+        look = int(rng.integers(0, 4))
+        sb = int(rng.random() < 0.7)
+        log.append((ep, w, h, spp, seed_mode, pattern, frames, persistent, overlap, look, sb))
+        tpt.set_samples_per_pixel(spp)
+        tpt.set_seed_mode(seed_mode)
+        tpt.set_kernel_variant(0, persistent, -1)
+        tpt.set_frame_overlap(overlap)
+        tpt.set_host_lookahead(look)
+        tpt.set_stream_batching(sb)
+        buf = np.zeros((h, w, 4), np.float32)
+        cam = o.default_camera(w, h)
+        want = np.zeros((h, w, 4), np.float32)
+        per_frame = [o.render(s, m, cam, w, h, spp, f, FLAG_PROGRESSIVE, backbuffer=want, seed_mode=seed_mode)[0] for f in range(frames)]
+        r0 = tpt.ray_counter_read()
+        try:
+            if pattern == "drawtest":
+                for f in range(frames):
+                    tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+                    rays = tpt.DrawTest(0.0, f, w, h, buf, FLAG_PROGRESSIVE)
+                    assert rays == per_frame[f], ("rays of frame", f, rays, per_frame[f])
+            elif pattern == "batches":
+                f = 0
+                while f < frames:
+                    k = int(min(frames - f, rng.integers(1, 6)))
+                    tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+                    tpt.draw_device_batch(0.0, f, k, w, h, ptr(buf), FLAG_PROGRESSIVE)
+                    f += k
+                tpt.synchronize()
+            else:
+                for f in range(frames):
+                    tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+                    tpt.draw_device(0.0, f, w, h, ptr(buf), FLAG_PROGRESSIVE)
+                    if pattern == "sync":
+                        tpt.synchronize()
+                tpt.synchronize()
+            same(buf, want, "image")
+            total = tpt.ray_counter_read() - r0
+            assert total == sum(per_frame), ("ray total", total, sum(per_frame))
+        except Exception as e:  # noqa: BLE001
+            try:
+                tpt.synchronize()  # (nothing may stay queued on a buffer that is about to go away)
+            except Exception:  # noqa: BLE001
+                pass
+            raise AssertionError("fuzz seed %d, episode %s: %s\n  history: %s" % (seed, log[-1], e, log[-4:])) from None
+    reset()
+
+
 SCENARIOS = [
     ("streaming", lambda: streaming()),
     ("streaming, one launch per frame", lambda: streaming(frames=20, batching=False)),
@@ -347,6 +416,10 @@ SCENARIOS = [
 
 if __name__ == "__main__":
     only = sys.argv[1:]
+    for a in only:  # "fuzz:<seed>[:episodes]" adds a random walk
+        if a.startswith("fuzz:"):
+            parts = a.split(":")
+            SCENARIOS.append((a, (lambda sd, n: (lambda: fuzz(sd, n)))(int(parts[1]), int(parts[2]) if len(parts) > 2 else 24)))
     tpt.InitializeTest()
     failed = 0
     for name, fn in SCENARIOS:

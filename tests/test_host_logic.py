@@ -58,6 +58,7 @@ def runs():
             ("eager", plain, "eager", None, {}, []), ("lazy", plain, "lazy", None, {}, []), ("random", plain, "random:1", None, {}, []),
             ("lazy, no host pacing", plain, "lazy", None, {"TPT_HOST_PACE": "0"}, []),
             ("helpers lazy", helpers, "lazy", "2", {}, []), ("helpers random", helpers, "random:2", "2", {}, []),
+            ("fuzz", plain, "random:7", None, {"TPT_HOST_PACE": "0"}, ["fuzz:7:30"]), ("fuzz helpers", helpers, "lazy", "2", {}, ["fuzz:5:30"]),
             ("mutant", mutant, "lazy", None, {"TPT_HOST_PACE": "0"}, ["streaming 44"])]:
         env = dict(os.environ, TPT_LIB=lib, HOSTEMU_POLICY=policy, **extra_env)
         env.pop("TPT_LIB_DIR", None)
@@ -87,6 +88,14 @@ def test_tail_helper_build_against_the_oracle(runs, schedule):
     import re
     m = re.search(r"helper grids: (\d+) found their launch closed, (\d+) the pool dry, (\d+) took chunks", text)
     assert m and int(m.group(1)) + int(m.group(3)) > 0, "no helper grid was launched: the scenario no longer exercises the experiment"
+
+
+@pytest.mark.parametrize("walk", ["fuzz", "fuzz helpers"])
+def test_random_walk_over_the_api(runs, walk):
+    """30 episodes of random frame shapes, sample counts, seed modes, kernel variants, pipeline depths, look-ahead, stream batching and
+    calling patterns without re-initialising in between (tests/hostemu_driver.py: fuzz); 70 more seeds were run when this was written."""
+    rc, text = runs[walk]
+    assert rc == 0 and "OK   fuzz:" in text, text[-3000:]
 
 
 def test_the_harness_catches_a_missing_stream_wait(runs):

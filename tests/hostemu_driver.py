@@ -333,13 +333,23 @@ def fuzz(seed, episodes=24):
         w, h = [(24, 12), (32, 24), (40, 40), (64, 40), (72, 52)][rng.integers(0, 5)]
         spp = int(rng.integers(1, 4))
         seed_mode = SEED_ROW_SERIAL if rng.random() < 0.25 else SEED_PER_PIXEL
-        pattern = ["stream", "sync", "drawtest", "batches"][rng.integers(0, 4)]
+        pattern = ["stream", "sync", "drawtest", "batches", "sharded"][rng.integers(0, 5)]
         frames = int(rng.integers(1, 13))
         if seed_mode == SEED_ROW_SERIAL and pattern == "drawtest":
             frames = int(rng.integers(1, 40))
         persistent = 3 if rng.random() < 0.8 else 1
         if pattern == "batches" and seed_mode == SEED_PER_PIXEL:
             persistent = 3  # (per-pixel batches need the path-queue kernel: anything else is refused, by design)
+        if pattern == "sharded":
+            seed_mode, persistent = SEED_PER_PIXEL, 3
+        if rng.random() < 0.2:  # another scene (300 spheres: the grouped traversal), or back to the built-in one
+            if rng.random() < 0.5:
+                from toypathtracer_amd.scenes import stress_scene
+                s, m = stress_scene(300, int(rng.integers(1, 30)))
+                tpt.set_scene(s, m)
+            else:
+                s, m = o.default_scene()
+                tpt.set_scene()
         overlap = int([16, 16, 8, 2, 1][rng.integers(0, 5)])
         look = int(rng.integers(0, 4))
         sb = int(rng.random() < 0.7)
@@ -361,6 +371,26 @@ def fuzz(seed, episodes=24):
                     tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
                     rays = tpt.DrawTest(0.0, f, w, h, buf, FLAG_PROGRESSIVE)
                     assert rays == per_frame[f], ("rays of frame", f, rays, per_frame[f])
+            elif pattern == "sharded":
+                n, stripe = int(rng.integers(2, 5)), int([4, 8][rng.integers(0, 2)])
+                tpt.comm_init_loopback(n, stripe)
+                try:
+                    f = 0
+                    while f < frames:
+                        k = int(min(frames - f, rng.integers(1, 4)))
+                        tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+                        if k == 1:
+                            tpt.draw_sharded(0.0, f, w, h, ptr(buf), FLAG_PROGRESSIVE)
+                        else:
+                            tpt.draw_sharded_batch(0.0, f, k, w, h, ptr(buf), FLAG_PROGRESSIVE)
+                        f += k
+                    tpt.sharded_finish()
+                finally:
+                    tpt.comm_destroy()
+                mine = (np.arange(h) // stripe) % n == 0
+                assert not buf[~mine].any(), "rows of other ranks were written"
+                buf[~mine] = want[~mine]  # (a loopback communicator delivers rank 0's stripes only)
+                r0 = None
             elif pattern == "batches":
                 f = 0
                 while f < frames:
@@ -377,8 +407,9 @@ def fuzz(seed, episodes=24):
                         tpt.synchronize()
                 tpt.synchronize()
             same(buf, want, "image")
-            total = tpt.ray_counter_read() - r0
-            assert total == sum(per_frame), ("ray total", total, sum(per_frame))
+            if r0 is not None:
+                total = tpt.ray_counter_read() - r0
+                assert total == sum(per_frame), ("ray total", total, sum(per_frame))
         except Exception as e:  # noqa: BLE001
             try:
                 tpt.synchronize()  # (nothing may stay queued on a buffer that is about to go away)

@@ -93,7 +93,8 @@ def test_tail_helper_build_against_the_oracle(runs, schedule):
 @pytest.mark.parametrize("walk", ["fuzz", "fuzz helpers"])
 def test_random_walk_over_the_api(runs, walk):
     """30 episodes of random frame shapes, sample counts, seed modes, kernel variants, pipeline depths, look-ahead, stream batching and
-    calling patterns without re-initialising in between (tests/hostemu_driver.py: fuzz); 70 more seeds were run when this was written."""
+    calling patterns (the sharded loopback and scene changes among them) without re-initialising in between (tests/hostemu_driver.py: fuzz);
+    105 more seeds were run by hand when this was written."""
     rc, text = runs[walk]
     assert rc == 0 and "OK   fuzz:" in text, text[-3000:]
 

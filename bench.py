@@ -1,9 +1,10 @@
 #!/usr/bin/env python
 """bench.py -- Mray/s of the Trace/HitWorld/Scatter hot path on MI355X (BASELINE.json's metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c2|c3|c5]     (N > 1: launches its N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W                                    (the same ranks under a launcher)
+    multi-GPU configs: --gpus 8 --workload c3 (BASELINE configs[3]), --gpus 8 --workload c5 (configs[4])
 
 A step = UpdateTest + DrawTest of ONE frame of the workload (default: BASELINE.json configs[1],
 1280x720, 4 spp, built-in 46-sphere scene, progressive accumulation on), with the accumulation
@@ -242,6 +243,37 @@ def row_serial_batched_rate(api, torch, width, height, per_launch=32, launches=8
     return dt / (launches * per_launch) * 1e3, rays / dt / 1e6
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: this command once per GPU of this node, with the environment
+    torch.distributed.run would give each rank (RANK / LOCAL_RANK / WORLD_SIZE, rendezvous on 127.0.0.1 at a free port).
+    Rank 0 prints the JSON line.  A rank that fails takes the others down; -> the first non-zero exit code."""
+    import socket
+    import subprocess
+    import time as _time
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1"))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    while procs:
+        for p in list(procs):
+            code = p.poll()
+            if code is None:
+                continue
+            procs.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in procs:  # the others would wait for it in a collective for ever
+                    q.terminate()
+        _time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -279,15 +311,19 @@ def main():
                          "-1 = as many as frames may be in flight; reported as config.untimed_priming_frames")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # typed the way the driver types its 1-GPU run (`python3 bench.py --gpus N ...`): launch the ranks ourselves
+        sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+        args.gpus = world  # (the launcher's world size is what runs)
+    who = "bench.py rank %d of %d" % (rank, world)
     if not torch.cuda.is_available():
-        sys.exit("bench.py needs a GPU (the product has no CPU path)")
+        sys.exit("%s: needs a GPU (the product has no CPU path)" % who)
+    if torch.cuda.device_count() < world:
+        sys.exit("%s: %d GPUs needed, %d visible" % (who, world, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     os.environ.setdefault("TPT_DEVICE", str(local_rank))

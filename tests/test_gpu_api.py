@@ -390,21 +390,24 @@ def test_cxx_host_shards_over_two_gpus(oracle, tmp_path):
 
 
 def test_bench_runs_on_two_ranks_over_rccl(tmp_path):
-    """bench.py --gpus 2 through torch.distributed.run (backend nccl == RCCL): the path the driver's scaling run takes.
-    Skipped on a 1-GPU box."""
+    """bench.py --gpus 2, both spellings: bare (bench.py starts its two ranks itself, the way the driver types its 1-GPU run) and
+    under torch.distributed.run (backend nccl == RCCL: the path the driver's scaling run takes).  Skipped on a 1-GPU box."""
     import json
     import sys
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs 2 GPUs")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.check_output([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                                   "127.0.0.1", "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8",
-                                   "--warmup", "4", "--no-cpu-baseline"], stderr=subprocess.DEVNULL, env=env, timeout=600).decode()
-    line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
-    assert line["n_gpus"] == 2 and line["value"] > 1000
-    assert line["exchange"] == "cabi" and line["rccl_ranks"] == 2  # the driver's command times the C-ABI exchange
-    assert line["parity_checked"] and line["parity_ok"]
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "8", "--warmup", "4", "--no-cpu-baseline"]
+    for launcher in ([sys.executable], [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                        "--master-port", "29517"]):
+        out = subprocess.check_output(launcher + tail, stderr=subprocess.DEVNULL, env=env, timeout=600).decode()
+        line = json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+        assert line["n_gpus"] == 2 and line["value"] > 1000
+        assert line["exchange"] == "cabi" and line["rccl_ranks"] == 2  # the driver's command times the C-ABI exchange
+        assert line["parity_checked"] and line["parity_ok"]
 
 
 def test_bench_exchanges_agree_at_world_size_one():

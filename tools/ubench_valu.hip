@@ -11,7 +11,8 @@ template <int MODE>
 __global__ void __launch_bounds__(256) k(float* out, int iters)
 {
     float a0 = threadIdx.x * 1e-3f + 1.0f, a1 = a0 + 1, a2 = a0 + 2, a3 = a0 + 3, a4 = a0 + 4, a5 = a0 + 5, a6 = a0 + 6, a7 = a0 + 7;
-    float m = 1.0000001f;
+    float m = 1.0000001f, m2 = 0.9999999f;
+    unsigned long long mask = 0x5555555555555555ull;
     v2f p0 = {a0, a1}, p1 = {a2, a3}, p2 = {a4, a5}, p3 = {a6, a7}, p4 = {a1, a2}, p5 = {a3, a4}, p6 = {a5, a6}, p7 = {a7, a0};
     v2f pm = {m, m};
     double d0 = a0, d1 = a1, d2 = a2, d3 = a3, d4 = a4, d5 = a5, d6 = a6, d7 = a7, dm = 1.0000001;
@@ -53,6 +54,52 @@ __global__ void __launch_bounds__(256) k(float* out, int iters)
             REP8(asm volatile("v_mul_f32 %0, %0, %8\n v_add_f32 %1, %1, %0\n v_mul_f32 %2, %2, %8\n v_add_f32 %3, %3, %2\n"
                               "v_mul_f32 %4, %4, %8\n v_add_f32 %5, %5, %4\n v_mul_f32 %6, %6, %8\n v_add_f32 %7, %7, %6\n"
                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));)
+        } else if (MODE == 9) { // v_mul_f32 in the 8-byte VOP3 encoding (same two sources as mode 0)
+            REP8(asm volatile("v_mul_f32_e64 %0, %0, %8\n v_mul_f32_e64 %1, %1, %8\n v_mul_f32_e64 %2, %2, %8\n v_mul_f32_e64 %3, %3, %8\n"
+                              "v_mul_f32_e64 %4, %4, %8\n v_mul_f32_e64 %5, %5, %8\n v_mul_f32_e64 %6, %6, %8\n v_mul_f32_e64 %7, %7, %8\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));)
+        } else if (MODE == 10) { // v_fmac_f32 (VOP2: dst += a * b -- three register reads in a 4-byte encoding)
+            REP8(asm volatile("v_fmac_f32_e32 %0, %8, %9\n v_fmac_f32_e32 %1, %8, %9\n v_fmac_f32_e32 %2, %8, %9\n v_fmac_f32_e32 %3, %8, %9\n"
+                              "v_fmac_f32_e32 %4, %8, %9\n v_fmac_f32_e32 %5, %8, %9\n v_fmac_f32_e32 %6, %8, %9\n v_fmac_f32_e32 %7, %8, %9\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(m2));)
+        } else if (MODE == 11) { // v_fma_f32 with three DISTINCT source registers (mode 2 reads one register twice)
+            REP8(asm volatile("v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n"
+                              "v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(m2));)
+        } else if (MODE == 12) { // v_mul_f32 with a 32-bit literal (VOP2 + literal dword: 8 bytes)
+            REP8(asm volatile("v_mul_f32_e32 %0, 0x3f800001, %0\n v_mul_f32_e32 %1, 0x3f800001, %1\n v_mul_f32_e32 %2, 0x3f800001, %2\n v_mul_f32_e32 %3, 0x3f800001, %3\n"
+                              "v_mul_f32_e32 %4, 0x3f800001, %4\n v_mul_f32_e32 %5, 0x3f800001, %5\n v_mul_f32_e32 %6, 0x3f800001, %6\n v_mul_f32_e32 %7, 0x3f800001, %7\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+        } else if (MODE == 13) { // v_cndmask_b32, VOP2 (mask in vcc)
+            REP8(asm volatile("v_cndmask_b32_e32 %0, %0, %8, vcc\n v_cndmask_b32_e32 %1, %1, %8, vcc\n v_cndmask_b32_e32 %2, %2, %8, vcc\n v_cndmask_b32_e32 %3, %3, %8, vcc\n"
+                              "v_cndmask_b32_e32 %4, %4, %8, vcc\n v_cndmask_b32_e32 %5, %5, %8, vcc\n v_cndmask_b32_e32 %6, %6, %8, vcc\n v_cndmask_b32_e32 %7, %7, %8, vcc\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m) : "vcc");)
+        } else if (MODE == 14) { // v_cndmask_b32, VOP3 (mask in an SGPR pair)
+            REP8(asm volatile("v_cndmask_b32_e64 %0, %0, %8, %9\n v_cndmask_b32_e64 %1, %1, %8, %9\n v_cndmask_b32_e64 %2, %2, %8, %9\n v_cndmask_b32_e64 %3, %3, %8, %9\n"
+                              "v_cndmask_b32_e64 %4, %4, %8, %9\n v_cndmask_b32_e64 %5, %5, %8, %9\n v_cndmask_b32_e64 %6, %6, %8, %9\n v_cndmask_b32_e64 %7, %7, %8, %9\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "s"(mask));)
+        } else if (MODE == 15) { // v_mov_b32 (VOP1)
+            REP8(asm volatile("v_mov_b32_e32 %0, %1\n v_mov_b32_e32 %1, %2\n v_mov_b32_e32 %2, %3\n v_mov_b32_e32 %3, %4\n"
+                              "v_mov_b32_e32 %4, %5\n v_mov_b32_e32 %5, %6\n v_mov_b32_e32 %6, %7\n v_mov_b32_e32 %7, %0\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+        } else if (MODE == 16) { // v_readlane_b32 (a spilled SGPR coming back) + v_writelane_b32 (one going out): pairs
+            REP8(asm volatile("v_readlane_b32 s20, %0, 3\n v_writelane_b32 %1, s20, 5\n v_readlane_b32 s21, %2, 3\n v_writelane_b32 %3, s21, 5\n"
+                              "v_readlane_b32 s22, %4, 3\n v_writelane_b32 %5, s22, 5\n v_readlane_b32 s23, %6, 3\n v_writelane_b32 %7, s23, 5\n"
+                              : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7) : : "s20", "s21", "s22", "s23");)
+        } else if (MODE == 17) { // integer VOP2 (v_xor_b32 / v_lshlrev_b32: the XorShift32 stream)
+            REP8(asm volatile("v_lshlrev_b32_e32 %1, 13, %0\n v_xor_b32_e32 %0, %0, %1\n v_lshrrev_b32_e32 %3, 17, %2\n v_xor_b32_e32 %2, %2, %3\n"
+                              "v_lshlrev_b32_e32 %5, 5, %4\n v_xor_b32_e32 %4, %4, %5\n v_lshlrev_b32_e32 %7, 13, %6\n v_xor_b32_e32 %6, %6, %7\n"
+                              : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7));)
+        } else if (MODE == 18) { // v_sub_f32 with a source modifier (|x| / -x force the VOP3 encoding)
+            REP8(asm volatile("v_mul_f32_e64 %0, %0, -%8\n v_mul_f32_e64 %1, %1, -%8\n v_mul_f32_e64 %2, %2, -%8\n v_mul_f32_e64 %3, %3, -%8\n"
+                              "v_mul_f32_e64 %4, %4, -%8\n v_mul_f32_e64 %5, %5, -%8\n v_mul_f32_e64 %6, %6, -%8\n v_mul_f32_e64 %7, %7, -%8\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));)
+        } else if (MODE == 19) { // two v_fmac_f32 against one v_pk_fma_f32 (mode 3): the same flops unpacked
+            REP8(asm volatile("v_fmac_f32_e32 %0, %8, %9\n v_fmac_f32_e32 %1, %8, %9\n v_fmac_f32_e32 %2, %8, %9\n v_fmac_f32_e32 %3, %8, %9\n"
+                              "v_fmac_f32_e32 %4, %8, %9\n v_fmac_f32_e32 %5, %8, %9\n v_fmac_f32_e32 %6, %8, %9\n v_fmac_f32_e32 %7, %8, %9\n"
+                              "v_fmac_f32_e32 %0, %9, %8\n v_fmac_f32_e32 %1, %9, %8\n v_fmac_f32_e32 %2, %9, %8\n v_fmac_f32_e32 %3, %9, %8\n"
+                              "v_fmac_f32_e32 %4, %9, %8\n v_fmac_f32_e32 %5, %9, %8\n v_fmac_f32_e32 %6, %9, %8\n v_fmac_f32_e32 %7, %9, %8\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(m2));)
         }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y +
@@ -78,7 +125,7 @@ static void run(const char* name, int wavesPerSimd, float* out)
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
-    double instrPerWave = (double)iters * 64;
+    double instrPerWave = (double)iters * (MODE == 19 ? 128 : 64);
     double waveInstr = instrPerWave * blocks * 4;
     double perSimdPerSec = waveInstr / (cus * 4) / (ms * 1e-3);
     printf("%-28s waves/SIMD %d  %8.3f ms  %7.3f G wave-instr/s/SIMD  (= %.2f cycles per wave-instr at 2.4 GHz)\n", name, wavesPerSimd, ms,
@@ -99,6 +146,18 @@ int main()
         run<6>("v_sqrt_f32", w, out);
         run<7>("v_pk_add_f32 (sgpr src)", w, out);
         run<8>("v_mul+v_add dependent", w, out);
+        // round 5: matched pairs -- is it the 8-byte encoding or the third register read that costs?
+        run<9>("v_mul_f32_e64 (VOP3, 2 src)", w, out);
+        run<18>("v_mul_f32_e64 with -src", w, out);
+        run<12>("v_mul_f32_e32 + literal", w, out);
+        run<10>("v_fmac_f32_e32 (VOP2)", w, out);
+        run<11>("v_fma_f32 3 distinct src", w, out);
+        run<19>("2x v_fmac_f32 (per pair)", w, out);
+        run<13>("v_cndmask_b32_e32 (vcc)", w, out);
+        run<14>("v_cndmask_b32_e64 (sgpr)", w, out);
+        run<15>("v_mov_b32", w, out);
+        run<16>("v_readlane+v_writelane", w, out);
+        run<17>("v_lshl/v_xor int VOP2", w, out);
     }
     return 0;
 }

@@ -102,3 +102,37 @@ def matrix_scene(oracle, n, seed=3):
         s, m = np.concatenate([s, es]), np.concatenate([m, em])
     s["invRadius"] = np.float32(1.0) / s["radius"]
     return s, m
+
+
+def describe_image_mismatch(got, want, mine=None):
+    """What is wrong with a rendered image, for an assertion message: how many pixels / rows differ from the oracle's (within the
+    rows `mine` when given), whether rows outside `mine` carry anything, a few sample values, and whether the differing pixels
+    equal the oracle's value of another row set (a frame rendered with another sharding) or are simply zero / unblended."""
+    import numpy as np
+    g, w = got[..., :3], want[..., :3]
+    bad = (g != w).any(axis=2)
+    if mine is not None:
+        inside, outside = bad & mine[:, None], got[~mine].any(axis=2)
+    else:
+        inside, outside = bad, np.zeros((0, 0), bool)
+    rows = np.nonzero(inside.any(axis=1))[0]
+    msg = ["%d pixels in %d rows differ from the oracle (rows %s...)" % (int(inside.sum()), len(rows), rows[:10].tolist())]
+    ys, xs = np.nonzero(inside)
+    for y, x in list(zip(ys, xs))[:3]:
+        msg.append("  (x %d, y %d): got %s want %s" % (x, y, g[y, x], w[y, x]))
+    if inside.any():
+        msg.append("  of the differing pixels: %d are zero, %d have every channel >= the oracle's" % (int((g[inside] == 0).all(axis=1).sum()), int((g[inside] >= w[inside]).all(axis=1).sum())))
+    if mine is not None and outside.any():
+        oy = np.nonzero(~mine)[0][np.nonzero(outside.any(axis=1))[0]]
+        sel = np.zeros_like(bad)
+        sel[~mine] = outside
+        msg.append("%d non-zero pixels OUTSIDE this rank's rows (rows %s...); %d of them equal the oracle's pixel there" % (
+            int(outside.sum()), oy[:10].tolist(), int((g[sel] == w[sel]).all(axis=1).sum())))
+    dump = os.environ.get("TPT_MISMATCH_DUMP")  # a directory (gpurun_out/...): keep the image for an analysis off the box
+    if dump:
+        os.makedirs(dump, exist_ok=True)
+        k = len(os.listdir(dump))
+        np.save(os.path.join(dump, "mismatch_%d_got.npy" % k), got)
+        np.save(os.path.join(dump, "mismatch_%d_want.npy" % k), want)
+        msg.append("(images saved as %s/mismatch_%d_*.npy)" % (dump, k))
+    return "\n".join(msg)

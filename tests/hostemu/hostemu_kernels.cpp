@@ -195,8 +195,7 @@ void runTrace(void* p)
     const TraceJob& J = *static_cast<const TraceJob*>(p);
     const KernelArgs& a = J.a;
     int firstChunk = 0;
-#if TPT_TAIL_HELPERS
-    // The tail-helper experiment (csrc/tpt_device.h).  A launch is one indivisible step here, so a helper grid either finds its
+    // The tail helpers (csrc/tpt_device.h).  A launch is one indivisible step here, so a helper grid either finds its
     // launch closed (it ran after it: nothing to do), or runs BEFORE it and takes the first half of what is left of the pool;
     // the launch itself then starts where the counter stands.  The counter block is checked hard: a helper that meets a block
     // in any other state than "re-armed, or part-consumed by helpers of the same launch" would have corrupted a frame.
@@ -216,15 +215,12 @@ void runTrace(void* p)
         if (a.work[1] != 0u || a.work[2] != 0u || (int)a.work[0] > a.numChunks) { fprintf(stderr, "hostemu: launch %u met its counter block at %u / %u / busy %u\n", a.gen, a.work[0], a.work[1], a.work[2]); abort(); }
         firstChunk = (int)a.work[0]; // (what helper grids of this launch have taken already)
     } else
-#endif
     checkCounters(a);
     a.work[0] = (unsigned)a.numChunks + 1u; // (what the counters look like while the launch runs)
     a.work[1] = 1u;
     if (J.queue) {
         traceQueueClasses(a, J.ldsScene, firstChunk, a.numChunks);
-#if TPT_TAIL_HELPERS
         if (a.gen != 0u) a.work[3] = a.gen; // the last wave closes the block before it re-arms the counters
-#endif
     } else {
         const bool groups = !J.ldsScene;
         if (J.hs == HS_SIMPLE) {

@@ -104,18 +104,50 @@ class Oracle:
                              vfov, aspect, aperture, focus)
         return cam
 
+    # Round 5: on the 256-thread hosts of the GPU boxes the checker itself was caught out -- two "parity failures" of the GPU suite had
+    # a GPU image equal to this oracle's output everywhere else and a `want` that differed at 46 of 24 000 pixels (same binary, same
+    # inputs; profiles/r05/README.md, tools/mismatch_analyse.py).  The code below is pure, so a checker that cannot be trusted once is
+    # run twice: on big hosts (or with TPT_ORACLE_REDUNDANT=1) every frame is rendered a second time with another thread count, and
+    # a disagreement is reported on stderr and settled by a third run (per-pixel majority).  TPT_ORACLE_REDUNDANT=0 switches it off.
+    redundant = os.environ.get("TPT_ORACLE_REDUNDANT", "1" if (os.cpu_count() or 1) >= 64 else "0") == "1"
+    disagreements = 0
+
     def render(self, spheres, mats, cam, w, h, spp, frame, flags=FLAG_PROGRESSIVE, seed_mode=SEED_ROW_SERIAL,
                math_mode=MATH_TPT, fold_mode=FOLD_RECURSIVE, backbuffer=None, y0=0, y1=None, threads=0,
                light_sampling=True, mitsuba_compare=False, animate_smoothing=None):
         if backbuffer is None:
             backbuffer = np.zeros((h, w, 4), np.float32)
         assert backbuffer.dtype == np.float32 and backbuffer.flags.c_contiguous and backbuffer.size == w * h * 4
-        p = Params(w, h, y0, h if y1 is None else y1, spp, frame, flags, seed_mode, math_mode, fold_mode, threads,
-                   0 if light_sampling else 1, 1 if mitsuba_compare else 0, 0 if animate_smoothing is None else 1,
-                   0.0 if animate_smoothing is None else float(animate_smoothing))
-        rays = self.lib.tpto_render(spheres.ctypes.data, mats.ctypes.data, len(spheres), cam.ctypes.data,
-                                    C.byref(p), backbuffer.ctypes.data)
-        return int(rays), backbuffer
+
+        def once(bb, nt):
+            p = Params(w, h, y0, h if y1 is None else y1, spp, frame, flags, seed_mode, math_mode, fold_mode, nt,
+                       0 if light_sampling else 1, 1 if mitsuba_compare else 0, 0 if animate_smoothing is None else 1,
+                       0.0 if animate_smoothing is None else float(animate_smoothing))
+            return int(self.lib.tpto_render(spheres.ctypes.data, mats.ctypes.data, len(spheres), cam.ctypes.data, C.byref(p), bb.ctypes.data))
+
+        if not Oracle.redundant:
+            return once(backbuffer, threads), backbuffer
+        before = backbuffer.copy()  # (the frame is blended into what the buffer holds, Test.cpp:293-295)
+        second = before.copy()
+        rays = once(backbuffer, threads)
+        rays2 = once(second, 24 if threads != 24 else 16)
+        if rays != rays2 or backbuffer.tobytes() != second.tobytes():
+            import sys
+            third = before.copy()
+            rays3 = once(third, 8)
+            a, b, c = (x.view(np.uint32) for x in (backbuffer, second, third))
+            n_ab, n_ac, n_bc = int((a != b).sum()), int((a != c).sum()), int((b != c).sum())
+            Oracle.disagreements += 1
+            msg = ("oracle_lib: THE CHECKER DISAGREES WITH ITSELF on this host (frame %d, %dx%dx%d): words differing run 1/2 %d, 1/3 %d, 2/3 %d; rays %d / %d / %d -- "
+                   "taking the per-word majority" % (frame, w, h, spp, n_ab, n_ac, n_bc, rays, rays2, rays3))
+            print(msg, file=sys.stderr, flush=True)
+            if os.environ.get("TPT_ORACLE_LOG"):  # (pytest captures stderr of passing tests: keep the evidence in a file)
+                with open(os.environ["TPT_ORACLE_LOG"], "a") as fh:
+                    fh.write(msg + "\n")
+            maj = np.where(a == b, a, np.where(a == c, a, b))  # (b == c where a is the odd one out; three different values: b)
+            backbuffer.view(np.uint32)[...] = maj
+            rays = rays if rays in (rays2, rays3) else rays2
+        return rays, backbuffer
 
     def render_frames(self, w, h, spp, frames, flags=FLAG_PROGRESSIVE, **kw):
         """Default scene + camera, frames 0..frames-1 on a zeroed buffer (the golden-vector harness)."""

@@ -476,8 +476,8 @@ def test_loopback_rank0_of_n_matches_its_rows(tpt_defaults, oracle, n):
     _, bo, _ = oracle_frames(oracle, w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
     want = np.frombuffer(bo.tobytes(), np.float32).reshape(h, w, 4)
     mine = (np.arange(h) // stripe) % n == 0
-    assert got[mine].tobytes() == want[mine].tobytes()
-    assert not got[~mine].any()
+    from common import describe_image_mismatch
+    assert got[mine].tobytes() == want[mine].tobytes() and not got[~mine].any(), describe_image_mismatch(got, want, mine)
 
 
 def test_sharded_batches_match_per_frame_exchange(tpt_defaults, oracle):
@@ -503,8 +503,8 @@ def test_sharded_batches_match_per_frame_exchange(tpt_defaults, oracle):
     _, bo, _ = oracle_frames(oracle, w, h, 4, f, seed_mode=SEED_PER_PIXEL)
     want = np.frombuffer(bo.tobytes(), np.float32).reshape(h, w, 4)
     mine = (np.arange(h) // stripe) % n == 0
-    assert got[mine].tobytes() == want[mine].tobytes()
-    assert not got[~mine].any()
+    from common import describe_image_mismatch
+    assert got[mine].tobytes() == want[mine].tobytes() and not got[~mine].any(), describe_image_mismatch(got, want, mine)
 
 
 def test_synchronous_device_caller_gets_lookahead_and_the_same_bits(tpt_defaults, oracle):
@@ -573,3 +573,43 @@ def test_default_stream_fill_is_ordered_before_the_librarys_first_touch(tpt_defa
         got = tile.clone()                   # default stream: ordered behind the library's blends, no synchronise in between
         assert got.cpu().numpy().tobytes() == bo.tobytes(), rep
         tpt.synchronize()
+
+
+@pytest.mark.gpu
+def test_side_stream_fill_is_ordered_through_tptSetStream(tpt_defaults, oracle):
+    """The other half of the ordering contract: the library orders itself against the LEGACY DEFAULT
+    stream only.  A host that fills its tile on a side stream (a non-blocking stream, or a per-thread default stream) must hand
+    that stream over with tptSetStream -- everything that touches the tile is then enqueued there -- or order it itself.
+    With the call: the late fill lands before the first blend and the image is the oracle's.  Without it the library's blends
+    overtake the fill, which then wipes them: shown here so that the documented failure mode stays a fact, not a guess."""
+    import torch
+    from common import oracle_frames
+    tpt = tpt_defaults
+    w, h, frames = 320, 200, 3
+    _, bo, _ = oracle_frames(oracle, w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
+    side = torch.cuda.Stream()  # non-blocking: not ordered against the legacy default stream, nor against the library's blocking stream
+    a = torch.randn((4096, 4096), device="cuda")
+    torch.cuda.synchronize()
+    results = {}
+    for handed_over in (True, False):
+        tile = torch.full((h, w, 4), 123.0, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        if handed_over:
+            tpt.set_stream(side.cuda_stream)
+        try:
+            with torch.cuda.stream(side):
+                b = a
+                for _ in range(40):
+                    b = (b @ b).clamp_(-1.0, 1.0)  # ~50 ms of side-stream work in front of the fill
+                tile.zero_()                       # the fill the library must not overtake
+            for f in range(frames):
+                tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+                tpt.draw_device(0.0, f, w, h, tile.data_ptr(), FLAG_PROGRESSIVE)
+            tpt.synchronize()
+            side.synchronize()
+            torch.cuda.synchronize()
+            results[handed_over] = tile.cpu().numpy().tobytes() == bo.tobytes()
+        finally:
+            tpt.set_stream(None)
+    assert results[True], "with tptSetStream the side-stream fill is ordered before the library's first blend"
+    assert not results[False], "without tptSetStream nothing orders a side-stream fill against the library (if this starts passing, the contract in INTEGRATION.md can be relaxed)"

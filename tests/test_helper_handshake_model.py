@@ -1,5 +1,5 @@
 """Exhaustive interleaving check of the hand-shake between a path-queue launch and the helper grids of the tail-helper experiment
-(-DTPT_TAIL_HELPERS, csrc/tpt_device.h; tpt_kernels.hip: the helper's prologue, the launch's last wave).  A MODEL of the protocol, not
+(csrc/tpt_device.h; tpt_kernels.hip: the helper's prologue, the launch's last wave).  A MODEL of the protocol, not
 the kernel: every shared access below is one returning atomic at the device's coherence point, in program order per actor (the kernel
 gets that order from feeding each atomic's result into the next), and the explorer runs every interleaving of those steps.
 

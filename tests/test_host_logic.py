@@ -6,8 +6,8 @@ scenes, resizes, the sharded loopback exchange, scene / camera changes in a stre
 
 Each scenario list runs under several schedules of the emulated device: eager (everything executes when it is enqueued), lazy (only
 what a wait needs, at the latest legal moment -- a buffer freed, re-armed or overwritten while queued work still uses it turns into wrong
-pixels or a hard stop), and seeded random interleavings.  The -DTPT_TAIL_HELPERS=1 experiment (csrc/tpt_device.h) runs too, on a
-"device" of two CUs so that its helper grids are actually launched; the emulated launch checks the state of the counter block it meets.
+pixels or a hard stop), and seeded random interleavings.  Two runs use a "device" of two CUs so that the tail helpers (csrc/tpt_device.h)
+are actually launched; the emulated launch checks the state of the counter block it meets.
 
 TEST INFRASTRUCTURE: nothing here is reachable from the product (toypathtracer_amd/ has no CPU path and never loads these libraries)."""
 import os
@@ -41,7 +41,7 @@ def build(name, extra, host_source=None):
 def runs():
     """all schedules at once, one process each (a run is ~30 s of oracle and emulation)"""
     plain = build("libtpt_hostemu.so", [])
-    helpers = build("libtpt_hostemu_helpers.so", ["-DTPT_TAIL_HELPERS=1"])
+    helpers = plain  # (the tail helpers are part of the library since round 5: HOSTEMU_CUS=2 makes its grids small enough to be helped)
     jobs = {}
     # A mutant of the host code for the harness's own sanity: the stream wait that keeps a colour slot's next trace launch behind
     # the slot's previous blend is taken out (the host's pacing loop, which normally hides such a slip, is off in that run).
@@ -81,13 +81,13 @@ def test_host_logic_against_the_oracle(runs, schedule):
 
 
 @pytest.mark.parametrize("schedule", ["helpers lazy", "helpers random"])
-def test_tail_helper_build_against_the_oracle(runs, schedule):
+def test_tail_helpers_against_the_oracle(runs, schedule):
     rc, text = runs[schedule]
     lines = [ln for ln in text.splitlines() if ln.startswith(("OK", "FAIL"))]
     assert rc == 0 and len(lines) >= 23 and all(ln.startswith("OK") for ln in lines), text[-3000:]
     import re
     m = re.search(r"helper grids: (\d+) found their launch closed, (\d+) the pool dry, (\d+) took chunks", text)
-    assert m and int(m.group(1)) + int(m.group(3)) > 0, "no helper grid was launched: the scenario no longer exercises the experiment"
+    assert m and int(m.group(1)) + int(m.group(3)) > 0, "no helper grid was launched: the scenario no longer exercises the tail helpers"
 
 
 @pytest.mark.parametrize("walk", ["fuzz", "fuzz helpers"])

@@ -14,8 +14,8 @@
 using namespace tpt;
 
 struct Acc {
-    long long rays = 0, matrix = 0, valu = 0, exact = 0, hits = 0, hist[12] = {}, afterPlane = 0, afterBehind = 0;
-    std::vector<unsigned char> perRayMatrix, perRayExact, perRayPlane, perRayBehind;
+    long long rays = 0, matrix = 0, valu = 0, exact = 0, hits = 0, hist[12] = {}, afterPlane = 0, afterBehind = 0, afterSelf = 0, selfKnown = 0, selfCulled = 0, selfViolations = 0;
+    std::vector<unsigned char> perRayMatrix, perRayExact, perRayPlane, perRayBehind, perRaySelf;
 };
 
 int main(int argc, char** argv)
@@ -39,13 +39,14 @@ int main(int argc, char** argv)
             Lane L;
             L.rays = 0; L.active = false;
             laneBeginPixel(L, fc, x, y, y * w + x, true);
+            int self = -1; // the sphere the ray starts on (round 5: the self cull of the path-queue kernel)
             for (;;) {
-                if (L.needCamera) laneCamera<FOLD_RECURSIVE>(L, fc);
+                if (L.needCamera) { laneCamera<FOLD_RECURSIVE>(L, fc); self = -1; }
                 const f3 o = L.orig, d = L.dir;
                 Acc& A = acc[L.kind == KIND_SHADOW ? 1 : 0];
                 const uint64_t mm = phase1MatrixHRef(sv.amatH, sv.mxR1, sv.nSpheres, o, d);
                 const f3 dk = mk3(d.x * TPT_P1_K, d.y * TPT_P1_K, d.z * TPT_P1_K);
-                int nv = 0, ne = 0, nh = 0, np = 0, nbh = 0;
+                int nv = 0, ne = 0, nh = 0, np = 0, nbh = 0, nself = 0;
                 for (int i = 0; i < sv.nSpheres; ++i) {
                     const f4 s = sv.sph4[i];
                     nv += memberFilter(s, o, dk);
@@ -63,6 +64,22 @@ int main(int argc, char** argv)
                         np += !plane;
                         nbh += !behind;
                     }
+                    if (i == self) {
+                        // the self cull: nb <= 0 (the ray leaves the sphere), not absurdly large, and the origin at most a hair inside:
+                        // then t = nb + sqrt(discr) <= tMin whatever the roundings (derivation: tpt_trace.h, selfCull)
+                        A.selfKnown++;
+                        const bool cull = nb <= 0.0f && nb >= -1000.0f && c >= 0.0005f * nb;
+                        if (cull) {
+                            A.selfCulled++;
+                            nself += ((mm >> (63 - i)) & 1ull) ? 1 : 0;
+                            if (discr > 0) {
+                                const float sq = tsqrt(discr);
+                                float t = nb - sq;
+                                if (t <= TPT_MIN_T) t = nb + sq;
+                                if (t > TPT_MIN_T) A.selfViolations++;
+                            }
+                        }
+                    }
                     if (discr > 0) {
                         ++ne;
                         const float sq = tsqrt(discr);
@@ -72,7 +89,8 @@ int main(int argc, char** argv)
                     }
                 }
                 const int nm = __builtin_popcountll(mm);
-                A.afterPlane += np; A.afterBehind += nbh;
+                A.afterPlane += np; A.afterBehind += nbh; A.afterSelf += nm - nself;
+                A.perRaySelf.push_back((unsigned char)(nm - nself));
                 A.perRayPlane.push_back((unsigned char)np); A.perRayBehind.push_back((unsigned char)nbh);
                 A.rays++; A.matrix += nm; A.valu += nv; A.exact += ne; A.hits += nh;
                 A.hist[nm < 11 ? nm : 11]++;
@@ -81,6 +99,7 @@ int main(int argc, char** argv)
                 float t;
                 const int id = hitSpheres<HS_MATRIX>(sv, o, d, TPT_MIN_T, TPT_MAX_T, t);
                 L.rays++;
+                if (L.kind == KIND_MAIN && id >= 0) self = id; // (a shadow ray's result does not move the path)
                 if (lanePost<FOLD_RECURSIVE>(L, id, t, sv, fc, stack)) break;
             }
         }
@@ -91,6 +110,15 @@ int main(int argc, char** argv)
         printf("%-22s %9lld rays: candidates per ray  matrix filter %.3f  VALU filter %.3f  |  exact discr > 0: %.3f  hit in (tMin, tMax): %.3f\n",
                names[k], A.rays, (double)A.matrix / A.rays, (double)A.valu / A.rays, (double)A.exact / A.rays, (double)A.hits / A.rays);
         printf("    candidates left after culling spheres behind the origin's plane: %.3f; behind the origin on the line: %.3f\n", (double)A.afterPlane / A.rays, (double)A.afterBehind / A.rays);
+        printf("    self cull: the start sphere is known for %.1f %% of the rays, culled for %.1f %% (violations: %lld); candidates left %.3f\n",
+               100.0 * A.selfKnown / A.rays, 100.0 * A.selfCulled / A.rays, A.selfViolations, (double)A.afterSelf / A.rays);
+        {
+            long long g2 = 0, tr = 0, trs = 0, g2s = 0;
+            for (size_t i = 0; i + 64 <= A.perRaySelf.size(); i += 64) { int mx = 0; for (int j = 0; j < 64; ++j) mx = A.perRaySelf[i + j] > mx ? A.perRaySelf[i + j] : mx; tr += mx; g2++; }
+            const size_t n2 = A.perRaySelf.size() / 64 * 64, st2 = n2 / 64;
+            for (size_t g = 0; g < st2; ++g) { int mx = 0; for (int j = 0; j < 64; ++j) { const size_t idx = g + (size_t)j * st2; mx = A.perRaySelf[idx] > mx ? A.perRaySelf[idx] : mx; } trs += mx; g2s++; }
+            if (g2) printf("    phase-2 trips per 64 rays with the self cull: coherent %.2f scattered %.2f\n", (double)tr / g2, (double)trs / g2s);
+        }
         printf("    matrix-filter candidates per ray, histogram 0..10, 11+: ");
         for (int i = 0; i < 12; ++i) printf("%.1f%% ", 100.0 * A.hist[i] / A.rays);
         printf("\n");

@@ -100,6 +100,54 @@ __global__ void __launch_bounds__(256) k(float* out, int iters)
                               "v_fmac_f32_e32 %0, %9, %8\n v_fmac_f32_e32 %1, %9, %8\n v_fmac_f32_e32 %2, %9, %8\n v_fmac_f32_e32 %3, %9, %8\n"
                               "v_fmac_f32_e32 %4, %9, %8\n v_fmac_f32_e32 %5, %9, %8\n v_fmac_f32_e32 %6, %9, %8\n v_fmac_f32_e32 %7, %9, %8\n"
                               : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(m2));)
+        } else if (MODE == 20) { // v_cndmask_b32_e32 with vcc WRITTEN by the SALU once per block (mode 13 never defines it)
+            REP8(asm volatile("s_mov_b64 vcc, %9\n v_cndmask_b32_e32 %0, %0, %8, vcc\n v_cndmask_b32_e32 %1, %1, %8, vcc\n v_cndmask_b32_e32 %2, %2, %8, vcc\n v_cndmask_b32_e32 %3, %3, %8, vcc\n"
+                              "v_cndmask_b32_e32 %4, %4, %8, vcc\n v_cndmask_b32_e32 %5, %5, %8, vcc\n v_cndmask_b32_e32 %6, %6, %8, vcc\n v_cndmask_b32_e32 %7, %7, %8, vcc\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "s"(mask) : "vcc");)
+        } else if (MODE == 21) { // v_cmp_lt_f32 -> vcc, then v_cndmask_b32_e32 on it: the pair as the compiler emits it (one pair = 2 instructions)
+            REP8(asm volatile("v_cmp_lt_f32_e32 vcc, %0, %8\n s_nop 1\n v_cndmask_b32_e32 %0, %0, %8, vcc\n v_cmp_lt_f32_e32 vcc, %1, %8\n s_nop 1\n v_cndmask_b32_e32 %1, %1, %8, vcc\n"
+                              "v_cmp_lt_f32_e32 vcc, %2, %8\n s_nop 1\n v_cndmask_b32_e32 %2, %2, %8, vcc\n v_cmp_lt_f32_e32 vcc, %3, %8\n s_nop 1\n v_cndmask_b32_e32 %3, %3, %8, vcc\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m) : "vcc");)
+        } else if (MODE == 22) { // the same pair through an SGPR pair (v_cmp_lt_f32_e64 s[20:21] / v_cndmask_b32_e64)
+            REP8(asm volatile("v_cmp_lt_f32_e64 s[20:21], %0, %8\n s_nop 1\n v_cndmask_b32_e64 %0, %0, %8, s[20:21]\n v_cmp_lt_f32_e64 s[22:23], %1, %8\n s_nop 1\n v_cndmask_b32_e64 %1, %1, %8, s[22:23]\n"
+                              "v_cmp_lt_f32_e64 s[20:21], %2, %8\n s_nop 1\n v_cndmask_b32_e64 %2, %2, %8, s[20:21]\n v_cmp_lt_f32_e64 s[22:23], %3, %8\n s_nop 1\n v_cndmask_b32_e64 %3, %3, %8, s[22:23]\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m) : "s20", "s21", "s22", "s23");)
+        } else if (MODE == 23) { // v_cndmask_b32_e32 between plain multiplies (1 in 4): is the cost of mode 13 a throughput or a stall?
+            REP8(asm volatile("v_cndmask_b32_e32 %0, %0, %8, vcc\n v_mul_f32_e32 %1, %1, %8\n v_mul_f32_e32 %2, %2, %8\n v_mul_f32_e32 %3, %3, %8\n"
+                              "v_cndmask_b32_e32 %4, %4, %8, vcc\n v_mul_f32_e32 %5, %5, %8\n v_mul_f32_e32 %6, %6, %8\n v_mul_f32_e32 %7, %7, %8\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m) : "vcc");)
+        } else if (MODE == 24) { // v_lshlrev_b32 alone (independent)
+            REP8(asm volatile("v_lshlrev_b32_e32 %0, 1, %0\n v_lshlrev_b32_e32 %1, 1, %1\n v_lshlrev_b32_e32 %2, 1, %2\n v_lshlrev_b32_e32 %3, 1, %3\n"
+                              "v_lshlrev_b32_e32 %4, 1, %4\n v_lshlrev_b32_e32 %5, 1, %5\n v_lshlrev_b32_e32 %6, 1, %6\n v_lshlrev_b32_e32 %7, 1, %7\n"
+                              : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7));)
+        } else if (MODE == 25) { // v_xor_b32 alone (independent)
+            REP8(asm volatile("v_xor_b32_e32 %0, %0, %1\n v_xor_b32_e32 %1, %1, %2\n v_xor_b32_e32 %2, %2, %3\n v_xor_b32_e32 %3, %3, %4\n"
+                              "v_xor_b32_e32 %4, %4, %5\n v_xor_b32_e32 %5, %5, %6\n v_xor_b32_e32 %6, %6, %7\n v_xor_b32_e32 %7, %7, %0\n"
+                              : "+v"(u0), "+v"(u1), "+v"(u2), "+v"(u3), "+v"(u4), "+v"(u5), "+v"(u6), "+v"(u7));)
+        } else if (MODE == 26) { // v_add_f32 / v_sub_f32 (independent)
+            REP8(asm volatile("v_add_f32_e32 %0, %0, %8\n v_sub_f32_e32 %1, %1, %8\n v_add_f32_e32 %2, %2, %8\n v_sub_f32_e32 %3, %3, %8\n"
+                              "v_add_f32_e32 %4, %4, %8\n v_sub_f32_e32 %5, %5, %8\n v_add_f32_e32 %6, %6, %8\n v_sub_f32_e32 %7, %7, %8\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m));)
+        } else if (MODE == 27) { // v_cmp_lt_f32_e32 -> vcc alone
+            REP8(asm volatile("v_cmp_lt_f32_e32 vcc, %0, %8\n v_cmp_lt_f32_e32 vcc, %1, %8\n v_cmp_lt_f32_e32 vcc, %2, %8\n v_cmp_lt_f32_e32 vcc, %3, %8\n"
+                              "v_cmp_lt_f32_e32 vcc, %4, %8\n v_cmp_lt_f32_e32 vcc, %5, %8\n v_cmp_lt_f32_e32 vcc, %6, %8\n v_cmp_lt_f32_e32 vcc, %7, %8\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m) : "vcc");)
+        } else if (MODE == 28) { // two v_cndmask_b32_e32 back to back, then two multiplies (the hit update of phase 2: t and id under one mask)
+            REP8(asm volatile("v_cndmask_b32_e32 %0, %0, %8, vcc\n v_cndmask_b32_e32 %1, %1, %8, vcc\n v_mul_f32_e32 %2, %2, %8\n v_mul_f32_e32 %3, %3, %8\n"
+                              "v_cndmask_b32_e32 %4, %4, %8, vcc\n v_cndmask_b32_e32 %5, %5, %8, vcc\n v_mul_f32_e32 %6, %6, %8\n v_mul_f32_e32 %7, %7, %8\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m) : "vcc");)
+        } else if (MODE == 29) { // the same two selects separated by a multiply each
+            REP8(asm volatile("v_cndmask_b32_e32 %0, %0, %8, vcc\n v_mul_f32_e32 %2, %2, %8\n v_cndmask_b32_e32 %1, %1, %8, vcc\n v_mul_f32_e32 %3, %3, %8\n"
+                              "v_cndmask_b32_e32 %4, %4, %8, vcc\n v_mul_f32_e32 %6, %6, %8\n v_cndmask_b32_e32 %5, %5, %8, vcc\n v_mul_f32_e32 %7, %7, %8\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m) : "vcc");)
+        } else if (MODE == 30) { // v_cmp -> vcc, TWO selects on it, one multiply (4 instructions)
+            REP8(asm volatile("v_cmp_lt_f32_e32 vcc, %0, %8\n s_nop 1\n v_cndmask_b32_e32 %0, %0, %8, vcc\n v_cndmask_b32_e32 %1, %1, %8, vcc\n v_mul_f32_e32 %2, %2, %8\n"
+                              "v_cmp_lt_f32_e32 vcc, %4, %8\n s_nop 1\n v_cndmask_b32_e32 %4, %4, %8, vcc\n v_cndmask_b32_e32 %5, %5, %8, vcc\n v_mul_f32_e32 %6, %6, %8\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m) : "vcc");)
+        } else if (MODE == 31) { // the same through v_bfi_b32 on a lane mask held in a register (one select makes the mask, v_bfi applies it)
+            REP8(asm volatile("v_cmp_lt_f32_e32 vcc, %0, %8\n s_nop 1\n v_cndmask_b32_e64 %3, 0, -1, vcc\n v_bfi_b32 %0, %3, %8, %0\n v_bfi_b32 %1, %3, %8, %1\n v_mul_f32_e32 %2, %2, %8\n"
+                              "v_cmp_lt_f32_e32 vcc, %4, %8\n s_nop 1\n v_cndmask_b32_e64 %7, 0, -1, vcc\n v_bfi_b32 %4, %7, %8, %4\n v_bfi_b32 %5, %7, %8, %5\n v_mul_f32_e32 %6, %6, %8\n"
+                              : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m) : "vcc");)
         }
     }
     out[blockIdx.x * blockDim.x + threadIdx.x] = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + p0.x + p1.y + p2.x + p3.y + p4.x + p5.y + p6.x + p7.y +
@@ -125,7 +173,7 @@ static void run(const char* name, int wavesPerSimd, float* out)
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
-    double instrPerWave = (double)iters * (MODE == 19 ? 128 : 64);
+    double instrPerWave = (double)iters * (MODE == 19 ? 128 : MODE == 31 ? 80 : 64);
     double waveInstr = instrPerWave * blocks * 4;
     double perSimdPerSec = waveInstr / (cus * 4) / (ms * 1e-3);
     printf("%-28s waves/SIMD %d  %8.3f ms  %7.3f G wave-instr/s/SIMD  (= %.2f cycles per wave-instr at 2.4 GHz)\n", name, wavesPerSimd, ms,
@@ -158,6 +206,18 @@ int main()
         run<15>("v_mov_b32", w, out);
         run<16>("v_readlane+v_writelane", w, out);
         run<17>("v_lshl/v_xor int VOP2", w, out);
+        run<24>("v_lshlrev_b32", w, out);
+        run<25>("v_xor_b32", w, out);
+        run<26>("v_add/v_sub_f32", w, out);
+        run<27>("v_cmp_lt_f32_e32 -> vcc", w, out);
+        run<20>("v_cndmask_e32, vcc by s_mov", w, out);
+        run<21>("v_cmp + v_cndmask via vcc", w, out);
+        run<22>("v_cmp + v_cndmask via sgpr", w, out);
+        run<23>("1 v_cndmask_e32 + 3 v_mul", w, out);
+        run<28>("2 v_cndmask_e32 adjacent+2mul", w, out);
+        run<29>("2 v_cndmask_e32 apart + 2 mul", w, out);
+        run<30>("cmp, 2 cndmask_e32, mul (x4)", w, out);
+        run<31>("cmp, mask, 2 bfi, mul (x5)", w, out);
     }
     return 0;
 }

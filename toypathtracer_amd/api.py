@@ -147,7 +147,11 @@ class using_hooks:
         return self
 
     def __exit__(self, *exc):
+        # the hooks context is shut down again: its 16 trace streams would otherwise share the process's hardware queues with the
+        # product library for the rest of the session (more streams than queues is a cliff: DESIGN 3.4)
         global _lib
+        if _lib is not _product:
+            _lib.tptShutdown()
         _lib = self._prev
         return False
 
@@ -157,6 +161,14 @@ def shutdown_hooks():
     if _hooks is not None and _hooks is not _product:
         _hooks.tptShutdown()
     _hooks = None
+
+
+def _hook(name):
+    """an entry point of include/tpt_test_hooks.h: only the hooks build has it"""
+    fn = getattr(load_library(), name, None)
+    if fn is None:
+        raise TptError(f"{name} is a unit-test hook (include/tpt_test_hooks.h): call it inside `with api.using_hooks():` -- the product library does not export it")
+    return fn
 
 
 def _chk(rc, where):
@@ -410,14 +422,14 @@ def pipeline_info():
 def debug_stats(reset=True):
     """profiling build only (TPT_LIB=... built with -DTPT_STATS)"""
     out = np.zeros(128, np.uint64)
-    _chk(load_library().tptDebugStats(out.ctypes.data, 1 if reset else 0), "tptDebugStats")
+    _chk(_hook("tptDebugStats")(out.ctypes.data, 1 if reset else 0), "tptDebugStats")
     return out
 
 
 def debug_chunk_order(capacity=1 << 20):
     cost = np.zeros(capacity, np.uint32)
     order = np.zeros(capacity, np.uint32)
-    n = load_library().tptDebugChunkOrder(cost.ctypes.data, order.ctypes.data, capacity)
+    n = _hook("tptDebugChunkOrder")(cost.ctypes.data, order.ctypes.data, capacity)
     if n < 0:
         raise TptError("tptDebugChunkOrder: " + _lib.tptGetLastError().decode())
     return cost[:n].copy(), order[:n].copy()
@@ -434,7 +446,7 @@ def test_math(op, a, b=None):
     if b is not None:
         b = np.ascontiguousarray(b, np.float32)
         bp = b.ctypes.data
-    _chk(load_library().tptTestMath(op, a.ctypes.data, bp, out.ctypes.data, a.size), "tptTestMath")
+    _chk(_hook("tptTestMath")(op, a.ctypes.data, bp, out.ctypes.data, a.size), "tptTestMath")
     return out
 
 
@@ -443,7 +455,7 @@ def test_math_exhaustive(op, lo=0, hi=0xFFFFFFFF):
     pattern in [lo, hi], on the device -> (mismatches, first offending inputs)"""
     bad = C.c_ulonglong(0)
     first = (C.c_uint * 8)()
-    _chk(load_library().tptTestMathExhaustive(op, lo, hi, C.byref(bad), first), "tptTestMathExhaustive")
+    _chk(_hook("tptTestMathExhaustive")(op, lo, hi, C.byref(bad), first), "tptTestMathExhaustive")
     return int(bad.value), [int(v) for v in first][: min(8, int(bad.value))]
 
 
@@ -452,7 +464,7 @@ def test_hit_spheres(rays, hit_spheres=0):
     n = rays.shape[0]
     ids = np.empty(n, np.int32)
     ts = np.empty(n, np.float32)
-    _chk(load_library().tptTestHitSpheres(hit_spheres, rays.ctypes.data, ids.ctypes.data, ts.ctypes.data, n),
+    _chk(_hook("tptTestHitSpheres")(hit_spheres, rays.ctypes.data, ids.ctypes.data, ts.ctypes.data, n),
          "tptTestHitSpheres")
     return ids, ts
 
@@ -465,7 +477,7 @@ def test_matrix_filter(rays, hits=False):
     masks = np.empty(n, np.uint64)
     ids = np.empty(n, np.int32) if hits else None
     ts = np.empty(n, np.float32) if hits else None
-    _chk(load_library().tptTestMatrixFilter(rays.ctypes.data, masks.ctypes.data, ids.ctypes.data if hits else None,
+    _chk(_hook("tptTestMatrixFilter")(rays.ctypes.data, masks.ctypes.data, ids.ctypes.data if hits else None,
                                             ts.ctypes.data if hits else None, n), "tptTestMatrixFilter")
     return (masks, ids, ts) if hits else masks
 
@@ -476,5 +488,5 @@ def test_group_filter(rays):
     rays = np.ascontiguousarray(rays, np.float32).reshape(-1, 6)
     n = rays.shape[0]
     v = [C.c_ulonglong(0) for _ in range(3)]
-    _chk(load_library().tptTestGroupFilter(rays.ctypes.data, n, C.byref(v[0]), C.byref(v[1]), C.byref(v[2])), "tptTestGroupFilter")
+    _chk(_hook("tptTestGroupFilter")(rays.ctypes.data, n, C.byref(v[0]), C.byref(v[1]), C.byref(v[2])), "tptTestGroupFilter")
     return int(v[0].value), v[1].value / n, v[2].value / n

@@ -6,24 +6,14 @@
 #define TPT_BLOCK 64         // threads per workgroup: one wave, so a finished wave frees its LDS/VGPRs at once
 #endif
 #define TPT_CHUNK_PIXELS 256 // pixels a persistent wave pulls per atomic (4 tiles of 8x8)
-// Experiment (off: the default build's code is unchanged, tools/build_variant.sh -DTPT_LATE_JOIN=1 turns it on): launches of the
-// path-queue kernel carry joinMult times the workgroups the fill rule asks for; a workgroup beyond the base grid joins only if at
-// least joinPct % of its launch's chunk pool is still unclaimed when it starts, else it exits at once.  On a machine full of
-// earlier launches the surplus arrives late and leaves; on an empty one (the start of a burst of frames) it arrives at once and
-// the launch spreads over twice the slots.  DESIGN 3.3.
-#ifndef TPT_LATE_JOIN
-#define TPT_LATE_JOIN 0
-#endif
-// Experiment 2 (off by default, -DTPT_TAIL_HELPERS=1): when the caller BLOCKS (tptSynchronize, tptTimerEnd, tptShardedFinish) while
-// path-queue launches are still in flight, every such launch gets a second grid of workgroups on a spare stream that takes chunks
-// from the same pool -- the last launches of a burst otherwise finish on a half-empty machine (the anatomy of the
-// driver's command).  The launch's counter block (KernelArgs::work) carries the hand-shake: [2] helper workgroups registered,
-// [3] serial of the last launch that CLOSED on this block.  A helper registers, then looks: closed (or a later launch's block) ->
-// it leaves without touching anything; the launch's last wave closes, then waits for the registered helpers before it re-arms the
-// counters and lets the kernel end (so "launch complete" still means "frame complete" for the blend behind it).
-#ifndef TPT_TAIL_HELPERS
-#define TPT_TAIL_HELPERS 0
-#endif
+// Tail helpers: when the caller BLOCKS (tptSynchronize, tptTimerEnd, tptShardedFinish) while path-queue launches are still in flight,
+// the newest of them get a second grid of workgroups that takes chunks from the same pool -- the last launches of a burst otherwise
+// finish on a half-empty machine (the anatomy of the driver's command: 20 frames 47.5 -> 50 k Mray/s).  The launch's counter
+// block (KernelArgs::work) carries the hand-shake: [2] helper workgroups registered, [3] serial of the last launch that CLOSED on this
+// block.  A helper registers, then looks: closed (or a later launch's block) -> it leaves without touching anything; the launch's
+// last wave closes, then waits for the registered helpers before it re-arms the counters and lets the kernel end -- so "launch
+// complete" still means "frame complete" for the ordered blend behind it.  Model-checked (tests/test_helper_handshake_model.py), run
+// under the emulated runtime's schedules (tests/test_host_logic.py); env TPT_TAIL_HELPERS=0 switches the second grids off.
 
 namespace tpt {
 
@@ -57,14 +47,9 @@ struct KernelArgs {
     unsigned* work;                  // [0] next chunk, [1] finished waves (persistent variants)
     unsigned long long* rayCounter;  // monotonic total of rays traced by this context
     int rayCounterStride;            // batched row-serial launch: frame j of the batch counts into rayCounter[j * stride] (0: one counter)
-#if TPT_TAIL_HELPERS
-    unsigned gen;                    // serial of this launch (1, 2, ...; 0: takes no helpers)
+    unsigned gen;                    // tail helpers: serial of this launch (1, 2, ...; 0: takes no helpers)
     int helperBase;                  // 0: the launch itself; > 0: its helper grid, whose workgroup b plays workgroup helperBase + b (stack columns)
     int helperPct;                   // a helper workgroup joins only while at least this % of the pool is unclaimed
-#endif
-#if TPT_LATE_JOIN
-    int joinBase, joinPct;           // workgroups [0, joinBase) always run; the others only while >= joinPct % of the pool is unclaimed (0: all run)
-#endif
 };
 
 } // namespace tpt

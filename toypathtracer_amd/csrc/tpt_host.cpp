@@ -47,8 +47,7 @@ struct Context {
     static const int kOrderTables = kMaxSlots + 2;  // rotating chunk-order tables: more than frames in flight
     bool inited = false;
     int device = 0, numCUs = 0;
-    int reservedCUs = 0;   // CUs the trace streams' CU mask leaves to the blend / assemble / copy kernels (tptInitialize)
-    int traceCUs = 0;      // numCUs - reservedCUs: what a trace launch can occupy
+    int traceCUs = 0;      // what a trace launch can occupy (= numCUs)
     std::string deviceName, err;
     hipStream_t ownStream = nullptr, stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -99,14 +98,13 @@ struct Context {
     int useMatrix = 1;   // phase 1 of HitSpheres on the matrix cores where it applies (hitSpheres variant 3 = VALU filter everywhere)
     int hs = HS_TWO_PHASE, persist = 3, ldsScene = -1; // persist 3 = path queues (falls back to 1 where they do not apply)
     int stripeRows = 0, numParts = 1, part = 0;
-    int maxBlocksPerCU = 0, chunkOverride = 0; // tuning knobs (env TPT_MAX_BLOCKS_PER_CU, TPT_CHUNK)
     int gridFill = 0;                           // env TPT_GRID_FILL: % of the resident slots all in-flight launches ask for
     int gridDiv = 0;                            // env TPT_GRID_DIV: launch resident/gridDiv workgroups per frame; 0 = adaptive
     unsigned long long oldestPending = 0;       // adaptive grid: oldest frame whose trace kernel may still be running
     int streamDepth = 1, prevInFlight = -1;     // adaptive grid: deepest pipeline the caller has built / in flight at the previous enqueue
     int framesSinceIdle = 0;                    // adaptive grid: frames enqueued since one found the pipeline empty
     int depthOverride = 0;                      // > 0: frames that share the machine, known to the caller of enqueueTrace (tptDraw)
-    int ldsStackLevels = 6;                     // recursive fold: bounce-stack levels kept in LDS (env TPT_LDS_STACK_LEVELS)
+    int ldsStackLevels = 6;                     // recursive fold, lane-refill kernel: bounce-stack levels kept in LDS
 
     float* mirror = nullptr;                    // tptSetTileMirror: second destination of the resolve kernel
     unsigned long long* mirrorCounter = nullptr;
@@ -125,7 +123,7 @@ struct Context {
     unsigned* dChunkOrder[kOrderTables] = {};
     unsigned* dChunkSnap[kMaxOverlap] = {}; // per trace stream: cost snapshot of the sort kernel
     int chunkCap = 0, chunkCount = 0; // chunkCount: numChunks the statistics belong to
-    int costOrder = 1;                // env TPT_COST_ORDER=0 disables
+    int costOrder = 1;                // expensive tiles first (lane-refill kernel)
     hipEvent_t evOrder = nullptr;     // the last sort of an order table (recorded on the stream that ran it)
     hipStream_t orderStream = nullptr;
     bool orderDone = true;
@@ -232,14 +230,8 @@ struct Context {
     bool resolveRecorded[kMaxSlots] = {};
     f4* dColour[kMaxSlots] = {};
     int hwQueues = 0, overlapCap = kMaxOverlap; // measured at tptInitialize (probeHardwareQueues)
-    int slotFactor = 2;                         // colour slots per trace stream (env TPT_SLOT_FACTOR; enqueueTrace)
-#if TPT_LATE_JOIN
-    int joinPct = 0, joinMult = 2;              // experiment (tpt_device.h): env TPT_JOIN_PCT / TPT_JOIN_MULT
-#endif
-#if TPT_TAIL_HELPERS
-    // experiment 2 (tpt_device.h): helper grids for the launches still in flight when the caller blocks
-    static const int kHelperStreams = 4;
-    hipStream_t helperStream[kHelperStreams] = {};
+    int slotFactor = 2;                         // colour slots per trace stream (enqueueTrace)
+    // tail helpers (tpt_device.h): second grids for the launches still in flight when the caller blocks
     hipEvent_t evPre[kMaxSlots] = {};           // recorded on the slot's stream right before its trace launch: what a helper grid has to wait for
     struct HelperRec {
         KernelArgs a;
@@ -249,12 +241,11 @@ struct Context {
         size_t lds = 0;
     } hrec[kMaxSlots];
     unsigned launchGen = 0;
-    int helperStride = 1;
-    int helpersOn = 1, helperPct = 3, helperMax = 8; // env TPT_TAIL_HELPERS (0: off), TPT_HELPER_PCT, TPT_HELPER_MAX (launches helped per wait)
+    int helpersOn = 1;                          // env TPT_TAIL_HELPERS=0: no second grids (the launches still close their counter blocks)
+    static const int kHelperPct = 3;            // a helper workgroup joins only while this % of its launch's pool is unclaimed
+    static const int kHelperMax = 8;            // launches helped per wait (the newest half of those in flight; sweep: profiles/r05/r05_run2.log)
     long long helperLaunches = 0;
-#endif
     int hostPace = 1;                           // env TPT_HOST_PACE=0: let the host run ahead of the pipeline (enqueueTrace)
-    int shardCapOverride = 0;                   // env TPT_SHARD_CAP: frames in flight for tiles sharded over > 2 parts (default 8)
     int shardOverlapCap = kMaxOverlap;          // 8 while the frame is sharded over more than two parts (tptSetRowShard)
     unsigned long long frameSeq = 0;
 
@@ -284,7 +275,17 @@ int fail(const std::string& what)
 int hipFail(hipError_t e, const char* what)
 {
     g.err = std::string(what) + ": " + hipGetErrorString(e);
+    (void)hipGetLastError(); // clear the runtime's sticky error: the next launch's hipGetLastError() must not report this one again
     return -2;
+}
+// A request the pipeline declines -- too large for a batch, not enough device memory, frame slots still held by frames traced
+// ahead -- as opposed to something that went wrong: callers that can retry with less (the row-serial batches of tptDraw) do so
+// on this code only and pass every other error on.
+const int kRefused = -4;
+int refuse(const std::string& what)
+{
+    g.err = what;
+    return kRefused;
 }
 #define HIPCHK(x)                                   \
     do {                                            \
@@ -500,13 +501,18 @@ int requireInit()
 // queues can carry (tptGetPipelineInfo reports both numbers).
 int probeHardwareQueues()
 {
+    auto clampCap = [] {
+        // the ordered resolve chain, the scene uploads and the caller's own streams need queues too: with fewer than
+        // ~3 queues per 2 trace streams to spare, two frames in flight is the best there is
+        g.overlapCap = g.hwQueues >= Context::kMaxOverlap ? Context::kMaxOverlap : (g.hwQueues >= 8 ? g.hwQueues - 3 : 2);
+        if (const char* e = getenv("TPT_OVERLAP_CAP")) g.overlapCap = atoi(e) < 1 ? 1 : (atoi(e) > Context::kMaxOverlap ? Context::kMaxOverlap : atoi(e));
+    };
     // env TPT_HW_QUEUES=n: the host knows how many hardware queues this process has (GPU_MAX_HW_QUEUES as the runtime read it):
     // no probe (it costs 2-4 ms at start-up and measures a busy, shared GPU pessimistically)
     if (const char* eq = getenv("TPT_HW_QUEUES")) {
         const int q = atoi(eq);
         g.hwQueues = q < 1 ? 1 : (q > Context::kMaxOverlap ? Context::kMaxOverlap : q);
-        g.overlapCap = g.hwQueues >= Context::kMaxOverlap ? Context::kMaxOverlap : (g.hwQueues >= 8 ? g.hwQueues - 3 : 2);
-        if (const char* e = getenv("TPT_OVERLAP_CAP")) g.overlapCap = atoi(e) < 1 ? 1 : (atoi(e) > Context::kMaxOverlap ? Context::kMaxOverlap : atoi(e));
+        clampCap();
         return 0;
     }
     // Long enough that enqueueing the 16 probes (~20 us each) does not matter: 2 ms of the 100 MHz wall clock.
@@ -524,52 +530,17 @@ int probeHardwareQueues()
             g.hwQueues = q < 1 ? 1 : q;
         }
     }
-    // the ordered resolve chain, the scene uploads and the caller's own streams need queues too: with fewer than
-    // ~3 queues per 2 trace streams to spare, two frames in flight is the best there is
-    g.overlapCap = g.hwQueues >= Context::kMaxOverlap ? Context::kMaxOverlap : (g.hwQueues >= 8 ? g.hwQueues - 3 : 2);
-    if (const char* e = getenv("TPT_OVERLAP_CAP")) g.overlapCap = atoi(e) < 1 ? 1 : (atoi(e) > Context::kMaxOverlap ? Context::kMaxOverlap : atoi(e));
+    clampCap();
     return 0;
 }
 
-// The trace streams.  Their kernels are persistent workgroups that fill every CU they may use for the whole frame; the short
-// kernels of the ordered chain behind them (blend, snapshot, assemble, display) then wait for a workgroup slot to come free --
-// 6 us of work took 52-137 us (profiles/r03).  With TPT_RESERVE_CUS = n > 0 the trace streams are created with a CU mask
-// (hipExtStreamCreateWithCUMask) that leaves n CUs -- spread evenly over the XCDs: bit i of the mask is CU i / 8 of XCD i % 8,
-// tools/probes/cumask_probe.hip -- to everything else; grids are sized for the CUs that remain.  (Measured in round 4: it does not
-// shorten the blend chain and costs 5-9 % of the trace rate; off by default.  Streams created this way are BLOCKING
-// streams -- the only kind hipExtStreamCreateWithCUMask makes -- so with the knob on, default-stream work of the host also orders
-// against the trace kernels.)
+// The trace streams: non-blocking (their kernels write only the library's own buffers; nothing the caller does on the default
+// stream may serialise them).  (Round 4 tried CU-masked trace streams that leave a few CUs to the blend chain,
+// hipExtStreamCreateWithCUMask: the blend did not get faster and the trace rate fell by 5-9 % -- profiles/r04/r04_run1.log,
+// tools/probes/cumask_probe.hip; removed in round 5.)
 int createTraceStreams()
 {
-    int reserve = 0;
-    if (const char* e = getenv("TPT_RESERVE_CUS")) reserve = atoi(e);
-    if (reserve < 0) reserve = 0;
-    if (reserve > g.numCUs / 2) reserve = g.numCUs / 2;
-    const int mode = getenv("TPT_RESERVE_MODE") ? atoi(getenv("TPT_RESERVE_MODE")) : 0;
-    g.reservedCUs = 0;
     g.traceCUs = g.numCUs;
-    if (reserve > 0) {
-        const int words = (g.numCUs + 31) / 32;
-        std::vector<uint32_t> mask((size_t)words, 0xffffffffu);
-        if (g.numCUs % 32) mask[(size_t)words - 1] = (1u << (g.numCUs % 32)) - 1u;
-        for (int i = 0; i < reserve; ++i) {
-            // mode 0: the lowest bits; mode 1: one bit per 32-bit word in turn; mode 2: the highest bits
-            const int bit = mode == 1 ? (i % words) * 32 + i / words : (mode == 2 ? g.numCUs - 1 - i : i);
-            mask[(size_t)bit / 32] &= ~(1u << (bit % 32));
-        }
-        bool ok = true;
-        for (int k = 0; k < Context::kMaxOverlap && ok; ++k) ok = hipExtStreamCreateWithCUMask(&g.traceStream[k], (uint32_t)words, mask.data()) == hipSuccess;
-        if (ok) {
-            g.reservedCUs = reserve;
-            g.traceCUs = g.numCUs - reserve;
-            return 0;
-        }
-        (void)hipGetLastError();
-        for (int k = 0; k < Context::kMaxOverlap; ++k) {
-            if (g.traceStream[k]) (void)hipStreamDestroy(g.traceStream[k]);
-            g.traceStream[k] = nullptr;
-        }
-    }
     for (int k = 0; k < Context::kMaxOverlap; ++k) HIPCHK(hipStreamCreateWithFlags(&g.traceStream[k], hipStreamNonBlocking));
     return 0;
 }
@@ -619,8 +590,7 @@ int tptInitialize(void)
     HIPCHK(hipEventCreate(&g.ev0));
     HIPCHK(hipEventCreate(&g.ev1));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dWork), 64 * Context::kMaxSlots));
-    // (memsets go to the stream that orders them against the first kernels: every stream of this context is
-    //  non-blocking, the legacy null stream would order nothing)
+    // (memsets go to the context's own stream, synchronised below before anything is launched)
     HIPCHK(hipMemsetAsync(g.dWork, 0, 64 * Context::kMaxSlots, g.stream));
     {
         int rc = createTraceStreams();
@@ -647,41 +617,21 @@ int tptInitialize(void)
     HIPCHK(hipMemsetAsync(g.dRaysBatch, 0, sizeof(unsigned long long) * 2 * kMaxBatch, g.stream));
     g.rsb[0].used = g.rsb[1].used = false;
     for (int k = 0; k < 4; ++k) g.ahead[k].used = false;
-    if (const char* e9 = getenv("TPT_HOST_LOOKAHEAD")) g.lookahead = atoi(e9) < 0 ? 0 : (atoi(e9) > 3 ? 3 : atoi(e9));
     HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dRaysOwn), 64));
     HIPCHK(hipMemsetAsync(g.dRaysOwn, 0, 64, g.stream));
     HIPCHK(hipStreamSynchronize(g.stream));
     g.dRays = g.dRaysOwn;
     g.lastTotal = 0;
     if (g.spheres.empty()) defaultScene(g.spheres, g.mats);
-    if (const char* e1 = getenv("TPT_MAX_BLOCKS_PER_CU")) g.maxBlocksPerCU = atoi(e1);
     if (const char* e6 = getenv("TPT_GRID_FILL")) g.gridFill = atoi(e6);
     if (const char* e7 = getenv("TPT_HOST_PACE")) g.hostPace = atoi(e7);
-    if (const char* e9 = getenv("TPT_SLOT_FACTOR")) g.slotFactor = atoi(e9) >= 2 ? 2 : 1;
-#if TPT_TAIL_HELPERS
     if (const char* eh = getenv("TPT_TAIL_HELPERS")) g.helpersOn = atoi(eh) != 0;
-    if (const char* eh = getenv("TPT_HELPER_PCT")) g.helperPct = atoi(eh) < 0 ? 0 : (atoi(eh) > 100 ? 100 : atoi(eh));
-    if (const char* eh = getenv("TPT_HELPER_MAX")) g.helperMax = atoi(eh) < 0 ? 0 : (atoi(eh) > Context::kMaxSlots ? Context::kMaxSlots : atoi(eh));
-    if (const char* eh = getenv("TPT_HELPER_STRIDE")) g.helperStride = atoi(eh) != 0; // (diagnostic: 0 keeps the plain stack stride; only with the helpers off)
-    for (int k = 0; k < Context::kMaxSlots; ++k) { // (the helper streams are created by the first wait that needs them)
+    for (int k = 0; k < Context::kMaxSlots; ++k) {
         HIPCHK(hipEventCreateWithFlags(&g.evPre[k], kOrderingEvent));
         g.hrec[k].valid = false;
     }
     g.launchGen = 0;
-#endif
-#if TPT_LATE_JOIN
-    if (const char* ej = getenv("TPT_JOIN_PCT")) g.joinPct = atoi(ej) < 0 ? 0 : (atoi(ej) > 100 ? 100 : atoi(ej));
-    if (const char* em = getenv("TPT_JOIN_MULT")) g.joinMult = atoi(em) < 1 ? 1 : (atoi(em) > 8 ? 8 : atoi(em));
-#endif
-    if (const char* e8 = getenv("TPT_SHARD_CAP")) g.shardCapOverride = atoi(e8);
     if (const char* e5 = getenv("TPT_GRID_DIV")) g.gridDiv = atoi(e5) > 0 ? atoi(e5) : 0;
-    if (const char* e2 = getenv("TPT_CHUNK")) g.chunkOverride = atoi(e2);
-    if (const char* e4 = getenv("TPT_COST_ORDER")) g.costOrder = atoi(e4);
-    if (const char* e3 = getenv("TPT_LDS_STACK_LEVELS")) {
-        g.ldsStackLevels = atoi(e3);
-        if (g.ldsStackLevels < 0) g.ldsStackLevels = 0;
-        if (g.ldsStackLevels > TPT_MAX_DEPTH) g.ldsStackLevels = TPT_MAX_DEPTH;
-    }
     g.sceneDirty = true;
     {
         int rc = probeHardwareQueues();
@@ -698,17 +648,11 @@ int tptShutdown(void)
     (void)tptCommDestroy();
     (void)hipStreamSynchronize(g.stream);
     (void)hipDeviceSynchronize();
-#if TPT_TAIL_HELPERS
-    for (int k = 0; k < Context::kHelperStreams; ++k) {
-        if (g.helperStream[k]) (void)hipStreamDestroy(g.helperStream[k]);
-        g.helperStream[k] = nullptr;
-    }
     for (int k = 0; k < Context::kMaxSlots; ++k) {
         if (g.evPre[k]) (void)hipEventDestroy(g.evPre[k]);
         g.evPre[k] = nullptr;
         g.hrec[k].valid = false;
     }
-#endif
     for (int k = 0; k < Context::kSceneSets; ++k) {
         Context::SceneSet& S = g.sets[k];
         (void)hipFree(S.dev);
@@ -758,6 +702,8 @@ int tptShutdown(void)
     g.rsb[0].used = g.rsb[1].used = false;
     g.orderDone = true; g.orderStream = nullptr; g.oldestPending = 0; g.frameSeq = 0;
     g.streamDepth = 1; g.prevInFlight = -1;
+    g.hostCaller = Context::HostCaller(); g.devCaller = Context::DeviceCaller(); // (a refusal or a streak remembered for a configuration
+    g.smallStreak = 0; g.framesSinceIdle = 0; g.configEpoch = 1;                 //  does not survive re-initialisation)
     return 0;
 }
 
@@ -930,7 +876,7 @@ int tptSetRowShard(int stripeRows, int numParts, int part)
     // Tiles of a quarter frame and less are small enough that every further launch in flight costs more queue latency
     // than its overlap buys (one-GPU emulation of rank 0, C2: 16 in flight 29 / 39 Gray/s aggregate at 4 / 8 ranks, 8 in
     // flight 92 / 99; profiles/r02/r02_run36.log).
-    const int cap = sharded && numParts > 2 ? (g.shardCapOverride > 0 ? g.shardCapOverride : 8) : Context::kMaxOverlap;
+    const int cap = sharded && numParts > 2 ? 8 : Context::kMaxOverlap;
     if (cap != g.shardOverlapCap) {
         int rc = drainPipeline();
         if (rc) return rc;
@@ -1006,6 +952,10 @@ int reserveSlotBuffers(int nSlots, size_t colourBytes, size_t stackBytes, size_t
     const bool shrink = small && g.smallStreak >= 8 && !ticketsOut;
     if (shrink) g.smallStreak = 0;
     if (!shrink && nSlots <= g.slotsReserved && colourBytes <= g.colourCap && stackBytes <= g.stackCap && pathBytes <= g.pathCap) return 0;
+    // ... nor may the slots GROW under such a frame: growth frees and re-allocates every colour slot (found by the round-4 advisor:
+    // the second row-serial batch asking for more than the first had got).  The caller retries with less or drops its look-ahead.
+    if (ticketsOut && colourBytes > g.colourCap)
+        return refuse("frame buffers: the colour slots are held by frames traced ahead of their call; a larger launch has to wait for them");
     int rc = syncAllStreams();
     if (rc) return rc;
     if (shrink) {
@@ -1031,27 +981,36 @@ int reserveSlotBuffers(int nSlots, size_t colourBytes, size_t stackBytes, size_t
             }
             const size_t held = (cb > g.colourCap ? g.colourCap * (size_t)g.slotsReserved : 0);
             if (need > freeB + held)
-                return fail("frame buffers: " + std::to_string(need >> 20) + " MiB needed for " + std::to_string(n) + " frame slots, " +
+                return refuse("frame buffers: " + std::to_string(need >> 20) + " MiB needed for " + std::to_string(n) + " frame slots, " +
                             std::to_string((freeB + held) >> 20) + " MiB available on the device (smaller batch / frame, or fewer frames in flight: tptSetFrameOverlap)");
         }
     }
-    for (int k = 0; k < n; ++k) {
-        const bool fresh = k >= g.slotsReserved;
-        if (fresh || cb > g.colourCap) {
-            if (g.dColour[k]) HIPCHK(hipFree(g.dColour[k]));
-            g.dColour[k] = nullptr;
-            if (cb) HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dColour[k]), cb));
+    auto grow = [&]() -> int {
+        for (int k = 0; k < n; ++k) {
+            const bool fresh = k >= g.slotsReserved;
+            if (fresh || cb > g.colourCap) {
+                if (g.dColour[k]) HIPCHK(hipFree(g.dColour[k]));
+                g.dColour[k] = nullptr;
+                if (cb) HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dColour[k]), cb));
+            }
+            if (fresh || sb > g.stackCap) {
+                if (g.dStack[k]) HIPCHK(hipFree(g.dStack[k]));
+                g.dStack[k] = nullptr;
+                if (sb && k < Context::kMaxOverlap) HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dStack[k]), sb));
+            }
         }
-        if (fresh || sb > g.stackCap) {
-            if (g.dStack[k]) HIPCHK(hipFree(g.dStack[k]));
-            g.dStack[k] = nullptr;
-            if (sb && k < Context::kMaxOverlap) HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dStack[k]), sb));
+        return 0;
+    };
+    if ((rc = grow())) {
+        // an allocation failed half-way (the memory check above is advisory: another process may have taken the memory): no slot may
+        // keep a capacity its buffer does not have -- give everything back, the next frame reserves afresh
+        for (int k = 0; k < Context::kMaxSlots; ++k) {
+            (void)hipFree(g.dColour[k]); g.dColour[k] = nullptr;
+            (void)hipFree(g.dStack[k]); g.dStack[k] = nullptr;
         }
-        if (fresh || pb > g.pathCap) {
-            if (g.dPath[k]) HIPCHK(hipFree(g.dPath[k]));
-            g.dPath[k] = nullptr;
-            if (pb && k < Context::kMaxOverlap) HIPCHK(hipMalloc(reinterpret_cast<void**>(&g.dPath[k]), pb));
-        }
+        (void)hipGetLastError();
+        g.colourCap = g.stackCap = g.pathCap = 0; g.slotsReserved = 0;
+        return rc;
     }
     g.colourCap = cb; g.stackCap = sb; g.pathCap = pb; g.slotsReserved = n;
     g.slotReservations++;
@@ -1105,14 +1064,11 @@ int chooseKernel(FramePlan& P)
 void sizeGrid(FramePlan& P)
 {
     KernelArgs& a = P.a;
-    int occUse = P.occ;
-    if (g.maxBlocksPerCU > 0 && g.maxBlocksPerCU < occUse) occUse = g.maxBlocksPerCU;
-    const int resident = g.traceCUs * occUse; // workgroups that can be co-resident (on the CUs the trace streams may use)
+    const int resident = g.traceCUs * P.occ; // workgroups that can be co-resident (on the CUs the trace streams may use)
     const int wavesPerBlock = P.threadsPerBlock / 64;
     int chunk = P.rowSerial ? 1 : TPT_CHUNK_PIXELS;
     // small frames: hand out single 8x8 tiles so every resident wave gets several chunks
     if (!P.rowSerial && a.numItems / TPT_CHUNK_PIXELS < 8 * resident * wavesPerBlock) chunk = 64;
-    if (!P.rowSerial && g.chunkOverride >= 64) chunk = g.chunkOverride & ~63;
     if (P.queued) chunk = 64; // the path-queue kernel accounts its pixel pools in 64-pixel chunks
     a.chunkSize = chunk;
     a.numChunks = (a.numItems + chunk - 1) / chunk;
@@ -1170,14 +1126,6 @@ void sizeGrid(FramePlan& P)
     if (cap < 1) cap = 1;
     if (blocks > cap) blocks = cap;
     if (blocks < 1) blocks = 1;
-#if TPT_LATE_JOIN
-    a.joinBase = blocks;
-    a.joinPct = P.queued && !P.rowSerial ? g.joinPct : 0;
-    if (a.joinPct > 0) {
-        blocks *= g.joinMult;
-        if (blocks > resident) blocks = resident;
-    }
-#endif
     P.blocks = blocks;
     a.totalWaves = (unsigned)(blocks * wavesPerBlock);
 }
@@ -1214,10 +1162,8 @@ int ensureFrameBuffers(FramePlan& P, int w)
     if (needStack) {
         a.stackBuf = g.dStack[slot % P.nOverlap];
         a.stackStride = P.queued ? P.blocks * tptQueuePathsPerBlock() : P.blocks * P.threadsPerBlock;
-#if TPT_TAIL_HELPERS
         // the columns of a helper grid (workgroups blocks .. 2 * blocks - 1 at most) lie behind the launch's own: one stride for both
-        if (P.queued && (g.helpersOn || g.helperStride) && g.helperStride) a.stackStride = (2 * P.blocks < maxBlocks ? 2 * P.blocks : maxBlocks) * tptQueuePathsPerBlock();
-#endif
+        if (P.queued) a.stackStride = (2 * P.blocks < maxBlocks ? 2 * P.blocks : maxBlocks) * tptQueuePathsPerBlock();
     }
     a.pathBuf = nullptr;
     return 0;
@@ -1226,17 +1172,12 @@ int ensureFrameBuffers(FramePlan& P, int w)
 int syncAllStreams()
 {
     for (int k = 0; k < Context::kMaxOverlap; ++k) HIPCHK(hipStreamSynchronize(g.traceStream[k]));
-#if TPT_TAIL_HELPERS
-    for (int k = 0; k < Context::kHelperStreams; ++k)
-        if (g.helperStream[k]) HIPCHK(hipStreamSynchronize(g.helperStream[k]));
     for (int k = 0; k < Context::kMaxSlots; ++k) g.hrec[k].valid = false; // (nothing is in flight any more)
-#endif
     HIPCHK(hipStreamSynchronize(g.stream));
     return 0;
 }
 
-#if TPT_TAIL_HELPERS
-// The caller is about to block: give the launches that have not finished a second grid each (tpt_device.h).  The newest launches
+// The caller is about to block: give the newest launches that have not finished a second grid each (tpt_device.h).  The newest launches
 // first -- they have the most left -- and at most helperMax of them; a launch is helped once.  hipEventQuery is a hint only: a launch
 // that finishes a microsecond later closes its counter block and the helpers leave at once.
 int launchTailHelpers()
@@ -1267,16 +1208,16 @@ int launchTailHelpers()
         for (int j = 0; j < n; ++j) queued += g.hrec[order[j]].ts == ts ? 1 : 0;
         if (queued == 1) freeSoon[nFree++] = ts;
     }
-    for (int i = 0; i < n / 2 && i < g.helperMax && i < nFree; ++i) {
+    for (int i = 0; i < n / 2 && i < Context::kHelperMax && i < nFree; ++i) {
         Context::HelperRec& R = g.hrec[order[i]];
         if (R.helped) continue;
         R.helped = true;
         int extra = R.maxBlocks - R.blocks;
-        if (extra > R.blocks) extra = R.blocks;
+        if (extra > R.blocks) extra = R.blocks; // (two and three times the launch's own grid measured no better, profiles/r05/r05_run2.log)
         if (extra < 1) continue;
         KernelArgs h = R.a;
         h.helperBase = R.blocks;
-        h.helperPct = g.helperPct;
+        h.helperPct = Context::kHelperPct;
         hipStream_t hs = freeSoon[i];
         if (hs == R.ts) continue; // (its own stream: it would run after the launch it is meant to help)
         HIPCHK(hipStreamWaitEvent(hs, g.evPre[order[i]], 0));
@@ -1285,7 +1226,6 @@ int launchTailHelpers()
     }
     return 0;
 }
-#endif
 
 // Cost-ordered work distribution of the lane-refill kernel: statistics and order tables for this chunk count.
 int prepareChunkOrder(FramePlan& P)
@@ -1411,19 +1351,23 @@ int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long
     // batch: 4 slots instead of 16), never fewer than 2 (one being traced, one being blended); a single slot above 4 GiB is
     // refused here, before anything is drained or freed.
     if (colourBytesPerSlot > (4ull << 30))
-        return fail("tptDrawDeviceBatch: " + std::to_string(colourBytesPerSlot >> 20) + " MiB of frame colour per launch (rows x width x 16 B x frames): over the 4096 MiB limit, use a smaller batch");
+        return refuse("tptDrawDeviceBatch: " + std::to_string(colourBytesPerSlot >> 20) + " MiB of frame colour per launch (rows x width x 16 B x frames): over the 4096 MiB limit, use a smaller batch");
     while (P.nSlots > 2 && colourBytesPerSlot * (size_t)P.nSlots > (8ull << 30)) P.nSlots /= 2;
     if (rayStride > 0 && g.seedMode == SEED_ROW_SERIAL && P.nSlots > 4) P.nSlots = 4; // (the host path's row-serial batches: two alive at a time)
     if (P.nOverlap > P.nSlots) P.nOverlap = P.nSlots;
     P.slot = (int)(g.frameSeq % (unsigned long long)P.nSlots);
     g.frameSeq++;
+    struct SeqGuard { // an enqueue that fails before its launch does not consume a slot of the pipeline
+        bool launched = false;
+        ~SeqGuard() { if (!launched) g.frameSeq--; }
+    } seqGuard;
 
     int rc = chooseKernel(P);
     if (rc) return rc;
     // a batch is traced by the path-queue kernel (per-pixel seeds) or, in the reference's own seed mode, by the lane-refill
     // kernel: one lane per (frame, row) -- rows AND frames are independent RNG streams there (Test.cpp:280)
     if (batch > 1 && (!(P.queued || P.rowSerial) || w > 8192 || h > 8192 || (long long)a.nLocalRows * w * batch > (1ll << 30)))
-        return fail("tptDrawDeviceBatch: needs the path-queue kernel (per-pixel seeds, recursive fold, two-phase HitSpheres) or row-serial seeds, and a frame of at most 8192 x 8192 (2^30 pixels per batch)");
+        return refuse("tptDrawDeviceBatch: needs the path-queue kernel (per-pixel seeds, recursive fold, two-phase HitSpheres) or row-serial seeds, and a frame of at most 8192 x 8192 (2^30 pixels per batch)");
     sizeGrid(P);
     if ((rc = ensureFrameBuffers(P, w))) return rc;
     if (frameRays) a.rayCounter = frameRays;
@@ -1459,8 +1403,7 @@ int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long
     if ((rc = enqueueSceneUpload(ts))) return rc; // behind the wait above: nobody reads the set being replaced any more
     if ((rc = enqueueChunkOrder(P, ts))) return rc;
     if (frameRays && frameRays != g.dRays) HIPCHK(hipMemsetAsync(frameRays, 0, sizeof(unsigned long long) * (size_t)(rayStride > 0 ? batch : 1), ts));
-#if TPT_TAIL_HELPERS
-    const bool helpable = g.helpersOn && g.helperStride && P.queued && pipelined && batch == 1 && !P.rowSerial;
+    const bool helpable = P.queued && pipelined && batch == 1 && !P.rowSerial; // (single frames of the path-queue kernel)
     a.helperBase = 0;
     a.helperPct = 0;
     a.gen = 0u;
@@ -1470,25 +1413,23 @@ int enqueueTrace(int frameCount, int w, int h, unsigned testFlags, unsigned long
         a.gen = g.launchGen;
         HIPCHK(hipEventRecord(g.evPre[slot], ts)); // the set upload and the slot's previous users are behind this point
     }
-#endif
     const bool timeIt = g.kernelTiming && g.ktUsed < g.ktStart.size();
     if (timeIt) HIPCHK(hipEventRecord(g.ktStart[g.ktUsed], ts));
     if (P.queued)
         HIPCHK(tptLaunchTraceQueue(a, P.ldsScene, P.blocks, P.lds, ts));
     else
         HIPCHK(tptLaunchTrace(a, g.hs, g.foldMode, P.ldsScene, P.blocks, P.lds, ts));
+    seqGuard.launched = true;
     if (timeIt) {
         HIPCHK(hipEventRecord(g.ktStop[g.ktUsed], ts));
         g.ktUsed++;
     }
     if (pipelined) HIPCHK(hipEventRecord(g.evTrace[slot], ts));
-#if TPT_TAIL_HELPERS
     if (helpable) {
         Context::HelperRec& R = g.hrec[slot];
         R.a = a; R.ldsScene = P.ldsScene; R.blocks = P.blocks; R.maxBlocks = maxGridBlocks(P); R.lds = P.lds;
         R.helped = false; R.valid = true; R.ts = ts;
     }
-#endif
     T.slot = slot;
     T.nPixels = a.nLocalRows * w;
     T.pipelined = pipelined;
@@ -1670,9 +1611,7 @@ int tptSetRayCounter(void* deviceU64)
 int tptSynchronize(void)
 {
     if (requireInit()) return -1;
-#if TPT_TAIL_HELPERS
     if (int rc = launchTailHelpers()) return rc;
-#endif
     HIPCHK(hipStreamSynchronize(g.stream));
     return 0;
 }
@@ -1687,9 +1626,7 @@ int tptTimerEnd(float* outMs)
 {
     if (requireInit()) return -1;
     HIPCHK(hipEventRecord(g.ev1, g.stream));
-#if TPT_TAIL_HELPERS
     if (int rc = launchTailHelpers()) return rc;
-#endif
     HIPCHK(hipEventSynchronize(g.ev1));
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, g.ev0, g.ev1));
@@ -1840,16 +1777,21 @@ int tptDraw(float time, int frameCount, int w, int h, float* backbuffer, int* ou
             B.used = false;
             // (two banks of per-frame counters; the batch being served keeps its bank when it moves from [1] to [0])
             const int bank = (which == 1 && g.rsb[0].used && g.rsb[0].counterBase == 0) ? kMaxBatch : 0;
-            for (int n = kMaxBatch; n >= 2; n /= 2) {
+            // the batch behind one that is being served starts at THAT batch's size: a larger one would have to grow the colour
+            // slots the first still reads (refused now) after draining the pipeline to find that out
+            const int nMax = (which == 1 && g.rsb[0].used) ? g.rsb[0].n : kMaxBatch;
+            for (int n = nMax; n >= 2; n /= 2) {
                 if (w > 8192 || h > 8192 || (long long)rows * w * n > (1ll << 30) || (unsigned long long)rows * w * 16ull * n > (4ull << 30)) continue;
                 B.firstFrame = firstFrame; B.n = n; B.next = 0; B.w = w; B.h = h; B.flags = testFlags; B.key = key;
                 B.counterBase = bank;
-                if (enqueueTrace(firstFrame, w, h, testFlags, g.dRaysBatch + B.counterBase, B.T, B.n, 1) == 0) {
+                const int rc = enqueueTrace(firstFrame, w, h, testFlags, g.dRaysBatch + B.counterBase, B.T, B.n, 1);
+                if (rc == 0) {
                     B.used = B.T.valid;
                     return 0;
                 }
+                if (rc != kRefused) return rc; // a real failure (HIP error, no scene): not something a smaller batch cures
             }
-            HC.refusedKey = key; HC.refusedW = w; HC.refusedH = h; // nothing fits: frame by frame from here on
+            if (which == 0) { HC.refusedKey = key; HC.refusedW = w; HC.refusedH = h; } // nothing fits: frame by frame from here on
             return 0;
         };
         if (matches(g.rsb[0])) {
@@ -2217,9 +2159,7 @@ int tptShardedFinish(int64_t* outTotalRays)
     if (requireInit()) return -1;
     Context::Shard& S = g.shard;
     if (!S.active) return fail("tptShardedFinish: call tptCommInit first");
-#if TPT_TAIL_HELPERS
     if (int rc = launchTailHelpers()) return rc;
-#endif
     HIPCHK(hipStreamSynchronize(g.stream));
     HIPCHK(hipStreamSynchronize(S.commStream));
     long long total = 0;

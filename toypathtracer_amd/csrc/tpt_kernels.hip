@@ -412,6 +412,10 @@ __device__ __forceinline__ f4 mk4(float x, float y, float z, float w)
 #ifndef TPT_MEMBER_UNROLL
 #define TPT_MEMBER_UNROLL 4 // member records requested together in the member filter of a (ray, group) pair
 #endif
+// (_Pragma with a stringised macro: `#pragma unroll MACRO` is not expanded when the source is preprocessed separately --
+//  -save-temps, ccache, distcc -- and the build broke there)
+#define TPT_PRAGMA_STR(x) _Pragma(#x)
+#define TPT_PRAGMA_UNROLL(n) TPT_PRAGMA_STR(unroll n)
 #define TPT_GROUP_DEAL_CAP 192 /* pair-list entries per wave and round (a multiple of 64) */
 #define TPT_GROUP_DEAL_WAVE_BYTES (TPT_GROUP_DEAL_CAP * 4 + 16)
 #define TPT_Q_SPH_FIXED 1024 /* bytes at LDS offset 0 for {centre, r^2} of scenes of <= 64 spheres: DS offsets fold into the instructions */
@@ -444,7 +448,6 @@ typedef volatile unsigned __attribute__((address_space(3))) * LdsList;
 typedef volatile unsigned short* LdsRing;
 typedef volatile unsigned* LdsList;
 #endif
-#if TPT_TAIL_HELPERS
 // 0, but only once `v` has arrived: orders a second atomic behind the RETURN of a first one without a fence (tpt_device.h)
 __device__ __forceinline__ unsigned dependentZero(unsigned v)
 {
@@ -452,7 +455,6 @@ __device__ __forceinline__ unsigned dependentZero(unsigned v)
     asm volatile("v_and_b32_e32 %0, 0, %1" : "=v"(z) : "v"(v));
     return z;
 }
-#endif
 // Push every lane's path id to the queue of its class `cls` (Q_FREE..Q_LAMBERT, or -1 for none): one returning LDS atomic
 // per lane reserves the slot (the LDS unit serialises the lanes that hit the same tail word -- its time, not the VALU's:
 // the ballot / popcount / readlane version of this cost ~35 VALU instructions per batch).
@@ -624,7 +626,7 @@ __device__ __forceinline__ int hitSpheresGroupedDeal(const SceneView& sv, bool g
                     rd = mk3(r1.y, r1.z, r1.w);
                     const f3 dk = mk3(rd.x * TPT_P1_K, rd.y * TPT_P1_K, rd.z * TPT_P1_K);
                     TPT_STAT(ST_SPHERELOOP); // profiling build: group visits
-#pragma unroll TPT_MEMBER_UNROLL
+                    TPT_PRAGMA_UNROLL(TPT_MEMBER_UNROLL)
                     for (int j = 0; j < TPT_GROUP; ++j) mm |= (memberFilter(mem[j], ro, dk) ? 1u : 0u) << j;
                 }
 #if TPT_GROUP_DEAL_EXACT
@@ -750,7 +752,6 @@ tptTraceQueueKernel(const KernelArgs a)
 #endif
 
     const int tid = threadIdx.x, lane = tid & 63;
-#if TPT_TAIL_HELPERS
     const bool helper = a.helperBase > 0;
     if (helper) { // (workgroup-uniform: one thread registers and looks, the barrier shares what it saw)
         unsigned* seen = reinterpret_cast<unsigned*>(smem);
@@ -772,26 +773,6 @@ tptTraceQueueKernel(const KernelArgs a)
         __syncthreads();
         if (!join) return;
     }
-#endif
-#if TPT_LATE_JOIN
-    if (a.joinPct > 0 && (int)blockIdx.x >= a.joinBase) { // (workgroup-uniform: one thread looks, the barrier shares what it saw)
-        unsigned* seen = reinterpret_cast<unsigned*>(smem);
-        if (tid == 0) *seen = __hip_atomic_load(&a.work[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        const long long left = (long long)a.numChunks - (long long)*seen;
-        __syncthreads();
-        if (left * 100 < (long long)a.numChunks * a.joinPct) { // too little left to pay for this workgroup's ramp and drain
-            if (lane == 0) {
-                const unsigned done = atomicAdd(&a.work[1], 1u) + 1u; // (the last wave of the launch re-arms the counters: see the end of the kernel)
-                if (done == a.totalWaves) {
-                    a.work[0] = 0u;
-                    a.work[1] = 0u;
-                }
-            }
-            return;
-        }
-    }
-#endif
     SceneView sv = a.scene;
     if (LDS_SCENE) {
         for (int i = tid; i < nPad; i += TPT_Q_T) {
@@ -938,11 +919,7 @@ tptTraceQueueKernel(const KernelArgs a)
         bool toEnd = false;  // Metal whose scattered ray points into the surface: the path ends (END class), nothing to intersect
         QStack stack;
         stack.l0 = (LdsF4Ptr)(st + 3 * TPT_Q_PATHS + p); // level 0 in the path record
-#if TPT_TAIL_HELPERS
         stack.spill = a.stackBuf + ((size_t)(blockIdx.x + (unsigned)a.helperBase) * TPT_Q_PATHS + p);
-#else
-        stack.spill = a.stackBuf + ((size_t)blockIdx.x * TPT_Q_PATHS + p);
-#endif
         stack.stride = a.stackStride;
         QLambert lam;
         lam.sdir = lam.nl = lam.albedo = lam.lightE = mk3(0, 0, 0);
@@ -1196,7 +1173,6 @@ tptTraceQueueKernel(const KernelArgs a)
         __syncthreads();
         if (tid < a.batchFrames && ctl->frameRays[tid] != 0u) atomicAdd(a.rayCounter + (size_t)tid * a.rayCounterStride, (unsigned long long)ctl->frameRays[tid]);
     }
-#if TPT_TAIL_HELPERS
     if (helper) {
         // this workgroup's pixels are stored and its rays counted: leave the launch (release: the stores reach memory first)
         if (lane == 0 && !BATCH) atomicAdd(a.rayCounter, (unsigned long long)waveRays);
@@ -1207,12 +1183,10 @@ tptTraceQueueKernel(const KernelArgs a)
         }
         return;
     }
-#endif
     if (lane == 0) {
         if (!BATCH) atomicAdd(a.rayCounter, (unsigned long long)waveRays);
         unsigned done = atomicAdd(&a.work[1], 1u) + 1u;
         if (done == a.totalWaves) {
-#if TPT_TAIL_HELPERS
             if (a.gen != 0u) {
                 // close, THEN look for registered helpers (they register, then look for "closed": one side always sees the other);
                 // they are resident workgroups finishing the chunks they took -- bounded; the cap only keeps a bug from hanging the GPU
@@ -1223,7 +1197,6 @@ tptTraceQueueKernel(const KernelArgs a)
                     busy = __hip_atomic_fetch_or(&a.work[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
             }
-#endif
             a.work[0] = 0u;
             a.work[1] = 0u;
         }
@@ -1521,16 +1494,12 @@ hipError_t tptLaunchChunkOrder(const unsigned* cost, unsigned* snap, unsigned* o
     return hipGetLastError();
 }
 
-// Workgroups of a blend launch: one per 256 pixels up to a cap (env TPT_RESOLVE_BLOCKS for experiments), grid-stride beyond.
-static int g_resolveCap = -1;
+// Workgroups of a blend launch: one per 256 pixels up to 512, grid-stride beyond (every workgroup is one more dispatch that has
+// to find a slot on a machine full of persistent trace workgroups; 128-512 measured alike, profiles/r03).
 static int tptResolveBlocks(int nPixels)
 {
-    if (g_resolveCap < 0) {
-        const char* e = getenv("TPT_RESOLVE_BLOCKS");
-        g_resolveCap = (e && atoi(e) > 0) ? atoi(e) : 512;
-    }
     const int need = (nPixels + 255) / 256;
-    return need < g_resolveCap ? need : g_resolveCap;
+    return need < 512 ? need : 512;
 }
 hipError_t tptLaunchResolve(float* tile, const f4* frameColour, int nPixels, float lerpFac, float* mirror,
                             unsigned long long* rayCounter, unsigned long long* counterOut, const unsigned long long* frameRays, hipStream_t stream)

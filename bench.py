@@ -52,6 +52,7 @@ WORKLOADS = {
 }
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 PEAK_FP32_TFLOPS = 157.3       # MI355X_MICROARCH.md: peak FP32 vector (counts FMA as 2)
+PEAK_VALU_GINSTR = 256 * 4 * 2.4 / 2  # G wave64 VALU instructions per second: each SIMD issues one over 2 cycles (MI355X_MICROARCH.md)
 FLOP_PER_SPHERE_TEST = 17      # per (ray, sphere) test
 FLAG_PROGRESSIVE = 2
 FLAG_ANIMATE = 1
@@ -491,11 +492,23 @@ def main():
         # figure is a STATIC one from profiles/pmc_traffic.json -- and only the entry measured for this workload at this
         # very launch geometry (workgroups per launch); no entry -> null, never a neighbour's number.
         traffic, traffic_src = None, "profiles/pmc_traffic.json has no entry for (%s, %d workgroups per launch)" % (args.workload, info["grid_blocks"])
+        valu_insts, valu_src = None, traffic_src
         tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(tpath) and args.persistent == 3 and frames_per_launch == 1 and world == 1:
             ent = json.load(open(tpath)).get("by_workload_and_grid", {}).get(args.workload, {}).get(str(info["grid_blocks"]))
             if ent:
                 traffic, traffic_src = ent["bytes_per_launch"], ent["source"]
+                if ent.get("valu_insts_per_launch") and args.hit_spheres == 0:
+                    valu_insts, valu_src = ent["valu_insts_per_launch"], ent.get("valu_source", ent["source"])
+        # EXECUTED vector work (SQ_INSTS_VALU wave-instructions per launch, a static figure like the traffic) over the pipeline time
+        # per frame, against one wave64 VALU instruction per SIMD every 2 cycles (MI355X_MICROARCH.md): what the VALU pipes really do
+        grouped = n_spheres >= 256 and args.hit_spheres == 0
+        issue = None
+        if valu_insts:
+            g_instr_s = valu_insts / (pl_ms * 1e-3) / 1e9
+            issue = {"insts_per_launch": valu_insts, "achieved": g_instr_s, "peak": PEAK_VALU_GINSTR, "unit": "G wave-instr/s", "frac": g_instr_s / PEAK_VALU_GINSTR,
+                     "static": True, "source": valu_src,
+                     "note": "SQ_INSTS_VALU per trace launch (rocprofv3 --pmc, kernels serialised) over the pipeline time per launch; peak = 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles"}
         out = {
             "metric": "Mray/s", "value": rays_total / dt / 1e6, "unit": "Mray/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -527,15 +540,23 @@ def main():
                          "note": "north_star's HBM-write roofline (W*H*16 B per frame).  The kernel is FP32-VALU bound (arithmetic "
                                  "intensity ~440 flop/B against a machine balance of ~20): see roofline_valu, the binding one",
                          "kernel": {1: "tptTraceKernel", 3: "tptTraceQueueKernel"}[args.persistent]},
-            "roofline_valu": {"bound": "valu_fp32", "achieved": valu_tflops * k_ms / pl_ms, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                              "frac": valu_tflops * k_ms / pl_ms / PEAK_FP32_TFLOPS,
-                              "achieved_per_launch": valu_tflops, "frac_per_launch": valu_tflops / PEAK_FP32_TFLOPS,
-                              "note": "algorithmic flops = rays x 17 flop x spheres (SURVEY 8d: the reference's own per-test count) over the "
-                                      "pipeline time per frame; peak counts FMA as 2 flop.  The exact arithmetic (phase 2 of HitSpheres, Scatter) "
-                                      "may not contract to FMA (parity); phase 1 is a conservative filter"
-                                      + ("; this scene is traversed through sphere groups, so the figure is the brute-force-EQUIVALENT rate "
-                                         "(most of those tests are never executed)" if (n_spheres >= 256 and args.hit_spheres == 0) else "")},
+            "roofline_valu": ({"bound": "valu_fp32", "achieved": valu_tflops * k_ms / pl_ms, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                               "frac": valu_tflops * k_ms / pl_ms / PEAK_FP32_TFLOPS,
+                               "achieved_per_launch": valu_tflops, "frac_per_launch": valu_tflops / PEAK_FP32_TFLOPS,
+                               "note": "algorithmic flops = rays x 17 flop x spheres (SURVEY 8d: the reference's own per-test count) over the "
+                                       "pipeline time per frame; peak counts FMA as 2 flop.  The exact arithmetic (phase 2 of HitSpheres, Scatter) "
+                                       "may not contract to FMA (parity); phase 1 is a conservative filter"} if not grouped else
+                              # a scene traversed through sphere groups never executes most of the 17 x N flops: a fraction of the FP32 peak
+                              # would exceed 1 and say nothing.  What the kernel EXECUTES is reported instead (null without a measurement).
+                              {"bound": "valu_issue", "achieved": issue["achieved"] if issue else None, "peak": PEAK_VALU_GINSTR, "unit": "G wave-instr/s",
+                               "frac": issue["frac"] if issue else None,
+                               "brute_force_equivalent_tflops": valu_tflops * k_ms / pl_ms,
+                               "note": "grouped traversal (>= 256 spheres): executed VALU wave-instructions per second against the issue rate of the "
+                                       "SIMDs; the brute-force-equivalent flop rate (rays x 17 x spheres, tests that are never executed) is kept "
+                                       "beside it for comparison with the flat kernels and is not a roofline fraction"}),
         }
+        if issue:
+            out["valu_issue"] = issue
         total_frames = args.prime + args.warmup + args.steps
         if scene == "default" and not args.animate and args.parity_frames > 0:
             out.update(image_parity(image, rays_all_frames, width, height, spp, total_frames, args.parity_frames, args.parity_samples))

@@ -612,4 +612,5 @@ def test_side_stream_fill_is_ordered_through_tptSetStream(tpt_defaults, oracle):
         finally:
             tpt.set_stream(None)
     assert results[True], "with tptSetStream the side-stream fill is ordered before the library's first blend"
-    assert not results[False], "without tptSetStream nothing orders a side-stream fill against the library (if this starts passing, the contract in INTEGRATION.md can be relaxed)"
+    if tpt.pipeline_info()["hw_queues"] >= 16:  # (streams that have to share hardware queues are ordered by accident)
+        assert not results[False], "without tptSetStream nothing orders a side-stream fill against the library (if this starts passing, the contract in INTEGRATION.md can be relaxed)"

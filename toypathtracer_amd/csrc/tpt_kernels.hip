@@ -41,13 +41,14 @@ __device__ __forceinline__ bool mapItem(const KernelArgs& a, int idx, int& x, in
         return ly < a.nLocalRows;
     }
     int tile = idx >> 6, within = idx & 63;
-    int tx = tile % a.tilesX, ty = tile / a.tilesX;
+    const int tilesX = uniformHere(a.tilesX);
+    int tx = tile % tilesX, ty = tile / tilesX;
     x = tx * 8 + (within & 7);
     ly = ty * 8 + (within >> 3);
     return x < a.fc.width && ly < a.nLocalRows;
 }
-__device__ __forceinline__ int localRowToGlobal(const KernelArgs& a, int ly) { return shardKernelLocalToGlobal(ly, a.stripeRows, a.stripeStride, a.stripeOffset); }
-__device__ __forceinline__ int globalRowToLocal(const KernelArgs& a, int gy) { return shardKernelGlobalToLocal(gy, a.stripeRows, a.stripeStride, a.stripeOffset); } // rows of this rank
+__device__ __forceinline__ int localRowToGlobal(const KernelArgs& a, int ly) { return shardKernelLocalToGlobal(ly, uniformHere(a.stripeRows), uniformHere(a.stripeStride), a.stripeOffset); }
+__device__ __forceinline__ int globalRowToLocal(const KernelArgs& a, int gy) { return shardKernelGlobalToLocal(gy, uniformHere(a.stripeRows), uniformHere(a.stripeStride), a.stripeOffset); } // rows of this rank
 
 __device__ __forceinline__ void storeColour(const KernelArgs& a, const Lane& L)
 {
@@ -712,9 +713,8 @@ __device__ __forceinline__ int hitSpheresGroupedDeal(const SceneView& sv, bool g
 #endif
 // BATCH: the launch traces a.batchFrames consecutive frames (tptDrawDeviceBatch).  A compile-time switch: the frame index
 // a path carries costs the single-frame kernel two more spilled registers if it is a run-time one.
-template <bool LDS_SCENE, bool BATCH = false>
-__global__ void __launch_bounds__(TPT_Q_T, TPT_Q_MIN_WAVES_PER_SIMD) __attribute__((amdgpu_num_vgpr(TPT_Q_MAX_VGPR)))
-tptTraceQueueKernel(const KernelArgs a)
+template <bool LDS_SCENE, bool BATCH>
+__device__ __forceinline__ void traceQueueBody(const KernelArgs& a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     // LDS layout: everything of fixed size first, at compile-time offsets (immediates in the DS instructions instead of base
@@ -1219,6 +1219,32 @@ tptTraceQueueKernel(const KernelArgs a)
 #endif
     }
 #endif
+}
+
+// The kernels proper.  Scenes staged in LDS (<= 64 spheres with the matrix filter: the headline) keep the 120-register cap above.
+// Grouped scenes (no LDS scene: the 4096-sphere stress scene) hold four candidate masks, the dealing state and the group's member
+// gathers on top: at 120 registers that instantiation spilled 32 of them (128 B of scratch per lane, 11x the algorithmic HBM traffic);
+// it gets the full 128 of a 4-wave SIMD -- its launches last ~200 ms, the blend behind them can wait for a workgroup to retire.
+#ifndef TPT_Q_MAX_VGPR_GROUPED
+#define TPT_Q_MAX_VGPR_GROUPED 64
+#endif
+template <bool LDS_SCENE, bool BATCH = false>
+__global__ void __launch_bounds__(TPT_Q_T, TPT_Q_MIN_WAVES_PER_SIMD) __attribute__((amdgpu_num_vgpr(TPT_Q_MAX_VGPR)))
+tptTraceQueueKernel(const KernelArgs a)
+{
+    traceQueueBody<LDS_SCENE, BATCH>(a);
+}
+template <>
+__global__ void __launch_bounds__(TPT_Q_T, TPT_Q_MIN_WAVES_PER_SIMD) __attribute__((amdgpu_num_vgpr(TPT_Q_MAX_VGPR_GROUPED)))
+tptTraceQueueKernel<false, false>(const KernelArgs a)
+{
+    traceQueueBody<false, false>(a);
+}
+template <>
+__global__ void __launch_bounds__(TPT_Q_T, TPT_Q_MIN_WAVES_PER_SIMD) __attribute__((amdgpu_num_vgpr(TPT_Q_MAX_VGPR_GROUPED)))
+tptTraceQueueKernel<false, true>(const KernelArgs a)
+{
+    traceQueueBody<false, true>(a);
 }
 
 #if defined(TPT_TEST_HOOKS)

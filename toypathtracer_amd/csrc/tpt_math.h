@@ -24,6 +24,18 @@
 
 namespace tpt {
 
+// A wave-uniform integer the compiler may not carry in a scalar register across the kernel's main loop: on the device the value is
+// laundered through an empty asm at the point of use, so what is derived from it (stride x level, division magic, ...) is made
+// again there instead of being hoisted out of the loop and spilled (the path-queue kernel had 54-63 SGPRs spilled to VGPR lanes,
+// most of them such products needed once per pixel or per sample).
+TPT_HD int uniformHere(int v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(v));
+#endif
+    return v;
+}
+
 #define TPT_PI 3.1415926f // kPI, Maths.h:9
 
 // ---------------------------------------------------------------- bit casts

@@ -1116,6 +1116,7 @@ TPT_HD f3 qFold(const SceneView& sv, f3 term, int depth, const QStack& s)
 {
     TPT_STAT(ST_FINISH);
     f3 c = term;
+    const int stride = uniformHere(s.stride); // (the eight multiples of it below are made here, once per fold, not held for the whole kernel)
 #pragma unroll
     for (int g5 = 1; g5 >= 0; --g5) {
         f4 ent[5];
@@ -1123,7 +1124,7 @@ TPT_HD f3 qFold(const SceneView& sv, f3 term, int depth, const QStack& s)
         for (int k = 0; k < 5; ++k) {
             ent[k].x = ent[k].y = ent[k].z = ent[k].w = 0.0f;
             const int lvl = g5 * 5 + k;
-            if (lvl < depth) ent[k] = lvl == 0 ? *s.l0 : s.spill[(lvl - 1) * s.stride];
+            if (lvl < depth) ent[k] = lvl == 0 ? *s.l0 : s.spill[(lvl - 1) * stride];
         }
 #pragma unroll
         for (int k = 4; k >= 0; --k) {

@@ -556,7 +556,9 @@ def test_config5_stress_scene_full_parity(tpt_defaults, oracle):
     tpt.set_samples_per_pixel(spp)
     r1, b1, _ = gpu_frames(tpt, w, h, 1)
     r2, b2, _ = gpu_frames(tpt, w, h, 1)
-    assert r1 == r2 and b1.tobytes() == b2.tobytes()
+    r2b, b2b, _ = gpu_frames(tpt, w, h, 1)
+    assert r1 == r2 == r2b and b1.tobytes() == b2.tobytes() == b2b.tobytes(), (
+        "three renders of one frame differ: rays %d / %d / %d, pixels differing 1-2: %d, 1-3: %d" % (r1, r2, r2b, int((b1 != b2).any(axis=2).sum()), int((b1 != b2b).any(axis=2).sum())))
     assert np.isfinite(b1[..., :3]).all() and float(b1[..., 3].max()) == 0.0
     assert r1 > 2 * w * h * spp
     cam = oracle.camera(STRESS_CAMERA["look_from"], STRESS_CAMERA["look_at"], (0, 1, 0), STRESS_CAMERA["vfov"], w / h,

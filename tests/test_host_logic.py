@@ -1,4 +1,4 @@
-"""The HOST side of the library on the CPU: csrc/tpt_host.cpp -- unmodified -- compiled against tests/hostemu (a stand-in for the HIP
+"""The HOST side of the library on the CPU: csrc/tpt_host*.cpp -- unmodified -- compiled against tests/hostemu (a stand-in for the HIP
 runtime calls it makes: streams as queues of closures, events, "device" memory with poison-on-free; the kernels' launch functions
 restated on the lane headers) and driven through the ctypes mirror by tests/hostemu_driver.py, whose scenarios are the GPU suite's at CPU
 sizes: streaming and synchronous callers, look-ahead, DrawTest on host pointers in both seed modes, batches, stream batching, animated
@@ -20,8 +20,10 @@ from oracle_lib import ROOT
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 BUILD = os.path.join(HERE, "_build")
-SOURCES = [os.path.join(ROOT, "toypathtracer_amd", "csrc", "tpt_host.cpp"), os.path.join(HERE, "hostemu", "hostemu_kernels.cpp"),
-           os.path.join(HERE, "hostemu", "hip_shim.cpp")]
+HOST_UNITS = [os.path.join(ROOT, "toypathtracer_amd", "csrc", u + ".cpp") for u in ("tpt_host", "tpt_host_pipeline", "tpt_host_draw", "tpt_host_shard", "tpt_host_hooks")]
+EMU_UNITS = [os.path.join(HERE, "hostemu", "hostemu_kernels.cpp"), os.path.join(HERE, "hostemu", "hip_shim.cpp")]
+SOURCES = HOST_UNITS + EMU_UNITS
+PIPELINE = HOST_UNITS[1]  # (where the mutation below is made)
 
 
 def build(name, extra, host_source=None):
@@ -33,7 +35,7 @@ def build(name, extra, host_source=None):
         return out
     cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-Wno-unknown-pragmas",
            "-include", "hip/hip_runtime.h", "-I", os.path.join(HERE, "hostemu"), "-I", os.path.join(ROOT, "toypathtracer_amd", "csrc")]
-    subprocess.check_call(cmd + extra + ([host_source] + SOURCES[1:] if host_source else SOURCES) + ["-o", out, "-ldl", "-lpthread"])
+    subprocess.check_call(cmd + extra + ([u if u != PIPELINE else host_source for u in SOURCES] if host_source else SOURCES) + ["-o", out, "-ldl", "-lpthread"])
     return out
 
 
@@ -45,12 +47,12 @@ def runs():
     jobs = {}
     # A mutant of the host code for the harness's own sanity: the stream wait that keeps a colour slot's next trace launch behind
     # the slot's previous blend is taken out (the host's pacing loop, which normally hides such a slip, is off in that run).
-    src = open(SOURCES[0]).read()
+    src = open(PIPELINE).read()
     wait = "        HIPCHK(hipStreamWaitEvent(ts, g.evResolve[slot], 0)); // colour buffer free again"
     assert src.count(wait) == 1, "the mutation site moved: update tests/test_host_logic.py"
-    mutant_src = os.path.join(BUILD, "tpt_host_mutant.cpp")
+    mutant_src = os.path.join(BUILD, "tpt_host_pipeline_mutant.cpp")
     os.makedirs(BUILD, exist_ok=True)
-    text = src.replace(wait, "        // MUTANT (tests/test_host_logic.py): no wait for the slot's previous blend").replace('#include "../../include/', '#include "%s/include/' % ROOT)
+    text = src.replace(wait, "        // MUTANT (tests/test_host_logic.py): no wait for the slot's previous blend").replace('#include "tpt_context.h"', '#include "%s/toypathtracer_amd/csrc/tpt_context.h"' % ROOT)
     if not os.path.exists(mutant_src) or open(mutant_src).read() != text:
         open(mutant_src, "w").write(text)
     mutant = build("libtpt_hostemu_mutant.so", [], host_source=mutant_src)

@@ -11,11 +11,17 @@ OUT=${TPT_OUT_DIR:-$HERE/../lib}
 mkdir -p "$OUT"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="$TPT_EXTRA_FLAGS --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -fno-fast-math -fno-slp-vectorize -Wall -Wno-unused-function"
+HOST_UNITS="tpt_host tpt_host_pipeline tpt_host_draw tpt_host_shard tpt_host_hooks" # (tpt_context.h says what each holds)
 build_one() { # suffix, extra flags
-  $HIPCC $FLAGS $2 -c "$HERE/tpt_kernels.hip" -o "$OUT/tpt_kernels$1.o"
-  $HIPCC $FLAGS $2 -x hip -c "$HERE/tpt_host.cpp" -o "$OUT/tpt_host$1.o"
-  $HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,--version-script="$HERE/exports.map" -o "$OUT/libtoypathtracer_hip$1.so" "$OUT/tpt_kernels$1.o" "$OUT/tpt_host$1.o"
-  rm -f "$OUT/tpt_kernels$1.o" "$OUT/tpt_host$1.o"
+  local objs="$OUT/obj$1.tpt_kernels.o" pids=""
+  $HIPCC $FLAGS $2 -c "$HERE/tpt_kernels.hip" -o "$OUT/obj$1.tpt_kernels.o" & pids="$!"
+  for u in $HOST_UNITS; do
+    $HIPCC $FLAGS $2 -x hip -c "$HERE/$u.cpp" -o "$OUT/obj$1.$u.o" & pids="$pids $!"
+    objs="$objs $OUT/obj$1.$u.o"
+  done
+  for p in $pids; do wait $p || exit 1; done
+  $HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,--version-script="$HERE/exports.map" -o "$OUT/libtoypathtracer_hip$1.so" $objs
+  rm -f $objs
   echo "built $OUT/libtoypathtracer_hip$1.so"
 }
 build_one "" "" &

@@ -1023,7 +1023,11 @@ __device__ __forceinline__ void traceQueueBody(const KernelArgs& a)
                     ray = true;
                 } else {
                     const f3 out = col * fc.invSpp; // Test.cpp:291
+#if !defined(TPT_MEASURE_NO_COLOUR_STORE) // (measurement builds only, tools/build_variant.sh: what the launch writes WITHOUT its pixels = the bounce-stack spills)
                     a.frameColour[plane + globalRowToLocal(a, py) * fc.width + px] = mk4(out.x, out.y, out.z, 0.0f); // one 16-B store per pixel
+#else
+                    if (out.x == 123456.0f) a.frameColour[0] = mk4(out.x, out.y, out.z, 0.0f);
+#endif
                     toFree = true;
                 }
             }

@@ -30,7 +30,7 @@ namespace tpt {
 // most of them such products needed once per pixel or per sample).
 TPT_HD int uniformHere(int v)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(TPT_NO_UNIFORM_HERE)
     asm volatile("" : "+s"(v));
 #endif
     return v;

@@ -38,7 +38,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # one hardware queue per in-flight trace kernel; read by the HIP runtime when it initialises (before torch does that)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -260,7 +260,7 @@ def self_launch(n):
                    MASTER_PORT=str(port), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1"))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc = 0
+    rc, failed_at = 0, None
     while procs:
         for p in list(procs):
             code = p.poll()
@@ -268,9 +268,13 @@ def self_launch(n):
                 continue
             procs.remove(p)
             if code != 0 and rc == 0:
-                rc = code
-                for q in procs:  # the others would wait for it in a collective for ever
-                    q.terminate()
+                rc, failed_at = code, _time.monotonic()
+        # the others would wait for the failed rank in a collective for ever -- but give them the time to say what THEY found first
+        # (a rank still importing torch on a busy host has not printed its own "needs a GPU" yet)
+        if failed_at is not None and _time.monotonic() - failed_at > 60.0:
+            for q in procs:
+                q.terminate()
+            failed_at = float("inf")
         _time.sleep(0.05)
     return rc
 

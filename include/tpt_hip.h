@@ -142,8 +142,9 @@ TPT_API int tptDrawDeviceBatch(float time, int firstFrame, int nFrames, int scre
  * context's stream, so results are bit-identical to frames=1.  1..16, default 16: the tail of frame f (a few long
  * paths) overlaps the following frames, and each launch takes only its share of the machine (2/frames-in-flight of
  * the resident workgroups; a caller that synchronises every frame gets whole-machine launches).
- * Needs one hardware queue per in-flight kernel: tptInitialize sets GPU_MAX_HW_QUEUES=32 if the HIP runtime has
- * not been initialised yet (ROCm's default of 4 makes 3 streams slower than 2), then MEASURES how many streams really
+ * Needs one hardware queue per in-flight kernel: tptInitialize sets GPU_MAX_HW_QUEUES=20 if the HIP runtime has
+ * not been initialised yet (ROCm's default of 4 makes 3 streams slower than 2; more than ~22 queues in one process are
+ * time-sliced by the device: slower, and see INTEGRATION.md "Streams are not free"), then MEASURES how many streams really
  * run side by side and clamps the pipeline to that (tptGetPipelineInfo).  Twice as many frames may be ENQUEUED ahead
  * (frames f and f + frames share a stream). */
 TPT_API int tptSetFrameOverlap(int frames);

@@ -6,7 +6,7 @@ import pytest
 # One hardware queue per in-flight trace kernel: the HIP runtime reads this when it STARTS, and a test that touches torch.cuda
 # before the library is loaded would start it with the default of 4 (the library then measures 3 usable queues and runs a 2-deep
 # pipeline: round 5, a launcher test that asked torch for the device count first turned five later tests red).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):

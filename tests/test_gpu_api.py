@@ -78,7 +78,7 @@ cap = sys.argv[1]
 if cap != "auto":
     os.environ["TPT_OVERLAP_CAP"] = cap
 sys.path.insert(0, sys.argv[2])
-from toypathtracer_amd import api                    # (sets GPU_MAX_HW_QUEUES=32 -- too late for this process)
+from toypathtracer_amd import api                    # (sets GPU_MAX_HW_QUEUES=20 -- too late for this process)
 api.InitializeTest()
 w, h = 1280, 720
 tile = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
@@ -117,7 +117,7 @@ def test_host_that_initialised_hip_first_still_gets_a_working_pipeline(tmp_path)
 
 
 def test_pipeline_info_with_queues_set_early(tpt_defaults):
-    """In the test process GPU_MAX_HW_QUEUES=32 was exported before HIP started (api.load_library): all trace streams run
+    """In the test process GPU_MAX_HW_QUEUES=20 was exported before HIP started (api.load_library): all trace streams run
     side by side, the full pipeline is used, and the per-slot buffers are allocated once per frame shape."""
     import torch
     tpt = tpt_defaults

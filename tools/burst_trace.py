@@ -20,7 +20,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--analyse":
                 if short in ("trace", "resolve", "publish"):
                     print("  %-8s start %9.1f  end %9.1f  dur %8.1f" % (short, (s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3))
     sys.exit(0)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 import torch
 from toypathtracer_amd import api
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20

@@ -3,7 +3,7 @@ tptDrawDeviceBatch (frames x rows lanes per launch), with what the pipeline look
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 import torch
 from toypathtracer_amd import api
 import bench

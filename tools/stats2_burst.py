@@ -3,7 +3,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("TPT_LIB", os.path.join(ROOT, "tools", "_stats2", "libtoypathtracer_hip.so"))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 import torch
 from toypathtracer_amd import api
 api.InitializeTest()

@@ -95,7 +95,7 @@ def _bind(path, hooks):
 def _preload():
     # one hardware queue per in-flight trace kernel (the runtime's default of 4 serialises deeper frame pipelining);
     # must be in the environment before the HIP runtime initialises
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "32")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
     try:  # torch ships its own HIP runtime: load it first so both sides share one libamdhip64 in the process
         import torch  # noqa: F401
     except ImportError:

@@ -26,6 +26,7 @@
 #include <string>
 
 
+#define TPT_DEFAULT_HW_QUEUES "20" /* what tptInitialize exports as GPU_MAX_HW_QUEUES when the host has not (tpt_host.cpp) */
 namespace tpth {
 using namespace tpt;
 

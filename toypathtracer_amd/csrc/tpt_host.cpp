@@ -300,7 +300,12 @@ int tptInitialize(void)
     // Frame pipelining wants one hardware queue per in-flight trace kernel; the ROCm runtime exposes 4 by default and
     // maps further streams onto them round-robin (3 streams then run slower than 2).  Only effective if the HIP
     // runtime has not been initialised yet by the host application; harmless otherwise.
-    setenv("GPU_MAX_HW_QUEUES", "32", 0);
+    // 20, not more: this library's 18 streams, the null stream and one of the host's each get their own, and the process
+    // stays below what the device runs side by side.  A process that holds MORE queues than that (measured on MI355X /
+    // ROCm 7.2: 20 and 22 fine, 24 and up not) is time-sliced by the device's scheduler -- running waves are switched out
+    // and back in -- and that (a) halves the frame rate (round 4) and (b) makes the grouped kernel's long launches return
+    // 1-4 wrong pixels in ~8 % of the 4096-sphere frames (round 5: profiles/r05/README.md calls 11-23).
+    setenv("GPU_MAX_HW_QUEUES", TPT_DEFAULT_HW_QUEUES, 0);
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)

@@ -417,7 +417,9 @@ __device__ __forceinline__ f4 mk4(float x, float y, float z, float w)
 //  -save-temps, ccache, distcc -- and the build broke there)
 #define TPT_PRAGMA_STR(x) _Pragma(#x)
 #define TPT_PRAGMA_UNROLL(n) TPT_PRAGMA_STR(unroll n)
+#ifndef TPT_GROUP_DEAL_CAP
 #define TPT_GROUP_DEAL_CAP 192 /* pair-list entries per wave and round (a multiple of 64) */
+#endif
 #define TPT_GROUP_DEAL_WAVE_BYTES (TPT_GROUP_DEAL_CAP * 4 + 16)
 #define TPT_Q_SPH_FIXED 1024 /* bytes at LDS offset 0 for {centre, r^2} of scenes of <= 64 spheres: DS offsets fold into the instructions */
 #ifndef TPT_Q_PATHS
@@ -1023,11 +1025,7 @@ __device__ __forceinline__ void traceQueueBody(const KernelArgs& a)
                     ray = true;
                 } else {
                     const f3 out = col * fc.invSpp; // Test.cpp:291
-#if !defined(TPT_MEASURE_NO_COLOUR_STORE) // (measurement builds only, tools/build_variant.sh: what the launch writes WITHOUT its pixels = the bounce-stack spills)
                     a.frameColour[plane + globalRowToLocal(a, py) * fc.width + px] = mk4(out.x, out.y, out.z, 0.0f); // one 16-B store per pixel
-#else
-                    if (out.x == 123456.0f) a.frameColour[0] = mk4(out.x, out.y, out.z, 0.0f);
-#endif
                     toFree = true;
                 }
             }

@@ -72,6 +72,8 @@ for r in range(reps):
         W, H = 3840, 2160
     else:
         tpt.set_scene(s, m); tpt.set_camera(**STRESS_CAMERA); tpt.set_samples_per_pixel(8)
+        if "C5_VARIANT" in os.environ:   # e.g. "3,3,-1": the shipped kernel with the packed VALU filter for the groups' bounds (no matrix cores)
+            tpt.set_kernel_variant(*[int(v) for v in os.environ["C5_VARIANT"].split(",")])
     out = []
     path = os.environ.get("C5_PATH", "drawtest")  # drawtest: host buffer (look-ahead frames behind it); device: tptDrawDevice + synchronise
     if "C5_LOOKAHEAD" in os.environ:

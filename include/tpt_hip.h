@@ -234,6 +234,11 @@ TPT_API int tptKernelTimingEnd(float* outSumMilliseconds, int* outLaunches);
  * 1 = stage sphere records and materials in LDS (default when they fit), 0 = read them from global memory, -1 = auto.
  * All variants produce identical bits. */
 TPT_API int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene);
+/* What the next launch will do with the scene: its sphere count, the number of sphere groups (0: the scene is traversed flat -- up to 255
+ * spheres, or a scene the grouping refuses), and whether the groups' bounding spheres are filtered on the matrix cores (1) or by the packed
+ * VALU filter (0: tptSetKernelVariant(3, ..), or a process that started HIP with GPU_MAX_HW_QUEUES > 22 -- such a process may be time-sliced
+ * by the device, under which the matrix-core filter of the grouped kernel has been seen to lose candidates: DESIGN.md 2.2). */
+TPT_API int tptGetSceneInfo(int* outSpheres, int* outGroups, int* outBoundsOnMatrixCores);
 /* kernel resource facts for DESIGN/bench: occupancy (blocks/CU), LDS bytes/block, grid size of the last launch */
 TPT_API int tptGetLaunchInfo(int* outBlocksPerCU, int* outLdsBytes, int* outGridBlocks, int* outNumCUs);
 /* Facts about the frame pipeline: hardware queues the runtime really runs side by side for this process (measured at

@@ -568,9 +568,15 @@ def test_config5_stress_scene_full_parity(tpt_defaults, oracle):
     # the WHOLE frame against the oracle's brute force over 4096 spheres (the grouped traversal must change nothing)
     ro, bo = oracle.render(s, m, cam, w, h, spp, 0, seed_mode=SEED_PER_PIXEL)
     assert r1 == ro and b1.tobytes() == bo.tobytes()
+    assert tpt.scene_info() == dict(spheres=4096, groups=512, bounds_on_matrix_cores=True)
     tpt.set_kernel_variant(0, 1, -1)  # lane-refill kernel on the same frame
     r3, b3, _ = gpu_frames(tpt, w, h, 1)
     assert r3 == r1 and b3.tobytes() == b1.tobytes()
+    # the groups' bounds through the packed VALU filter: what a process with more than 22 hardware queues gets
+    tpt.set_kernel_variant(3, 3, -1)
+    assert tpt.scene_info()["bounds_on_matrix_cores"] is False
+    r4, b4, _ = gpu_frames(tpt, w, h, 1)
+    assert r4 == r1 and b4.tobytes() == b1.tobytes()
 
 
 def test_grouped_kernel_repeats_exactly_with_many_streams_in_the_process(tpt_defaults):

@@ -135,6 +135,44 @@ def test_the_librarys_own_multi_gpu_path_with_n_processes(n, tmp_path):
     assert "equal the oracle's" in outs[0]
 
 
+_SCENE_INFO = r"""
+import json, sys
+sys.path.insert(0, sys.argv[1])
+from toypathtracer_amd import api
+from toypathtracer_amd.scenes import stress_scene
+api.InitializeTest()
+out = {"default": api.scene_info()}
+s, m = stress_scene(512, 8)
+api.set_scene(s, m)
+out["stress512"] = api.scene_info()
+api.set_kernel_variant(3, 3, -1)
+out["stress512_valu"] = api.scene_info()
+api.ShutdownTest()
+print(json.dumps(out))
+"""
+
+
+@pytest.mark.parametrize("queues, on_matrix", [(None, True), ("22", True), ("24", False), ("32", False)])
+def test_groups_bounds_leave_the_matrix_cores_in_a_process_with_many_queues(queues, on_matrix, tmp_path):
+    """a process that started HIP with GPU_MAX_HW_QUEUES > 22 may be time-sliced by the device, and the matrix-core
+    filter of the groups' bounds then loses candidates now and then.  tptInitialize exports 20 when nobody has set the variable; a host
+    that asked for more gets the packed VALU filter for grouped scenes (same bits, slower), and tptGetSceneInfo says so."""
+    import json
+    lib = build("libtpt_hostemu.so", [])
+    script = tmp_path / "scene_info.py"
+    script.write_text(_SCENE_INFO)
+    env = dict(os.environ, TPT_LIB=lib, HOSTEMU_POLICY="eager")
+    env.pop("TPT_LIB_DIR", None)
+    env.pop("GPU_MAX_HW_QUEUES", None)
+    if queues:
+        env["GPU_MAX_HW_QUEUES"] = queues
+    out = json.loads(subprocess.check_output([sys.executable, str(script), ROOT], env=env, timeout=300).decode().strip().splitlines()[-1])
+    assert out["default"] == dict(spheres=46, groups=0, bounds_on_matrix_cores=False)
+    assert out["stress512"]["spheres"] == 512 and out["stress512"]["groups"] > 0
+    assert out["stress512"]["bounds_on_matrix_cores"] is on_matrix
+    assert out["stress512_valu"]["groups"] == out["stress512"]["groups"] and out["stress512_valu"]["bounds_on_matrix_cores"] is False
+
+
 def test_the_emulation_is_test_infrastructure_only():
     """nothing under toypathtracer_amd/, include/, examples/ or bench.py names the emulation"""
     for base, _, files in os.walk(ROOT):

@@ -5,8 +5,9 @@ a profiling session to find when it was lost:
   * the LDS rings / pair lists / stack level 0 are DS operations -- a volatile access through a generic pointer compiles to a
     FLAT load, which reaches LDS through the vector-memory path (rounds 2-3: flat_load_ushort in the pop and push spins);
   * phase 1 of HitSpheres runs on the matrix cores (v_mfma_f32_32x32x16_f16), 8 of them for the <= 64-sphere table;
-  * 120 VGPRs: four waves per SIMD, i.e. two 8-wave workgroups per CU, and room left for the resolve kernel's waves;
-  * register spills of the headline kernel stay where they were measured (4 VGPRs, 20 B of scratch);
+  * 120 VGPRs for the kernels that stage the scene in LDS: four waves per SIMD, i.e. two 8-wave workgroups per CU, and room left for
+    the resolve kernel's waves; 128 for the grouped-scene instantiations (round 5: 32 -> 22 spilled registers, HBM traffic 11.3 x -> 5.9 x);
+  * register spills stay where they were measured in round 5 (headline: 2 VGPRs, 12 B of scratch, 33 SGPRs spilled to lanes; grouped: 22 VGPRs, 92 B);
   * the hot path holds no IEEE division expansion beyond the cold fallbacks of the short forms (tpt_math.h).
 """
 import os
@@ -100,11 +101,13 @@ def test_register_budget_of_the_queue_kernels(code_object):
             assert m["agpr_count"] == 0
             assert m["max_flat_workgroup_size"] == 512 and m["wavefront_size"] == 64
     head = meta[QUEUE % (1, 0)]
-    assert head["vgpr_spill_count"] <= 4 and head["private_segment_fixed_size"] <= 20, head
-    assert meta[QUEUE % (1, 1)]["vgpr_spill_count"] <= 4
-    # the grouped-scene kernels hold four candidate masks and the dealing state on top: spills measured, bounded here
+    assert head["vgpr_count"] <= 120, head  # (the resolve kernel's waves start beside a machine full of these: DESIGN 3.4)
+    assert head["vgpr_spill_count"] <= 2 and head["private_segment_fixed_size"] <= 12, head
+    assert head["sgpr_spill_count"] <= 36, head  # round 5: 63 -> 33 (scalars made where they are used: uniformHere)
+    assert meta[QUEUE % (1, 1)]["vgpr_count"] <= 120 and meta[QUEUE % (1, 1)]["vgpr_spill_count"] <= 2
+    # the grouped-scene kernels hold four candidate masks and the dealing state on top: 128 registers since round 5
     for batch in (0, 1):
-        assert meta[QUEUE % (0, batch)]["vgpr_spill_count"] <= 32 and meta[QUEUE % (0, batch)]["private_segment_fixed_size"] <= 128
+        assert meta[QUEUE % (0, batch)]["vgpr_spill_count"] <= 22 and meta[QUEUE % (0, batch)]["private_segment_fixed_size"] <= 92, meta[QUEUE % (0, batch)]
 
 
 def test_divisions_of_the_hot_path_are_the_short_forms(code_object):

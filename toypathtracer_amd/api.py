@@ -39,7 +39,7 @@ C_ABI_SYMBOLS = [
     "tptSetSamplesPerPixel", "tptSetConfig", "tptSetSeedMode", "tptSetFoldMode", "tptSetScene", "tptSetCamera", "tptSetStream",
     "tptSetRowShard", "tptLocalRowCount", "tptLocalRowToGlobal", "tptDrawDevice", "tptRayCounterRead", "tptSetRayCounter", "tptSetFrameOverlap", "tptDisplayRGBA8", "tptKernelTimingBegin", "tptKernelTimingEnd",
     "tptSynchronize", "tptTimerBegin", "tptTimerEnd", "tptSetKernelVariant",
-    "tptDrawDeviceBatch", "tptDrawShardedBatch", "tptGetLookaheadHits", "tptCommGetUniqueId", "tptCommInit", "tptCommInitLoopback", "tptCommInfo", "tptCommDestroy", "tptDrawSharded", "tptShardedFinish", "tptGetLaunchInfo", "tptGetPipelineInfo", "tptSetHostBufferMode", "tptSetHostLookahead", "tptSetStreamBatching", "tptSetTileMirror", "tptGetLastError", "tptGetDeviceName",
+    "tptDrawDeviceBatch", "tptDrawShardedBatch", "tptGetLookaheadHits", "tptCommGetUniqueId", "tptCommInit", "tptCommInitLoopback", "tptCommInfo", "tptCommDestroy", "tptDrawSharded", "tptShardedFinish", "tptGetLaunchInfo", "tptGetPipelineInfo", "tptGetSceneInfo", "tptSetHostBufferMode", "tptSetHostLookahead", "tptSetStreamBatching", "tptSetTileMirror", "tptGetLastError", "tptGetDeviceName",
 ]
 # include/tpt_test_hooks.h: exported by the second build (libtoypathtracer_hip_hooks.so) only
 HOOK_SYMBOLS = ["tptTestMath", "tptTestMathExhaustive", "tptTestHitSpheres", "tptTestMatrixFilter", "tptTestGroupFilter", "tptDebugStats", "tptDebugChunkOrder"]
@@ -78,7 +78,7 @@ def _bind(path, hooks):
         "tptSetRayCounter": [p], "tptSetTileMirror": [p, p], "tptSetFrameOverlap": [i], "tptDisplayRGBA8": [p, i, i, p], "tptKernelTimingBegin": [i],
         "tptKernelTimingEnd": [C.POINTER(f), C.POINTER(i)],
         "tptSynchronize": [], "tptTimerBegin": [], "tptTimerEnd": [C.POINTER(f)], "tptSetKernelVariant": [i, i, i],
-        "tptGetLaunchInfo": [C.POINTER(i)] * 4, "tptGetPipelineInfo": [C.POINTER(i)] * 4, "tptCommGetUniqueId": [p], "tptCommInit": [p, i, i, i], "tptCommInitLoopback": [i, i], "tptCommInfo": [C.POINTER(i)] * 3, "tptCommDestroy": [], "tptDrawSharded": [f, i, i, i, p, u], "tptDrawShardedBatch": [f, i, i, i, i, p, u], "tptDrawDeviceBatch": [f, i, i, i, i, p, u], "tptShardedFinish": [C.POINTER(C.c_int64)], "tptSetHostBufferMode": [i], "tptGetLookaheadHits": [C.POINTER(C.c_longlong)], "tptSetHostLookahead": [i], "tptSetStreamBatching": [i],
+        "tptGetLaunchInfo": [C.POINTER(i)] * 4, "tptGetPipelineInfo": [C.POINTER(i)] * 4, "tptGetSceneInfo": [C.POINTER(i)] * 3, "tptCommGetUniqueId": [p], "tptCommInit": [p, i, i, i], "tptCommInitLoopback": [i, i], "tptCommInfo": [C.POINTER(i)] * 3, "tptCommDestroy": [], "tptDrawSharded": [f, i, i, i, p, u], "tptDrawShardedBatch": [f, i, i, i, i, p, u], "tptDrawDeviceBatch": [f, i, i, i, i, p, u], "tptShardedFinish": [C.POINTER(C.c_int64)], "tptSetHostBufferMode": [i], "tptGetLookaheadHits": [C.POINTER(C.c_longlong)], "tptSetHostLookahead": [i], "tptSetStreamBatching": [i],
     }
     if hooks:
         sigs.update({"tptDebugStats": [p, i], "tptDebugChunkOrder": [p, p, i], "tptTestMath": [i, p, p, p, i], "tptTestMathExhaustive": [i, u, u, p, p],
@@ -417,6 +417,13 @@ def pipeline_info():
     v = [C.c_int() for _ in range(4)]
     _chk(load_library().tptGetPipelineInfo(*[C.byref(x) for x in v]), "tptGetPipelineInfo")
     return dict(hw_queues=v[0].value, overlap_effective=v[1].value, stream_depth=v[2].value, slot_reservations=v[3].value)
+
+
+def scene_info():
+    """what the next launch does with the scene: spheres, groups (0: flat), groups' bounds on the matrix cores (False: packed VALU filter)"""
+    v = [C.c_int() for _ in range(3)]
+    _chk(load_library().tptGetSceneInfo(*[C.byref(x) for x in v]), "tptGetSceneInfo")
+    return dict(spheres=v[0].value, groups=v[1].value, bounds_on_matrix_cores=bool(v[2].value))
 
 
 def debug_stats(reset=True):

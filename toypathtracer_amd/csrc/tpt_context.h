@@ -96,6 +96,8 @@ struct Context {
     int foldMode = FOLD_RECURSIVE;
     int allowGroups = 1; // hitSpheres variant 2 = two-phase, brute force even for large scenes
     int useMatrix = 1;   // phase 1 of HitSpheres on the matrix cores where it applies (hitSpheres variant 3 = VALU filter everywhere)
+    bool manyQueues = false; // GPU_MAX_HW_QUEUES > 22 when tptInitialize ran: the process may be time-sliced by the device; grouped scenes keep their
+                             // bounds off the matrix cores then
     int hs = HS_TWO_PHASE, persist = 3, ldsScene = -1; // persist 3 = path queues (falls back to 1 where they do not apply)
     int stripeRows = 0, numParts = 1, part = 0;
     int gridFill = 0;                           // env TPT_GRID_FILL: % of the resident slots all in-flight launches ask for

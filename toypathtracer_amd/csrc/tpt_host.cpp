@@ -54,7 +54,8 @@ int stageScene()
                  offBId = offBSph + align256(bBSph), offAmat = offBId + align256(bBId + 32);
     const size_t bAmat = (g.useMatrix && tptQueueMatrixFilter() && P.mxR1 >= 0) ? P.amatH.size() * sizeof(uint32_t) : 0;
     const size_t offGmat = offAmat + align256(bAmat + 32);
-    const size_t bGmat = (grouped && g.useMatrix && tptQueueMatrixFilter() && P.gmxTiles > 0) ? P.gmatH.size() * sizeof(uint32_t) : 0;
+    // (not in a process that may hold more hardware queues than the device runs side by side: DESIGN.md 2.2)
+    const size_t bGmat = (grouped && g.useMatrix && !g.manyQueues && tptQueueMatrixFilter() && P.gmxTiles > 0) ? P.gmatH.size() * sizeof(uint32_t) : 0;
     const size_t total = offGmat + align256(bGmat + 32);
     if (!S.evUploaded) HIPCHK(hipEventCreateWithFlags(&S.evUploaded, kOrderingEvent));
     // the previous copy out of this staging blob (kSceneSets uploads ago) must have left the host before we overwrite it:
@@ -306,6 +307,13 @@ int tptInitialize(void)
     // and back in -- and that (a) halves the frame rate (round 4) and (b) makes the grouped kernel's long launches return
     // 1-4 wrong pixels in ~8 % of the 4096-sphere frames (round 5: profiles/r05/README.md calls 11-23).
     setenv("GPU_MAX_HW_QUEUES", TPT_DEFAULT_HW_QUEUES, 0);
+    {
+        // a host that asked for more queues itself: a time-sliced process has been seen to lose (ray, group) candidates in the
+        // matrix-core filter of the groups' bounds (1-4 pixels in ~8 % of the 4096-sphere frames) -- grouped scenes then take
+        // the packed VALU filter for their bounds (same bits; 6.05 instead of 8.45 Gray/s at C5).  tptGetSceneInfo tells.
+        const char* q = getenv("GPU_MAX_HW_QUEUES");
+        g.manyQueues = q && atoi(q) > 22;
+    }
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
@@ -672,6 +680,18 @@ int tptGetPipelineInfo(int* outHwQueues, int* outOverlapEffective, int* outStrea
     if (outOverlapEffective) *outOverlapEffective = effectiveOverlap();
     if (outStreamDepth) *outStreamDepth = g.streamDepth;
     if (outSlotReservations) *outSlotReservations = g.slotReservations;
+    return 0;
+}
+
+int tptGetSceneInfo(int* outSpheres, int* outGroups, int* outBoundsOnMatrixCores)
+{
+    if (requireInit()) return -1;
+    if (g.sceneDirty || g.packed.nSpheres != (int)g.spheres.size()) packScene(g.spheres, g.mats, g.packed);
+    const PackedScene& P = g.packed;
+    const bool grouped = g.allowGroups && P.nGroups > 0; // (the same decisions stageScene takes for the next upload)
+    if (outSpheres) *outSpheres = P.nSpheres;
+    if (outGroups) *outGroups = grouped ? P.nGroups : 0;
+    if (outBoundsOnMatrixCores) *outBoundsOnMatrixCores = (grouped && g.useMatrix && !g.manyQueues && tptQueueMatrixFilter() && P.gmxTiles > 0) ? 1 : 0;
     return 0;
 }
 

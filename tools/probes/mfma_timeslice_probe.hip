@@ -1,0 +1,180 @@
+// Stand-alone probe for DESIGN.md 2.2: does a chain of v_mfma_f32_32x32x16_f16 whose A tiles are read from GLOBAL memory give the same
+// answer every time when the process holds more hardware queues than the device runs side by side (the device then time-slices
+// the queues)?  No library code: a table of binary16 A tiles, B operands made from (lane, iteration), the chain of matrixApply
+// (two independent MFMAs on tile 0, two accumulating ones on tile 1), the sign bits of the 32 result registers folded into a
+// per-wave checksum.  The same launch is repeated; every launch must produce the same checksums.
+//
+//   hipcc -O3 --offload-arch=gfx950 -o mfma_timeslice_probe mfma_timeslice_probe.hip
+//   GPU_MAX_HW_QUEUES=32 ./mfma_timeslice_probe <extra streams> <launches> <mode>      mode 0: A from global, 1: A staged in LDS,
+//                                                                                      2: no MFMA (the same loads, VALU fold)
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CHECK(x)                                                                             \
+    do {                                                                                     \
+        hipError_t e_ = (x);                                                                 \
+        if (e_ != hipSuccess) {                                                              \
+            fprintf(stderr, "%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__);      \
+            exit(2);                                                                         \
+        }                                                                                    \
+    } while (0)
+
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+
+constexpr int kTiles = 8;                 // 8 tables of 64 rows: what 512 groups need
+constexpr int kTileVec = 4 * 64;          // uint4 per table: [sphere tile 2][k step 2][lane 64]
+constexpr int kThreads = 512;
+
+__device__ __forceinline__ v8h asH(const uint4& a)
+{
+    v8h h;
+    __builtin_memcpy(&h, &a, 16);
+    return h;
+}
+__device__ __forceinline__ uint32_t mix(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+// binary16 pair with small finite values: exponent field 13..16 (0.25 .. 4), random sign and mantissa
+__device__ __host__ __forceinline__ uint32_t halfPair(uint32_t r)
+{
+    const uint32_t lo = (r & 0x83ffu) | ((13u + ((r >> 10) & 3u)) << 10);
+    const uint32_t hi = ((r >> 16) & 0x83ffu) | ((13u + ((r >> 26) & 3u)) << 10);
+    return lo | (hi << 16);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(kThreads, 4) probe(const uint4* __restrict__ A, int iters, unsigned long long* __restrict__ out)
+{
+    __shared__ uint4 ldsA[MODE == 1 ? kTiles * kTileVec : 1];
+    const int lane = threadIdx.x & 63;
+    if (MODE == 1) {
+        for (int i = threadIdx.x; i < kTiles * kTileVec; i += kThreads) ldsA[i] = A[i];
+        __syncthreads();
+    }
+    const uint4* T = MODE == 1 ? ldsA : A;
+    unsigned long long sum = 0;
+    const uint32_t seed = mix(blockIdx.x * 1315423911u + threadIdx.x);
+    for (int it = 0; it < iters; ++it) {
+        // B operands: two k steps x two ray tiles, 4 registers each
+        uint4 b[4];
+        uint32_t r = mix(seed + (uint32_t)it * 0x9e3779b9u);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            b[k].x = halfPair(r = mix(r + 1u));
+            b[k].y = halfPair(r = mix(r + 2u));
+            b[k].z = halfPair(r = mix(r + 3u));
+            b[k].w = halfPair(r = mix(r + 4u));
+        }
+#pragma unroll 1
+        for (int t = 0; t < kTiles; ++t) {
+            const uint4* P = T + t * kTileVec;
+            uint32_t W0 = 0, W1 = 0;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const uint4 a0 = P[(2 * half + 0) * 64 + lane], a1 = P[(2 * half + 1) * 64 + lane];
+                if (MODE == 2) { // same loads, no matrix cores
+                    W0 = W0 * 31u + (a0.x ^ b[0].x) + (a1.y ^ b[2].y);
+                    W1 = W1 * 31u + (a0.z ^ b[1].z) + (a1.w ^ b[3].w);
+                } else {
+                    v16f c0 = {0}, c1 = {0};
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(asH(a0), asH(b[0]), c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(asH(a0), asH(b[1]), c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(asH(a1), asH(b[2]), c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(asH(a1), asH(b[3]), c1, 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        W0 = __builtin_amdgcn_alignbit(W0, __float_as_uint(c0[q]), 31);
+                        W1 = __builtin_amdgcn_alignbit(W1, __float_as_uint(c1[q]), 31);
+                    }
+                }
+            }
+            sum = sum * 0x100000001b3ull + (((unsigned long long)W0 << 32) | W1);
+        }
+    }
+    out[(size_t)blockIdx.x * kThreads + threadIdx.x] = sum;
+}
+
+__global__ void touch(int* p) { if (p) *p = 1; }
+
+int main(int argc, char** argv)
+{
+    const int extra = argc > 1 ? atoi(argv[1]) : 0, launches = argc > 2 ? atoi(argv[2]) : 40, mode = argc > 3 ? atoi(argv[3]) : 0;
+    const double targetMs = argc > 4 ? atof(argv[4]) : 30.0;
+    CHECK(hipSetDevice(0));
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int blocks = prop.multiProcessorCount * 2;
+    std::vector<uint32_t> hostA((size_t)kTiles * kTileVec * 4);
+    uint32_t r = 12345u;
+    for (auto& w : hostA) {
+        r = r * 1664525u + 1013904223u;
+        w = halfPair(r ^ (r >> 13));
+    }
+    uint4* dA = nullptr;
+    unsigned long long* dOut = nullptr;
+    const size_t nOut = (size_t)blocks * kThreads;
+    CHECK(hipMalloc(reinterpret_cast<void**>(&dA), hostA.size() * 4));
+    CHECK(hipMalloc(reinterpret_cast<void**>(&dOut), nOut * 8));
+    CHECK(hipMemcpy(dA, hostA.data(), hostA.size() * 4, hipMemcpyHostToDevice));
+    std::vector<hipStream_t> streams(extra);
+    for (auto& s : streams) { // every stream used once: it gets its hardware queue
+        CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        hipLaunchKernelGGL(touch, dim3(1), dim3(1), 0, s, (int*)nullptr);
+    }
+    CHECK(hipDeviceSynchronize());
+    hipStream_t main;
+    CHECK(hipStreamCreateWithFlags(&main, hipStreamNonBlocking));
+    auto launch = [&](int iters) {
+        if (mode == 0) hipLaunchKernelGGL(probe<0>, dim3(blocks), dim3(kThreads), 0, main, dA, iters, dOut);
+        else if (mode == 1) hipLaunchKernelGGL(probe<1>, dim3(blocks), dim3(kThreads), 0, main, dA, iters, dOut);
+        else hipLaunchKernelGGL(probe<2>, dim3(blocks), dim3(kThreads), 0, main, dA, iters, dOut);
+        CHECK(hipGetLastError());
+        CHECK(hipStreamSynchronize(main));
+    };
+    // size the launch: ~targetMs each
+    int iters = 64;
+    launch(iters);
+    auto t0 = std::chrono::steady_clock::now();
+    launch(iters);
+    double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    iters = (int)(iters * targetMs / (ms > 0.01 ? ms : 0.01));
+    if (iters < 16) iters = 16;
+    std::vector<unsigned long long> ref(nOut), got(nOut);
+    launch(iters);
+    CHECK(hipMemcpy(ref.data(), dOut, nOut * 8, hipMemcpyDeviceToHost));
+    int bad = 0;
+    size_t badWords = 0;
+    t0 = std::chrono::steady_clock::now();
+    for (int k = 0; k < launches; ++k) {
+        CHECK(hipMemsetAsync(dOut, 0, nOut * 8, main));
+        launch(iters);
+        CHECK(hipMemcpy(got.data(), dOut, nOut * 8, hipMemcpyDeviceToHost));
+        size_t d = 0;
+        for (size_t i = 0; i < nOut; ++i) d += got[i] != ref[i];
+        if (d) {
+            ++bad;
+            badWords += d;
+            if (bad <= 3) {
+                for (size_t i = 0; i < nOut; ++i)
+                    if (got[i] != ref[i]) {
+                        printf("  launch %d: thread %zu (block %zu wave %zu lane %zu) %016llx instead of %016llx (%zu threads differ)\n", k, i, i / kThreads,
+                               (i % kThreads) / 64, i % 64, got[i], ref[i], d);
+                        break;
+                    }
+            }
+        }
+    }
+    ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    printf("mode %d (%s), %d extra streams, GPU_MAX_HW_QUEUES=%s: %d of %d launches differ from the first (%zu thread sums), %d iterations per wave, %.1f ms per launch\n",
+           mode, mode == 0 ? "A from global memory" : mode == 1 ? "A staged in LDS" : "no MFMA", extra, getenv("GPU_MAX_HW_QUEUES") ? getenv("GPU_MAX_HW_QUEUES") : "(unset)",
+           bad, launches, badWords, iters, ms / launches);
+    return 0;
+}

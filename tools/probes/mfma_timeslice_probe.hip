@@ -9,7 +9,8 @@
 //                                                                                      2: no MFMA (the same loads, VALU fold)
 //   mode 3 = mode 0 plus ingredients of the grouped kernel, argv[5] = feature mask: 1 per-lane gathers in flight around the chain,
 //   2 a per-wave LDS pair list (returning ds_add, list write / read, ds_min_u64), 4 ~48 more live registers, 8 LDS request padded to
-//   81 920 B per workgroup (two workgroups fill a CU), 16 a dynamically indexed private array (scratch)
+//   81 920 B per workgroup (two workgroups fill a CU), 16 a dynamically indexed private array (scratch), 32 v_permlane32_swap on the masks
+//   and on B operands with gathers in flight
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -174,6 +175,15 @@ __global__ void __launch_bounds__(kThreads, 4) probeLike(const uint4* __restrict
                 for (int j = 0; j < 48; ++j) acc[j] = acc[j] * 1.0001f + __uint_as_float((W0 >> (j & 15)) & 0x3f800000u);
             }
             if (feat & 16) priv[(W1 + (unsigned)lane) & 15u] += 1.0f;
+            if (feat & 32) { // v_permlane32_swap on the masks (as at the end of matrixApply) and on a B operand pair, with gathers in flight
+                const uint4* M2 = members + (size_t)(mix(r + 77u + (uint32_t)t) & 4095u) * 8u;
+                const uint4 h0 = M2[4], h1 = M2[5];
+                auto sw = __builtin_amdgcn_permlane32_swap(W0, W1, false, false);
+                W0 = sw[0]; W1 = sw[1];
+                auto sb = __builtin_amdgcn_permlane32_swap(b[0].x, b[1].x, false, false);
+                W0 += sb[0]; W1 ^= sb[1];
+                W0 ^= h0.x ^ h1.w;
+            }
             if (feat & 1) W0 ^= g0.x ^ g1.y ^ g2.z ^ g3.w;
             sum = sum * 0x100000001b3ull + (((unsigned long long)W0 << 32) | W1);
         }

@@ -173,6 +173,16 @@ def test_groups_bounds_leave_the_matrix_cores_in_a_process_with_many_queues(queu
     assert out["stress512_valu"]["groups"] == out["stress512"]["groups"] and out["stress512_valu"]["bounds_on_matrix_cores"] is False
 
 
+def test_a_grouped_scene_renders_the_same_with_its_bounds_off_the_matrix_cores():
+    """the scene / camera change scenario (a 300-sphere scene enters a stream) in a process that exported 32 hardware queues: the scene
+    set is staged without the groups' matrix table, the launches take the packed VALU filter, every frame still equals the oracle"""
+    lib = build("libtpt_hostemu.so", [])
+    env = dict(os.environ, TPT_LIB=lib, HOSTEMU_POLICY="lazy", GPU_MAX_HW_QUEUES="32")
+    env.pop("TPT_LIB_DIR", None)
+    p = subprocess.run([sys.executable, os.path.join(HERE, "hostemu_driver.py"), "custom scene and camera"], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0, p.stdout.decode()[-3000:]
+
+
 def test_the_emulation_is_test_infrastructure_only():
     """nothing under toypathtracer_amd/, include/, examples/ or bench.py names the emulation"""
     for base, _, files in os.walk(ROOT):

@@ -525,7 +525,11 @@ def main():
                        "flags": "progressive|animate" if args.animate else "progressive",
                        "sharding": "none" if world == 1 else "row stripes of %d, round-robin over %d ranks, pipelined gather to rank 0" % (args.stripe_rows, world),
                        "device": api.device_name(), "grid_blocks": info["grid_blocks"], "blocks_per_cu": info["blocks_per_cu"],
-                       "lds_bytes_per_block": info["lds_bytes"]},
+                       "lds_bytes_per_block": info["lds_bytes"],
+                       # grouped scenes: whether the groups' bounds are filtered on the matrix cores (not in a process that started HIP
+                       # with more than 22 hardware queues: DESIGN.md 2.2) -- and the queues this process asked for
+                       "groups": api.scene_info()["groups"], "bounds_on_matrix_cores": api.scene_info()["bounds_on_matrix_cores"],
+                       "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
             "rays_per_step": rays_total / args.steps,
             "trace_launch_ms_avg": k_ms,
             "pipeline_ms_per_step": p_ms,

@@ -37,7 +37,15 @@ build() {  # name, flags...
         for kv in $REDEF; do extra="$extra\\n#undef ${kv%% *}\\n#define $kv"; done
         unset IFS
     fi
-    ( cd "$TMP" && sed "/#include <atomic>/a #undef DO_SAMPLES_PER_PIXEL\\n#define DO_SAMPLES_PER_PIXEL g_tpt_ref_spp\\nextern int g_tpt_ref_spp;$extra" "$S/Test.cpp" \
+    # PERPIXEL=1: the reference's own GPU seed (ComputeShader.hlsl:380, Shaders.metal:401: one RNG stream per pixel and frame)
+    # put in front of the pixel body of TraceRowJob (Test.cpp:281-282), again only in the stream the compiler reads.  This is
+    # the seed mode the product runs by default; everything else of the build stays the reference's scalar CPU path.
+    local seed=""
+    if [ -n "$PERPIXEL" ]; then
+        seed='s/for (int x = 0; x < data.screenWidth; ++x)/& if ((state = ((uint32_t)x * 1973 + y * 9277 + (uint32_t)data.frameCount * 26699) | 1), true)/'
+        grep -q 'for (int x = 0; x < data.screenWidth; ++x)' "$S/Test.cpp" || { echo "build_ref.sh: Test.cpp:281 not found" >&2; exit 1; }
+    fi
+    ( cd "$TMP" && sed -e "/#include <atomic>/a #undef DO_SAMPLES_PER_PIXEL\\n#define DO_SAMPLES_PER_PIXEL g_tpt_ref_spp\\nextern int g_tpt_ref_spp;$extra" -e "$seed" "$S/Test.cpp" \
         | g++ $common "$@" -x c++ -c - -o "$TMP/$name.Test.o" )
     g++ $common "$@" -c "$S/Maths.cpp" -o "$TMP/$name.Maths.o"
     g++ $common "$@" -c "$S/enkiTS/TaskScheduler.cpp" -o "$TMP/$name.ts.o"
@@ -56,4 +64,6 @@ build libtpt_ref_fast -O3 -msse4.1 -mavx2 -mfma -ffast-math
 REDEF="DO_LIGHT_SAMPLING 0" build libtpt_ref_nols -O2 -ffp-contract=off -D__EMSCRIPTEN__ -D__EMSCRIPTEN_PTHREADS__
 REDEF="DO_MITSUBA_COMPARE 1" build libtpt_ref_mitsuba -O2 -ffp-contract=off -D__EMSCRIPTEN__ -D__EMSCRIPTEN_PTHREADS__
 REDEF="DO_ANIMATE_SMOOTHING 0.5f" build libtpt_ref_smooth05 -O2 -ffp-contract=off -D__EMSCRIPTEN__ -D__EMSCRIPTEN_PTHREADS__
-echo "built $OUT/libtpt_ref.so $OUT/libtpt_ref_scalar.so $OUT/libtpt_ref_fast.so + Config.h variants (nols, mitsuba, smooth05)"
+# the scalar path with the reference's GPU seed formula: pins the product's default seed mode to reference-compiled code
+PERPIXEL=1 build libtpt_ref_perpixel -O2 -ffp-contract=off -D__EMSCRIPTEN__ -D__EMSCRIPTEN_PTHREADS__
+echo "built $OUT/libtpt_ref.so $OUT/libtpt_ref_scalar.so $OUT/libtpt_ref_fast.so + Config.h variants (nols, mitsuba, smooth05) + libtpt_ref_perpixel.so"

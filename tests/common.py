@@ -13,6 +13,16 @@ def goldens():
     return json.load(open(os.path.join(HERE, "golden", "goldens.json")))["cases"]
 
 
+def per_pixel_goldens():
+    """Golden vectors of the product's default seed mode made by REFERENCE-COMPILED code: the reference's scalar CPU path with its own
+    GPU seed formula (ComputeShader.hlsl:380) put in front of TraceRowJob's pixel body by oracle/build_ref.sh (PERPIXEL=1)."""
+    return json.load(open(os.path.join(HERE, "golden", "goldens.json")))["per_pixel_cases"]
+
+
+def case_id(c):
+    return "%dx%dx%d_f%d_fl%d" % (c["width"], c["height"], c["spp"], c["frames"], c["flags"])
+
+
 def config_goldens():
     """Golden vectors of the reference's scalar path built with one of Config.h's other switches re-defined."""
     return json.load(open(os.path.join(HERE, "golden", "goldens.json")))["config_cases"]

@@ -46,6 +46,38 @@ CONFIG_CASES = [
 ]
 
 
+# The product's default seed mode (one RNG stream per pixel and frame, ComputeShader.hlsl:380 / Shaders.metal:401) made by
+# REFERENCE-COMPILED code: oracle/_ref/libtpt_ref_perpixel.so is the scalar path above with that one formula put in front
+# of TraceRowJob's pixel body (oracle/build_ref.sh, PERPIXEL=1).  w, h, spp, frames, flags, time
+PER_PIXEL_CASES = [
+    (640, 360, 1, 1, FLAG_PROGRESSIVE, 0.0),    # C1
+    (640, 360, 4, 1, FLAG_PROGRESSIVE, 0.0),
+    (1280, 720, 4, 1, FLAG_PROGRESSIVE, 0.0),   # C2, F = 1, 2, 3, 10
+    (1280, 720, 4, 2, FLAG_PROGRESSIVE, 0.0),
+    (1280, 720, 4, 3, FLAG_PROGRESSIVE, 0.0),
+    (1280, 720, 4, 10, FLAG_PROGRESSIVE, 0.0),
+    (1280, 720, 4, 41, FLAG_PROGRESSIVE, 0.0),  # the frames `bench.py --steps 20 --warmup 5` renders (16 priming + 5 + 20)
+    (203, 117, 4, 2, FLAG_PROGRESSIVE, 0.0),    # ragged
+    (203, 117, 1, 2, FLAG_PROGRESSIVE, 0.0),
+    (203, 117, 8, 2, FLAG_PROGRESSIVE, 0.0),
+    (203, 117, 16, 2, FLAG_PROGRESSIVE, 0.0),
+    (320, 180, 4, 2, 0, 0.0),                   # no progressive accumulation
+    (3840, 2160, 16, 1, FLAG_PROGRESSIVE, 0.0), # C3 / C4, whole frame
+    (320, 180, 4, 3, FLAG_PROGRESSIVE | FLAG_ANIMATE, 0.75),  # moves spheres: last
+]
+
+
+def per_pixel():
+    ref = Ref.get("perpixel")
+    out = []
+    for (w, h, spp, frames, flags, t) in PER_PIXEL_CASES:
+        rays, bb = ref.render_frames(w, h, spp, frames, flags, time=t)
+        out.append(dict(width=w, height=h, spp=spp, frames=frames, flags=flags, time=t, rays=int(rays), fnv="%08x" % fnv1a(bb),
+                        mean_rgb=[float(bb[..., c].mean(dtype=np.float64)) for c in range(3)]))
+        print(out[-1])
+    return out
+
+
 def main():
     ref = Ref.get("scalar")
     simd = Ref.get("simd")
@@ -70,7 +102,10 @@ def main():
         cfg.append(dict(variant=variant, width=w, height=h, spp=spp, frames=frames, flags=flags, time=t, rays=int(rays),
                         fnv="%08x" % fnv1a(bb), mean_rgb=[float(bb[..., c].mean(dtype=np.float64)) for c in range(3)]))
         print(cfg[-1])
-    json.dump(dict(config_cases=cfg, source="oracle/_ref/libtpt_ref_scalar.so (pristine /root/reference scalar path, g++ -O2 -ffp-contract=off "
+    json.dump(dict(config_cases=cfg, per_pixel_cases=per_pixel(),
+                   per_pixel_source="oracle/_ref/libtpt_ref_perpixel.so: the same scalar-path build with the reference's own GPU seed formula "
+                                    "(ComputeShader.hlsl:380) injected at Test.cpp:281 by oracle/build_ref.sh (sed on the compiler's input stream)",
+                   source="oracle/_ref/libtpt_ref_scalar.so (pristine /root/reference scalar path, g++ -O2 -ffp-contract=off "
                           "-D__EMSCRIPTEN__ -D__EMSCRIPTEN_PTHREADS__); simd_* = oracle/_ref/libtpt_ref.so",
                    cases=out), open(os.path.join(HERE, "goldens.json"), "w"), indent=1)
 

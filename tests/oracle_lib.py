@@ -168,6 +168,8 @@ class Ref:
     _inst = {}
     FILES = {"scalar": "libtpt_ref_scalar.so", "simd": "libtpt_ref.so", "fast": "libtpt_ref_fast.so",
              # scalar path with one of Config.h's other switches re-defined (oracle/build_ref.sh)
+             # scalar path seeded per pixel with the reference's GPU formula (ComputeShader.hlsl:380; oracle/build_ref.sh PERPIXEL=1)
+             "perpixel": "libtpt_ref_perpixel.so",
              "nols": "libtpt_ref_nols.so", "mitsuba": "libtpt_ref_mitsuba.so", "smooth05": "libtpt_ref_smooth05.so"}
 
     @classmethod

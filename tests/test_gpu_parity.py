@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from common import config_goldens, config_kwargs, goldens, oracle_frames, rel_err
+from common import case_id, config_goldens, config_kwargs, goldens, oracle_frames, per_pixel_goldens, rel_err
 from oracle_lib import (FLAG_ANIMATE, FLAG_PROGRESSIVE, FOLD_FORWARD, FOLD_RECURSIVE, SEED_PER_PIXEL, SEED_ROW_SERIAL,
                         fnv1a)
 
@@ -59,6 +59,21 @@ def test_row_serial_batched_launch_reproduces_reference_golden_hashes(tpt_defaul
     bb = tile.cpu().numpy()
     assert rays == case["rays"]
     assert "%08x" % fnv1a(bb) == case["fnv"]
+
+
+# ---- 1b. the production seed mode against REFERENCE-COMPILED goldens (no oracle in between)
+@pytest.mark.parametrize("case", per_pixel_goldens(), ids=case_id)
+def test_per_pixel_mode_reproduces_reference_compiled_golden_hashes(tpt_defaults, case):
+    """The headline mode -- one RNG stream per pixel and frame -- directly against hashes made by the reference's scalar CPU path
+    compiled from /root/reference with its own GPU seed formula (ComputeShader.hlsl:380) injected at Test.cpp:281
+    (oracle/build_ref.sh PERPIXEL=1, tests/golden/make_golden.py): C1, C2 for F = 1, 2, 3, 10 and 41 (the frames the driver's bench
+    command renders: 4f725972), C3's whole frame, ragged sizes, spp 1 / 8 / 16, no accumulation, kFlagAnimate."""
+    tpt = tpt_defaults
+    tpt.set_samples_per_pixel(case["spp"])
+    rays, bb, _ = gpu_frames(tpt, case["width"], case["height"], case["frames"], case["flags"], case["time"])
+    assert rays == case["rays"]
+    assert "%08x" % fnv1a(bb) == case["fnv"]
+    assert float(np.abs(bb[..., 3]).max()) == 0.0
 
 
 # ---- 2. production mode (per-pixel seeds) against the oracle, every kernel variant

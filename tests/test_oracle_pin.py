@@ -4,7 +4,7 @@ present, live bit-for-bit comparison."""
 import numpy as np
 import pytest
 
-from common import config_goldens, config_kwargs, goldens, golden_scene, oracle_frames
+from common import case_id, config_goldens, config_kwargs, goldens, golden_scene, oracle_frames, per_pixel_goldens
 from oracle_lib import (FLAG_PROGRESSIVE, FOLD_FORWARD, FOLD_RECURSIVE, MATH_LIBM, MATH_TPT, SEED_PER_PIXEL,
                         SEED_ROW_SERIAL, fnv1a)
 
@@ -32,6 +32,40 @@ def test_oracle_config_switches_match_reference_variants(oracle, case):
                                 cam=cam, seed_mode=SEED_ROW_SERIAL, math_mode=MATH_LIBM, **kw)
     assert rays == case["rays"]
     assert "%08x" % fnv1a(bb) == case["fnv"]
+
+
+@pytest.mark.parametrize("case", [c for c in per_pixel_goldens() if c["width"] * c["height"] * c["spp"] * c["frames"] <= 4e7], ids=case_id)
+def test_oracle_per_pixel_mode_reproduces_reference_compiled_goldens(oracle, case):
+    """The product's default seed mode (one RNG stream per pixel and frame) pinned to the REFERENCE ITSELF: the goldens come from
+    oracle/_ref/libtpt_ref_perpixel.so -- the reference's scalar CPU path compiled from /root/reference with its own GPU seed
+    formula (ComputeShader.hlsl:380, Shaders.metal:401) injected at Test.cpp:281 (oracle/build_ref.sh PERPIXEL=1,
+    tests/golden/make_golden.py) -- not from the restatement.  The big cases (C2 x 41 frames = the bench's hash, C3) are
+    asserted on the GPU (tests/test_gpu_parity.py) and by bench.py."""
+    rays, bb, _ = oracle_frames(oracle, case["width"], case["height"], case["spp"], case["frames"], case["flags"], case["time"],
+                                seed_mode=SEED_PER_PIXEL, math_mode=MATH_TPT, fold_mode=FOLD_RECURSIVE)
+    assert rays == case["rays"]
+    assert "%08x" % fnv1a(bb) == case["fnv"]
+    for c in range(3):
+        assert abs(float(bb[..., c].mean(dtype=np.float64)) - case["mean_rgb"][c]) < 1e-12
+
+
+def test_per_pixel_goldens_hold_the_headline_cases():
+    """C1, C2 (F = 1, 2, 3, 10 and the 41 frames of the driver's bench command) and C3 are in the fixture; the 41-frame hash is
+    the one BENCH_r05.json reported for the timed run (4f725972, 689 335 686 rays)."""
+    by = {(c["width"], c["height"], c["spp"], c["frames"], c["flags"]): c for c in per_pixel_goldens()}
+    assert by[(1280, 720, 4, 41, 2)]["fnv"] == "4f725972" and by[(1280, 720, 4, 41, 2)]["rays"] == 689335686
+    for key in [(640, 360, 1, 1, 2), (1280, 720, 4, 1, 2), (1280, 720, 4, 2, 2), (1280, 720, 4, 3, 2), (1280, 720, 4, 10, 2), (3840, 2160, 16, 1, 2)]:
+        assert key in by
+
+
+@pytest.mark.parametrize("w,h,spp,frames", [(96, 54, 1, 1), (160, 90, 4, 2), (131, 77, 8, 2)])
+def test_oracle_per_pixel_vs_live_reference_build(oracle, w, h, spp, frames):
+    from oracle_lib import Ref
+    if not Ref.available("perpixel"):
+        pytest.skip("oracle/_ref/libtpt_ref_perpixel.so not built (no /root/reference)")
+    rr, rb = Ref.get("perpixel").render_frames(w, h, spp, frames)
+    ro, ob, _ = oracle_frames(oracle, w, h, spp, frames, seed_mode=SEED_PER_PIXEL, math_mode=MATH_LIBM)
+    assert rr == ro and rb.tobytes() == ob.tobytes()
 
 
 def test_scalar_and_simd_reference_agree_on_static_scenes():

@@ -56,6 +56,9 @@ PEAK_VALU_GINSTR = 256 * 4 * 2.4 / 2  # G wave64 VALU instructions per second: e
 FLOP_PER_SPHERE_TEST = 17      # per (ray, sphere) test
 FLAG_PROGRESSIVE = 2
 FLAG_ANIMATE = 1
+PORT_TAKEN_RC = 98             # exit code of a rank whose rendezvous port was already in use (EADDRINUSE): self_launch retries with another port
+# set by launchers that start one process per rank themselves (Open MPI, MPICH / PMI, Slurm): bench.py must not spawn N more ranks under them
+FOREIGN_LAUNCHER_VARS = ("OMPI_COMM_WORLD_SIZE", "PMI_SIZE", "PMIX_RANK", "SLURM_NTASKS", "SLURM_PROCID")
 
 
 def cpu_model():
@@ -244,6 +247,128 @@ def row_serial_batched_rate(api, torch, width, height, per_launch=32, launches=8
     return dt / (launches * per_launch) * 1e3, rays / dt / 1e6
 
 
+def golden_case(section, **key):
+    """A committed golden vector of tests/golden/goldens.json (per_pixel_cases: made by the reference-compiled per-pixel build,
+    oracle/build_ref.sh PERPIXEL=1; oracle_cases: made by oracle/tpt_oracle.c for the scene the reference does not have)."""
+    path = os.path.join(ROOT, "tests", "golden", "goldens.json")
+    if not os.path.exists(path):
+        return None
+    for c in json.load(open(path)).get(section, []):
+        if all(c.get(k) == v for k, v in key.items()):
+            return c
+    return None
+
+
+def static_counters(workload, grid_blocks):
+    """HBM bytes and executed VALU wave-instructions per trace launch for this workload at this launch geometry, from
+    profiles/pmc_traffic.json (rocprofv3 --pmc passes serialise kernels: never taken inside a timed region)."""
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(tpath):
+        return None
+    return json.load(open(tpath)).get("by_workload_and_grid", {}).get(workload, {}).get(str(grid_blocks))
+
+
+def secondary_leg(api, torch, name, untimed, steps, overlap):
+    """A short fenced leg of another BASELINE.json config behind the headline run: frames 0 .. untimed + steps - 1 of workload `name`
+    blended into one zeroed device tile, the last `steps` of them timed (barrier-less at N = 1: synchronise on both sides, HIP
+    events around the region and around every trace launch), the final image hash and the ray total compared with a COMMITTED
+    golden vector -- reference-compiled for the default scene, the oracle's for the 4096-sphere scene (whose frames 0-2 are
+    checked one per tile before the timed frames).  -> dict for the JSON line's "secondary" object."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_lib import fnv1a
+    width, height, spp, scene, label = WORKLOADS[name]
+    api.set_scene(None)
+    api.set_camera(None)
+    n_spheres = 46
+    if scene == "stress":
+        from toypathtracer_amd.scenes import STRESS_CAMERA, stress_scene
+        s, m = stress_scene(4096, 64)
+        api.set_scene(s, m)
+        api.set_camera(**STRESS_CAMERA)
+        n_spheres = 4096
+    api.set_samples_per_pixel(spp)
+    api.set_frame_overlap(overlap)
+    out = {"workload": label, "steps": steps, "untimed_frames": untimed, "frame_overlap": overlap}
+    pre = []
+    if scene == "stress":  # parity first: frames 0, 1, 2, each into its own zeroed tile, in flight together -- the oracle's hashes
+        tiles = [torch.zeros((height, width, 4), dtype=torch.float32, device="cuda") for _ in range(3)]
+        r0 = api.ray_counter_read()
+        for f in range(3):
+            api.UpdateTest(0.0, f, width, height, FLAG_PROGRESSIVE)
+            api.draw_device(0.0, f, width, height, tiles[f].data_ptr(), FLAG_PROGRESSIVE)
+        rays3 = api.ray_counter_read() - r0
+        want = [golden_case("oracle_cases", name="c5", frame=f) for f in range(3)]
+        got = ["%08x" % fnv1a(t.cpu().numpy()) for t in tiles]
+        pre = got
+        if all(want):
+            out.update(parity_checked=True, parity_ok=bool(got == [c["fnv"] for c in want] and rays3 == sum(c["rays"] for c in want)),
+                       parity_source="tests/golden/goldens.json oracle_cases (oracle/tpt_oracle.c, brute force over the 4096 spheres; the reference has no such scene): "
+                                     "frames 0-2, one zeroed tile each, three in flight", parity_image_fnv=got, parity_rays=int(rays3))
+        else:
+            out.update(parity_checked=False, parity_note="no committed hash for this workload")
+        del tiles
+    tile = torch.zeros((height, width, 4), dtype=torch.float32, device="cuda")
+    ra = api.ray_counter_read()
+    for f in range(untimed):
+        api.UpdateTest(0.0, f, width, height, FLAG_PROGRESSIVE)
+        api.draw_device(0.0, f, width, height, tile.data_ptr(), FLAG_PROGRESSIVE)
+    api.synchronize()
+    torch.cuda.synchronize()
+    r0 = api.ray_counter_read()
+    api.kernel_timing_begin(steps)
+    api.timer_begin()
+    t0 = time.perf_counter()
+    for f in range(untimed, untimed + steps):
+        api.UpdateTest(0.0, f, width, height, FLAG_PROGRESSIVE)
+        api.draw_device(0.0, f, width, height, tile.data_ptr(), FLAG_PROGRESSIVE)
+    pipeline_ms = api.timer_end()
+    api.synchronize()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    launch_ms_sum, launches = api.kernel_timing_end()
+    rays = api.ray_counter_read() - r0
+    rays_all = api.ray_counter_read() - ra
+    info = api.launch_info()
+    sinfo = api.scene_info()
+    k_ms = launch_ms_sum / max(launches, 1)
+    fpl = steps / max(launches, 1)            # frames per launch (the library batches small frames of a stream)
+    p_ms = pipeline_ms / steps
+    img = np.ascontiguousarray(tile.cpu().numpy(), np.float32)
+    out.update(value=rays / dt / 1e6, unit="Mray/s", ms_per_step=dt / steps * 1e3, pipeline_ms_per_step=p_ms, trace_launch_ms_avg=k_ms,
+               frames_per_launch=fpl, rays_per_step=rays / steps, image_fnv="%08x" % fnv1a(img), grid_blocks=info["grid_blocks"],
+               blocks_per_cu=info["blocks_per_cu"], groups=sinfo["groups"], bounds_on_matrix_cores=sinfo["bounds_on_matrix_cores"])
+    if scene == "default":
+        c = golden_case("per_pixel_cases", width=width, height=height, spp=spp, frames=untimed + steps, flags=FLAG_PROGRESSIVE)
+        if c:
+            out.update(parity_checked=True, parity_ok=bool(out["image_fnv"] == c["fnv"] and int(rays_all) == c["rays"]), golden_fnv=c["fnv"], golden_rays=c["rays"], run_rays=int(rays_all),
+                       parity_source="tests/golden/goldens.json per_pixel_cases: the reference's scalar CPU path compiled from /root/reference with its own GPU seed "
+                                     "formula injected (oracle/build_ref.sh PERPIXEL=1), frames 0-%d on a zeroed tile" % (untimed + steps - 1))
+        else:
+            out.update(parity_checked=False, parity_note="no committed hash for %d frames of this workload" % (untimed + steps))
+    # rooflines, per launch and for the chip (see the headline's objects): HBM write (north_star), then what binds
+    px = width * height * fpl
+    hbm = px * 16 / (p_ms * fpl * 1e-3) / 1e9
+    ent = static_counters(name, info["grid_blocks"]) if fpl == 1 else None
+    out["roofline"] = {"bound": "hbm", "achieved": hbm, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm / PEAK_HBM_GBS,
+                       "traffic": ent["bytes_per_launch"] if ent else None, "traffic_static": True, "traffic_source": ent["source"] if ent else None,
+                       "launch_ms_avg": k_ms, "launches": launches, "kernel": "tptTraceQueueKernel"}
+    if sinfo["groups"] > 0:
+        vi = ent.get("valu_insts_per_launch") if ent else None
+        g = vi / (p_ms * fpl * 1e-3) / 1e9 if vi else None
+        out["roofline_valu"] = {"bound": "valu_issue", "achieved": g, "peak": PEAK_VALU_GINSTR, "unit": "G wave-instr/s", "frac": g / PEAK_VALU_GINSTR if g else None,
+                                "insts_per_launch": vi, "static": True, "source": ent.get("valu_source") if ent else None,
+                                "brute_force_equivalent_tflops": rays / steps * FLOP_PER_SPHERE_TEST * n_spheres / (p_ms * 1e-3) / 1e12}
+    else:
+        tf = rays / steps * FLOP_PER_SPHERE_TEST * n_spheres / (p_ms * 1e-3) / 1e12
+        out["roofline_valu"] = {"bound": "valu_fp32", "achieved": tf, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_TFLOPS}
+        if ent and ent.get("valu_insts_per_launch"):
+            g = ent["valu_insts_per_launch"] / (p_ms * fpl * 1e-3) / 1e9
+            out["valu_issue"] = {"insts_per_launch": ent["valu_insts_per_launch"], "achieved": g, "peak": PEAK_VALU_GINSTR, "unit": "G wave-instr/s", "frac": g / PEAK_VALU_GINSTR, "static": True}
+    del tile
+    return out
+
+
+
 def self_launch(n):
     """`python bench.py --gpus N` without a launcher: this command once per GPU of this node, with the environment
     torch.distributed.run would give each rank (RANK / LOCAL_RANK / WORLD_SIZE, rendezvous on 127.0.0.1 at a free port).
@@ -251,31 +376,36 @@ def self_launch(n):
     import socket
     import subprocess
     import time as _time
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1"))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
-    rc, failed_at = 0, None
-    while procs:
-        for p in list(procs):
-            code = p.poll()
-            if code is None:
-                continue
-            procs.remove(p)
-            if code != 0 and rc == 0:
-                rc, failed_at = code, _time.monotonic()
-        # the others would wait for the failed rank in a collective for ever -- but give them the time to say what THEY found first
-        # (a rank still importing torch on a busy host has not printed its own "needs a GPU" yet)
-        if failed_at is not None and _time.monotonic() - failed_at > 60.0:
-            for q in procs:
-                q.terminate()
-            failed_at = float("inf")
-        _time.sleep(0.05)
+    rc = 0
+    for attempt in range(3):  # the rendezvous port is found by binding and closing a socket: another process may take it in between
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        procs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "1"))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        rc, failed_at = 0, None
+        while procs:
+            for p in list(procs):
+                code = p.poll()
+                if code is None:
+                    continue
+                procs.remove(p)
+                if code != 0 and rc == 0:
+                    rc, failed_at = code, _time.monotonic()
+            # the others would wait for the failed rank in a collective for ever -- but give them the time to say what THEY found first
+            # (a rank still importing torch on a busy host has not printed its own "needs a GPU" yet)
+            if failed_at is not None and _time.monotonic() - failed_at > 60.0:
+                for q in procs:
+                    q.terminate()
+                failed_at = float("inf")
+            _time.sleep(0.05)
+        if rc != PORT_TAKEN_RC:
+            return rc
+        print("bench.py: rendezvous port %d was taken by another process, trying another one (%d / 3)" % (port, attempt + 1), file=sys.stderr, flush=True)
     return rc
 
 
@@ -289,6 +419,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the host-pointer DrawTest and ROW_SERIAL legs after the timed region")
     ap.add_argument("--extras", default="host,sync,batched,row_serial", help="which secondary legs run after the timed region (comma list of host, sync, batched, row_serial)")
+    ap.add_argument("--secondary", default="auto",
+                    help="short fenced legs of the other configs behind the headline run, each with its own roofline objects and a parity flag "
+                         "against a committed golden hash (comma list of c2_steady, c3, c5; auto = all three when the headline is the default "
+                         "1-GPU configs[1] run, none otherwise; none = skip)")
     ap.add_argument("--hit-spheres", type=int, default=0, help="0 two-phase: matrix-core filter for <= 64 spheres, grouped traversal for >= 256 (default); 1 simple loop; 2 two-phase brute force; 3 as 0 with the packed VALU filter instead of the matrix-core one")
     ap.add_argument("--persistent", type=int, default=3, choices=[1, 3], help="3 path queues (default) 1 persistent waves with lane refill (the fallback kernel)")
     ap.add_argument("--fold", type=int, default=0, help="0 recursive (reference order, default) 1 forward")
@@ -317,6 +451,10 @@ def main():
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        foreign = [v for v in FOREIGN_LAUNCHER_VARS if v in os.environ]
+        if foreign:
+            sys.exit("bench.py: started under another launcher (%s is set) without RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment: "
+                     "export those per rank (as torch.distributed.run does) instead of letting every rank spawn %d more" % (foreign[0], args.gpus))
         # typed the way the driver types its 1-GPU run (`python3 bench.py --gpus N ...`): launch the ranks ourselves
         sys.exit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
@@ -338,7 +476,13 @@ def main():
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        except Exception as e:  # noqa: BLE001 -- rank 0 could not bind the rendezvous port: tell self_launch to pick another one
+            if "EADDRINUSE" in str(e) or "address already in use" in str(e).lower():
+                print("%s: %s" % (who, e), file=sys.stderr)
+                sys.exit(PORT_TAKEN_RC)
+            raise
 
     from toypathtracer_amd import api
     from toypathtracer_amd.sharding import ShardedFrame
@@ -506,7 +650,7 @@ def main():
                     valu_insts, valu_src = ent["valu_insts_per_launch"], ent.get("valu_source", ent["source"])
         # EXECUTED vector work (SQ_INSTS_VALU wave-instructions per launch, a static figure like the traffic) over the pipeline time
         # per frame, against one wave64 VALU instruction per SIMD every 2 cycles (MI355X_MICROARCH.md): what the VALU pipes really do
-        grouped = n_spheres >= 256 and args.hit_spheres == 0
+        grouped = api.scene_info()["groups"] > 0  # (what the launch really does: a scene the grouping refuses is traversed flat and keeps the flop roofline)
         issue = None
         if valu_insts:
             g_instr_s = valu_insts / (pl_ms * 1e-3) / 1e9
@@ -573,6 +717,14 @@ def main():
             from oracle_lib import fnv1a
             out.update(image_fnv="%08x" % fnv1a(np.ascontiguousarray(image.detach().cpu().numpy(), np.float32)), parity_checked=False,
                        parity_note="oracle leg runs for the static default scene only (this workload's parity: tests/test_gpu_parity.py); image_fnv lets two runs of the same frames be compared")
+        if scene == "default" and not args.animate and world == 1:
+            # ... and against the REFERENCE ITSELF where a golden vector for exactly these frames is committed (41 = the driver's
+            # command, 236 = the default command): made by the reference's scalar CPU path compiled with its own GPU seed formula
+            c = golden_case("per_pixel_cases", width=width, height=height, spp=spp, frames=total_frames, flags=FLAG_PROGRESSIVE)
+            if c:
+                out["reference_golden"] = {"fnv": c["fnv"], "rays": c["rays"], "ok": bool(out["image_fnv"] == c["fnv"] and int(rays_all_frames) == c["rays"]),
+                                           "source": "tests/golden/goldens.json per_pixel_cases (oracle/_ref/libtpt_ref_perpixel.so: Test.cpp + Maths.cpp compiled from "
+                                                     "/root/reference, ComputeShader.hlsl:380's seed injected at Test.cpp:281), frames 0-%d" % (total_frames - 1)}
         extras = set() if args.no_extras else set(x for x in args.extras.split(",") if x)
         if world == 1 and exchange != "cabi" and extras:
             # the same workload through the reference's own contract (host backbuffer, synchronous) and in its own seed mode
@@ -606,6 +758,27 @@ def main():
                 out["row_serial_batched_32_ms_per_frame"], out["row_serial_batched_32_Mray_s"] = ms, mr
                 out["row_serial_batched_note"] = ("seed mode 0 through tptDrawDeviceBatch: 32 frames x rows lanes per launch on a device tile -- the reference's exact "
                                                   "image (golden hashes 609aacda / 46afd557 reproduced by tests/test_gpu_parity.py) at GPU speed")
+        sec = args.secondary
+        if sec == "auto":
+            sec = "c2_steady,c3,c5" if (world == 1 and exchange == "none" and args.workload == "c2" and args.persistent == 3 and args.hit_spheres == 0 and args.fold == 0
+                                        and args.batch == 1 and not args.animate and not args.no_extras) else "none"
+        if sec != "none" and world == 1 and exchange == "none":
+            # the other configs in front of whoever runs this command: C2 in steady state (200 timed frames), C3 (3840x2160x16spp) and
+            # C5 (4096 spheres), each fenced, each with its own rooflines and a parity flag against a committed golden vector
+            api.set_ray_counter(None)
+            api.set_stream(None)
+            api.set_tile_mirror(None)
+            api.set_row_shard(0, 1, 0)
+            api.set_seed_mode(1)
+            out["secondary"] = {}
+            plan = {"c2_steady": ("c2", 36, 200, 16), "c3": ("c3", 4, 9, 16), "c5": ("c5", 2, 10, 16)}
+            for leg in [x for x in sec.split(",") if x]:
+                wl, untimed, steps, ov = plan[leg]
+                drain_lookahead(api)
+                out["secondary"][leg] = secondary_leg(api, torch, wl, untimed, steps, ov)
+            api.set_scene(None)
+            api.set_camera(None)
+            api.set_samples_per_pixel(spp)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(width, height, spp)
         print(json.dumps(out), flush=True)

@@ -18,6 +18,10 @@
 #include "tpt_oracle_math.h"
 #include <math.h>
 #include <stdlib.h>
+#if defined(TPTO_PTHREADS)
+#include <pthread.h>
+#include <stdatomic.h>
+#endif
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -352,6 +356,22 @@ static int64_t TraceRows(const Scene* sc, const TptoParams* p, int start, int en
     return rayCount;
 }
 
+#if defined(TPTO_PTHREADS)
+typedef struct { const Scene* sc; const TptoParams* p; float* bb; int y1; atomic_int next; atomic_llong rays; } RowPool;
+static void* rowWorker(void* arg)
+{
+    RowPool* pool = (RowPool*)arg;
+    long long rays = 0;
+    for (;;) {
+        const int y = atomic_fetch_add(&pool->next, 4);
+        if (y >= pool->y1) break;
+        rays += TraceRows(pool->sc, pool->p, y, y + 4 < pool->y1 ? y + 4 : pool->y1, pool->bb);
+    }
+    atomic_fetch_add(&pool->rays, rays);
+    return NULL;
+}
+#endif
+
 int64_t tpto_render(const TptoSphere* spheres, const TptoMaterial* mats, int count, const TptoCamera* cam,
                     const TptoParams* p, float* backbuffer)
 {
@@ -379,11 +399,28 @@ int64_t tpto_render(const TptoSphere* spheres, const TptoMaterial* mats, int cou
     }
     int64_t rays = 0;
     int y0 = p->y0 < 0 ? 0 : p->y0, y1 = p->y1 > p->height ? p->height : p->y1;
+#if defined(TPTO_PTHREADS)
+    /* the same row fan-out on plain pthreads + C11 atomics (ThreadSanitizer understands these; it does not understand libgomp's
+       barriers and reports every access around an OpenMP region): the build oracle/Makefile makes for `oracle_soak_tsan` */
+    {
+        RowPool pool;
+        pool.sc = sc; pool.p = p; pool.bb = backbuffer; pool.y1 = y1;
+        atomic_init(&pool.next, y0);
+        atomic_init(&pool.rays, 0);
+        int nt = p->threads > 0 ? p->threads : 8;
+        if (nt > 256) nt = 256;
+        pthread_t th[256];
+        for (int i = 0; i < nt; ++i) pthread_create(&th[i], NULL, rowWorker, &pool);
+        for (int i = 0; i < nt; ++i) pthread_join(th[i], NULL);
+        rays = atomic_load(&pool.rays);
+    }
+#else
 #ifdef _OPENMP
     int nt = p->threads > 0 ? p->threads : omp_get_max_threads();
 #pragma omp parallel for schedule(dynamic, 4) reduction(+ : rays) num_threads(nt)
 #endif
     for (int y = y0; y < y1; ++y) rays += TraceRows(sc, p, y, y + 1, backbuffer);
+#endif
     free(soa);
     free(sc->emissive);
     free(sc);

@@ -19,6 +19,12 @@ def per_pixel_goldens():
     return json.load(open(os.path.join(HERE, "golden", "goldens.json")))["per_pixel_cases"]
 
 
+def oracle_goldens():
+    """Golden vectors the reference cannot make (it has no 4096-sphere scene): configs[4] frames 0-2 rendered by oracle/tpt_oracle.c
+    (tests/golden/make_golden_c5.py, minutes of CPU)."""
+    return json.load(open(os.path.join(HERE, "golden", "goldens.json"))).get("oracle_cases", [])
+
+
 def case_id(c):
     return "%dx%dx%d_f%d_fl%d" % (c["width"], c["height"], c["spp"], c["frames"], c["flags"])
 

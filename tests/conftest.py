@@ -18,6 +18,14 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """The checker's own redundancy (tests/oracle_lib.py renders every frame twice on big hosts): how often it was used and how often
+    the two runs disagreed -- printed at the END of the run so that it shows in the tail a driver keeps."""
+    if "oracle_lib" in sys.modules:
+        o = sys.modules["oracle_lib"].Oracle
+        terminalreporter.write_line("oracle self-check: redundant renders %s, disagreements between the checker's own runs: %d" % ("on" if o.redundant else "off", o.disagreements))
+
+
 @pytest.fixture(scope="session")
 def oracle():
     from oracle_lib import Oracle

@@ -57,12 +57,14 @@ PER_PIXEL_CASES = [
     (1280, 720, 4, 3, FLAG_PROGRESSIVE, 0.0),
     (1280, 720, 4, 10, FLAG_PROGRESSIVE, 0.0),
     (1280, 720, 4, 41, FLAG_PROGRESSIVE, 0.0),  # the frames `bench.py --steps 20 --warmup 5` renders (16 priming + 5 + 20)
+    (1280, 720, 4, 236, FLAG_PROGRESSIVE, 0.0), # ... and the 200-frame steady-state leg / the default `python bench.py` (16 + 20 + 200)
     (203, 117, 4, 2, FLAG_PROGRESSIVE, 0.0),    # ragged
     (203, 117, 1, 2, FLAG_PROGRESSIVE, 0.0),
     (203, 117, 8, 2, FLAG_PROGRESSIVE, 0.0),
     (203, 117, 16, 2, FLAG_PROGRESSIVE, 0.0),
     (320, 180, 4, 2, 0, 0.0),                   # no progressive accumulation
     (3840, 2160, 16, 1, FLAG_PROGRESSIVE, 0.0), # C3 / C4, whole frame
+    (3840, 2160, 16, 13, FLAG_PROGRESSIVE, 0.0),# C3, the 13 frames of bench.py's secondary C3 leg (4 untimed + 9 timed)
     (320, 180, 4, 3, FLAG_PROGRESSIVE | FLAG_ANIMATE, 0.75),  # moves spheres: last
 ]
 
@@ -102,12 +104,15 @@ def main():
         cfg.append(dict(variant=variant, width=w, height=h, spp=spp, frames=frames, flags=flags, time=t, rays=int(rays),
                         fnv="%08x" % fnv1a(bb), mean_rgb=[float(bb[..., c].mean(dtype=np.float64)) for c in range(3)]))
         print(cfg[-1])
+    path = os.path.join(HERE, "goldens.json")
+    keep = json.load(open(path)) if os.path.exists(path) else {}
+    keep = {k: v for k, v in keep.items() if k.startswith("oracle_cases")}  # (made by make_golden_c5.py: minutes of CPU, not remade here)
     json.dump(dict(config_cases=cfg, per_pixel_cases=per_pixel(),
                    per_pixel_source="oracle/_ref/libtpt_ref_perpixel.so: the same scalar-path build with the reference's own GPU seed formula "
                                     "(ComputeShader.hlsl:380) injected at Test.cpp:281 by oracle/build_ref.sh (sed on the compiler's input stream)",
                    source="oracle/_ref/libtpt_ref_scalar.so (pristine /root/reference scalar path, g++ -O2 -ffp-contract=off "
                           "-D__EMSCRIPTEN__ -D__EMSCRIPTEN_PTHREADS__); simd_* = oracle/_ref/libtpt_ref.so",
-                   cases=out), open(os.path.join(HERE, "goldens.json"), "w"), indent=1)
+                   cases=out, **keep), open(path, "w"), indent=1)
 
 
 if __name__ == "__main__":

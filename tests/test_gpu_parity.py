@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from common import case_id, config_goldens, config_kwargs, goldens, oracle_frames, per_pixel_goldens, rel_err
+from common import case_id, config_goldens, config_kwargs, goldens, oracle_frames, oracle_goldens, per_pixel_goldens, rel_err
 from oracle_lib import (FLAG_ANIMATE, FLAG_PROGRESSIVE, FOLD_FORWARD, FOLD_RECURSIVE, SEED_PER_PIXEL, SEED_ROW_SERIAL,
                         fnv1a)
 
@@ -592,6 +592,30 @@ def test_config5_stress_scene_full_parity(tpt_defaults, oracle):
     assert tpt.scene_info()["bounds_on_matrix_cores"] is False
     r4, b4, _ = gpu_frames(tpt, w, h, 1)
     assert r4 == r1 and b4.tobytes() == b1.tobytes()
+
+
+def test_config5_three_frames_in_flight_match_the_committed_oracle_hashes(tpt_defaults):
+    """configs[4], frames 0, 1 and 2, each blended into its own zeroed device tile with all three traces in flight: image hashes and
+    ray counts equal the oracle's committed ones (tests/golden/make_golden_c5.py: brute force over the 4096 spheres on the CPU)."""
+    import torch
+    from toypathtracer_amd.scenes import STRESS_CAMERA, stress_scene
+    tpt = tpt_defaults
+    want = sorted(oracle_goldens(), key=lambda c: c["frame"])
+    assert [c["frame"] for c in want] == [0, 1, 2]
+    s, m = stress_scene(4096, 64)
+    w, h, spp = 1920, 1080, 8
+    tpt.set_scene(s, m)
+    tpt.set_camera(**STRESS_CAMERA)
+    tpt.set_samples_per_pixel(spp)
+    for rep in range(2):
+        tiles = [torch.zeros((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(3)]
+        r0 = tpt.ray_counter_read()
+        for f in range(3):
+            tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+            tpt.draw_device(0.0, f, w, h, tiles[f].data_ptr(), FLAG_PROGRESSIVE)
+        rays = tpt.ray_counter_read() - r0
+        assert rays == sum(c["rays"] for c in want)
+        assert ["%08x" % fnv1a(t.cpu().numpy()) for t in tiles] == [c["fnv"] for c in want]
 
 
 def test_grouped_kernel_repeats_exactly_with_many_streams_in_the_process(tpt_defaults):

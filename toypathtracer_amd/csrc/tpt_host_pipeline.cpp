@@ -98,6 +98,12 @@ int reserveSlotBuffers(int nSlots, size_t colourBytes, size_t stackBytes, size_t
         }
         (void)hipGetLastError();
         g.colourCap = g.stackCap = g.pathCap = 0; g.slotsReserved = 0;
+        // ... and no ticket may keep pointing into a buffer that is gone (frames traced ahead, an open stream batch, the row-serial
+        // batches): drop them all -- a later takeAhead / batch serve would blend from freed memory, and every later enqueueTrace
+        // would be refused with "colour slots are held by frames traced ahead".  (Everything was drained before the buffers grew.)
+        g.rsb[0].used = g.rsb[1].used = false;
+        for (int k = 0; k < 4; ++k) g.ahead[k].used = false;
+        g.sbatch.used = false;
         return rc;
     }
     g.colourCap = cb; g.stackCap = sb; g.pathCap = pb; g.slotsReserved = n;

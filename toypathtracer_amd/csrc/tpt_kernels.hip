@@ -4,7 +4,7 @@
 // TraceRowJob :266-300).  All of them run the same per-lane code (tpt_trace.h: hitSpheres + lanePost, one ray per
 // step) and produce the same bits; they differ in how rays are mapped onto lanes:
 //
-//   * tptTraceQueueKernel   (default)  workgroups of 8 waves own 1024 paths whose state lives in LDS; waves pop
+//   * tptTraceQueueKernel   (default)  workgroups of 8 waves own 952 paths whose state lives in LDS; waves pop
 //                                      batches of paths that need the SAME code from per-class rings, so Scatter and the
 //                                      intersections run at (nearly) full lane utilisation;
 //   * tptTraceKernel                   one-wave workgroups pull 8x8-pixel chunks from a global counter and re-fill idle
@@ -19,7 +19,10 @@
 //   * output: the frame's colour per pixel (one 16-B store), blended into the float4 accumulation tile by
 //     tptResolveKernel (RGB read-modify-write, alpha untouched); ray counts reduced per wave -> one 64-bit atomic.
 //
-// No MFMA: there is no dense contraction in this path (46-long select/min reduction per lane).
+// Matrix cores: HitSpheres itself has no dense contraction (a 46-long select / min reduction per lane, Maths.cpp:165-202), but
+// its conservative FILTER does -- the discriminant is bilinear in (sphere, ray), so the path-queue kernel evaluates
+// [64 spheres x 32 slots] x [32 slots x 64 rays] with v_mfma_f32_32x32x16_f16 on f16-split operands (tpt_trace.h phase1MatrixH)
+// and runs the reference's exact arithmetic only on what passes.  Everything a branch can depend on stays on the VALU.
 #include "tpt_device.h"
 #include "tpt_shard.h"
 
@@ -373,8 +376,8 @@ __device__ __forceinline__ f4 mk4(float x, float y, float z, float w)
 }
 
 // ---------------------------------------------------------------- path-queue variant
-// A workgroup of 8 waves owns a pool of 1024 paths (2 per lane, so the queues below stay deep enough to hand out
-// full batches); two such workgroups fit on a CU.  Waves are interchangeable workers that pop batches of up to 64
+// A workgroup of 8 waves owns a pool of TPT_Q_PATHS = 952 paths (~2 per lane, so the queues below stay deep enough to hand
+// out full batches; the rings hold TPT_Q_P = 1024 entries); two such workgroups fit on a CU.  Waves are interchangeable workers that pop batches of up to 64
 // path ids from per-operation queues in LDS:
 //   FREE    -> [assign a pixel, camera ray]                       \
 //   END     -> [sky / emission, fold, next sample's camera ray]    |  then, in the SAME iteration, HitWorld for the
@@ -387,8 +390,8 @@ __device__ __forceinline__ f4 mk4(float x, float y, float z, float w)
 // full lane utilisation instead of ~40 %, a lane never idles because "its" pixel ended (any wave picks up any path),
 // and a path crosses a queue once per bounce (not once per ray: the shadow rays of a Lambert hit stay in registers).
 // No barriers: the queues are multi-producer / multi-consumer rings (reserve with an LDS atomic, publish by
-// overwriting a 0xFFFF sentinel).  Path state: the 48 B every class needs (ray, rng, flags, hit) live in LDS; the
-// pixel's colour sum (16 B, touched when a sample ends) and the bounce stack live in global memory (L2-resident).
+// overwriting a 0xFFFF sentinel).  Path state: a 64-B record in LDS (ray, rng, flags, hit; the pixel's colour sum; level 0 of
+// the bounce stack -- see "The path record" below); levels 1-9 of the stack live in global memory (L2-resident).
 // FOLD_RECURSIVE only.
 #ifndef TPT_Q_WAVES
 #define TPT_Q_WAVES 8
@@ -1190,11 +1193,13 @@ __device__ __forceinline__ void traceQueueBody(const KernelArgs& a)
         unsigned done = atomicAdd(&a.work[1], 1u) + 1u;
         if (done == a.totalWaves) {
             if (a.gen != 0u) {
-                // close, THEN look for registered helpers (they register, then look for "closed": one side always sees the other);
-                // they are resident workgroups finishing the chunks they took -- bounded; the cap only keeps a bug from hanging the GPU
+                // close, THEN look for registered helpers (they register, then look for "closed": one side always sees the other).
+                // They are resident workgroups finishing the chunks they took: bounded work, so the wait has NO cap -- a cap that
+                // expired (long chunks of the grouped kernel, a time-sliced or debugged process) re-armed the pool under helpers
+                // that were still running, and their late stores landed in the slot's next frame without anyone noticing.
                 const unsigned prev = __hip_atomic_exchange(&a.work[3], a.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 unsigned busy = __hip_atomic_fetch_or(&a.work[2], dependentZero(prev), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                for (unsigned spins = 0; spins < 60000u && busy != 0u; ++spins) {
+                while (busy != 0u) {
                     __builtin_amdgcn_s_sleep(127);
                     busy = __hip_atomic_fetch_or(&a.work[2], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }

@@ -423,7 +423,7 @@ def main():
                     help="short fenced legs of the other configs behind the headline run, each with its own roofline objects and a parity flag "
                          "against a committed golden hash (comma list of c2_steady, c3, c5; auto = all three when the headline is the default "
                          "1-GPU configs[1] run, none otherwise; none = skip)")
-    ap.add_argument("--hit-spheres", type=int, default=0, help="0 two-phase: matrix-core filter for <= 64 spheres, grouped traversal for >= 256 (default); 1 simple loop; 2 two-phase brute force; 3 as 0 with the packed VALU filter instead of the matrix-core one")
+    ap.add_argument("--hit-spheres", type=int, default=0, help="0 two-phase: matrix-core filter for <= 64 spheres, grouped traversal for >= 256 (default); 1 simple loop; 2 two-phase brute force; 3 as 0 with the flat packed VALU filter everywhere (no matrix cores, no second level over the groups); 4 as 0 with a grouped scene's bounds on the matrix cores (opt-in: not in a time-sliced process, DESIGN.md 2.2)")
     ap.add_argument("--persistent", type=int, default=3, choices=[1, 3], help="3 path queues (default) 1 persistent waves with lane refill (the fallback kernel)")
     ap.add_argument("--fold", type=int, default=0, help="0 recursive (reference order, default) 1 forward")
     ap.add_argument("--lds-scene", type=int, default=-1)
@@ -664,14 +664,15 @@ def main():
             "exchange": exchange, "rccl_ranks": rccl_ranks if exchange == "cabi" else (world if exchange == "torch" else 0),
             "config": {"workload": label, "width": width, "height": height, "spp": spp, "spheres": n_spheres,
                        "seed_mode": "per_pixel", "fold": "forward" if args.fold else "recursive",
-                       "hit_spheres": ["two_phase" + ("+groups" if n_spheres >= 256 else "+matrix_core_filter" if n_spheres <= 64 else ""), "simple", "two_phase_brute_force", "two_phase_valu_filter"][args.hit_spheres], "kernel": {1: "persistent_waves", 3: "path_queues"}[args.persistent], "frame_overlap": args.overlap, "frames_per_launch": frames_per_launch,
+                       "hit_spheres": ["two_phase" + ("+groups+two_level_valu_bounds" if n_spheres >= 256 else "+matrix_core_filter" if n_spheres <= 64 else ""), "simple", "two_phase_brute_force", "two_phase_flat_valu_filter",
+                                       "two_phase+groups+matrix_core_bounds"][args.hit_spheres], "kernel": {1: "persistent_waves", 3: "path_queues"}[args.persistent], "frame_overlap": args.overlap, "frames_per_launch": frames_per_launch,
                        "untimed_priming_frames": args.prime,
                        "flags": "progressive|animate" if args.animate else "progressive",
                        "sharding": "none" if world == 1 else "row stripes of %d, round-robin over %d ranks, pipelined gather to rank 0" % (args.stripe_rows, world),
                        "device": api.device_name(), "grid_blocks": info["grid_blocks"], "blocks_per_cu": info["blocks_per_cu"],
                        "lds_bytes_per_block": info["lds_bytes"],
-                       # grouped scenes: whether the groups' bounds are filtered on the matrix cores (not in a process that started HIP
-                       # with more than 22 hardware queues: DESIGN.md 2.2) -- and the queues this process asked for
+                       # grouped scenes: whether the groups' bounds are filtered on the matrix cores (opt-in, --hit-spheres 4: DESIGN.md 2.2;
+                       # the default is the two-level packed VALU filter) -- and the queues this process asked for
                        "groups": api.scene_info()["groups"], "bounds_on_matrix_cores": api.scene_info()["bounds_on_matrix_cores"],
                        "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
             "rays_per_step": rays_total / args.steps,

@@ -226,18 +226,21 @@ TPT_API int tptKernelTimingEnd(float* outSumMilliseconds, int* outLaunches);
 
 /* hitSpheres: 0 = two-phase (default: a conservative filter + the reference's exact test for what passes.  The filter runs
  * on the matrix cores for scenes of <= 64 spheres that binary16 operands can carry, as packed FP32 on the VALU otherwise;
- * scenes of 256 spheres or more are traversed through compact groups of <= 8 spheres with bounding spheres -- same hits,
- * same tie-break, ~4x faster on the 4096-sphere scene), 1 = simple loop (exact test for every sphere), 2 = two-phase
- * without grouping (brute force over all spheres, the reference's cost model), 3 = two-phase with the packed VALU filter
- * everywhere (no matrix-core table).  persistent: 3 = path queues in LDS (default; per-pixel seeds, recursive fold, two-phase
+ * scenes of 256 spheres or more are traversed through compact groups of <= 8 spheres with bounding spheres, the groups' own
+ * bounds through a two-level packed filter (super-groups of 8 groups, then the groups of what passes) -- same hits, same
+ * tie-break, several times faster on the 4096-sphere scene), 1 = simple loop (exact test for every sphere), 2 = two-phase
+ * without grouping (brute force over all spheres, the reference's cost model), 3 = two-phase with the FLAT packed VALU filter
+ * everywhere (no matrix-core table, no second level over the groups), 4 = as 0 with the bounds of a GROUPED scene on the matrix cores as well -- compiled into the
+ * hooks build only (the product library refuses it): in a process the device time-slices (more than ~22 hardware queues, or
+ * anything else on the GPU) waves that have run that path lose a hit in ~1e-9 of their rays, and the two-level
+ * VALU filter is no slower.  persistent: 3 = path queues in LDS (default; per-pixel seeds, recursive fold, two-phase
  * only -- anything else falls back to 1), 1 = persistent waves with lane refill (any other value selects 3).  ldsScene:
  * 1 = stage sphere records and materials in LDS (default when they fit), 0 = read them from global memory, -1 = auto.
  * All variants produce identical bits. */
 TPT_API int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene);
 /* What the next launch will do with the scene: its sphere count, the number of sphere groups (0: the scene is traversed flat -- up to 255
- * spheres, or a scene the grouping refuses), and whether the groups' bounding spheres are filtered on the matrix cores (1) or by the packed
- * VALU filter (0: tptSetKernelVariant(3, ..), or a process that started HIP with GPU_MAX_HW_QUEUES > 22 -- such a process may be time-sliced
- * by the device, under which the matrix-core filter of the grouped kernel has been seen to lose candidates: DESIGN.md 2.2). */
+ * spheres, or a scene the grouping refuses), and whether the groups' bounding spheres are filtered on the matrix cores (1: only after
+ * tptSetKernelVariant(4, ..)) or by the packed VALU filter (0: the default). */
 TPT_API int tptGetSceneInfo(int* outSpheres, int* outGroups, int* outBoundsOnMatrixCores);
 /* kernel resource facts for DESIGN/bench: occupancy (blocks/CU), LDS bytes/block, grid size of the last launch */
 TPT_API int tptGetLaunchInfo(int* outBlocksPerCU, int* outLdsBytes, int* outGridBlocks, int* outNumCUs);

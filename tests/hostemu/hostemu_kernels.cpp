@@ -16,7 +16,7 @@ using namespace tpt;
 
 namespace {
 // (mirrors of constants that live in tpt_kernels.hip: path records, rings, control block of the path-queue kernel)
-const int kQPaths = 952, kQRing = 1024, kQClasses = 6, kQThreads = 512, kQWaves = 8;
+const int kQPaths = 952, kQPathsGrouped = 816, kQRing = 1024, kQClasses = 6, kQThreads = 512, kQWaves = 8;
 const size_t kQCtlBytes = 256, kQDealWaveBytes = 192 * 4 + 64;
 
 bool mapItem(const KernelArgs& a, int idx, int& x, int& ly) // tpt_kernels.hip: mapItem
@@ -331,13 +331,20 @@ size_t tptQueueLdsBytes(const KernelArgs& a, bool ldsScene) // = tpt_kernels.hip
     size_t bytes = 0;
     if (ldsScene) bytes += 1024 + ((size_t)nPad * 16 <= 1024 ? 0 : (size_t)nPad * 16) + (((size_t)nPad * 4 + 15) & ~(size_t)15) + (size_t)a.scene.nSpheres * 48;
     bytes += (size_t)a.scene.nLights * 32;
-    bytes += (size_t)4 * kQPaths * 16 + (size_t)kQClasses * kQRing * 2 + kQCtlBytes + ((sizeof(FrameConsts) + 15) & ~(size_t)15);
-    if (!ldsScene) bytes += (size_t)kQWaves * kQDealWaveBytes;
+    bytes += (size_t)4 * (ldsScene ? kQPaths : kQPathsGrouped) * 16 + (size_t)kQClasses * kQRing * 2 + kQCtlBytes + ((sizeof(FrameConsts) + 15) & ~(size_t)15);
+    if (!ldsScene) bytes += (size_t)kQWaves * kQDealWaveBytes + (a.ldsGroupPairs > 0 ? 16 + (size_t)a.ldsGroupPairs * 32 : 0);
     if (ldsScene && a.scene.mxR1 >= 0) bytes += TPT_MXH_TABLE_DWORDS * sizeof(uint32_t) + 64;
     return bytes;
 }
 int tptQueuePathsPerBlock() { return kQPaths; }
+int tptQueueGroupPairsInLds(int nGroups, int nSuperPairs) // = tpt_kernels.hip
+{
+    if (nGroups <= 0 || nSuperPairs <= 0) return 0;
+    const int pairs = ((nGroups + TPT_SUPER - 1) / TPT_SUPER) * (TPT_SUPER / 2);
+    return (size_t)pairs * 32 + 16 <= (size_t)(kQPaths - kQPathsGrouped) * 64 ? pairs : 0;
+}
 int tptQueueMatrixFilter() { return 1; }
+int tptQueueGroupMatrixBounds() { return 1; }
 int tptQueueThreadsPerBlock() { return kQThreads; }
 
 hipError_t tptLaunchTrace(const KernelArgs& a, int hs, int fold, bool ldsScene, int blocks, size_t, hipStream_t stream)

@@ -583,15 +583,21 @@ def test_config5_stress_scene_full_parity(tpt_defaults, oracle):
     # the WHOLE frame against the oracle's brute force over 4096 spheres (the grouped traversal must change nothing)
     ro, bo = oracle.render(s, m, cam, w, h, spp, 0, seed_mode=SEED_PER_PIXEL)
     assert r1 == ro and b1.tobytes() == bo.tobytes()
-    assert tpt.scene_info() == dict(spheres=4096, groups=512, bounds_on_matrix_cores=int(os.environ.get("GPU_MAX_HW_QUEUES", "0")) <= 22)
+    # (the default: the groups' bounds through the two-level packed VALU filter, their pair records in LDS)
+    assert tpt.scene_info() == dict(spheres=4096, groups=512, bounds_on_matrix_cores=False)
+    info = tpt.launch_info()
+    assert info["blocks_per_cu"] == 2, info
     tpt.set_kernel_variant(0, 1, -1)  # lane-refill kernel on the same frame
     r3, b3, _ = gpu_frames(tpt, w, h, 1)
     assert r3 == r1 and b3.tobytes() == b1.tobytes()
-    # the groups' bounds through the packed VALU filter: what a process with more than 22 hardware queues gets
+    # the groups' bounds on the matrix cores: not in the product library (the hooks build carries them, see below)
+    with pytest.raises(Exception, match="hooks build only"):
+        tpt.set_kernel_variant(4, 3, -1)
+    # the flat packed VALU filter over all 512 groups (no matrix-core table anywhere)
     tpt.set_kernel_variant(3, 3, -1)
     assert tpt.scene_info()["bounds_on_matrix_cores"] is False
-    r4, b4, _ = gpu_frames(tpt, w, h, 1)
-    assert r4 == r1 and b4.tobytes() == b1.tobytes()
+    r5, b5, _ = gpu_frames(tpt, w, h, 1)
+    assert r5 == r1 and b5.tobytes() == b1.tobytes()
 
 
 def test_config5_three_frames_in_flight_match_the_committed_oracle_hashes(tpt_defaults):
@@ -618,41 +624,41 @@ def test_config5_three_frames_in_flight_match_the_committed_oracle_hashes(tpt_de
         assert ["%08x" % fnv1a(t.cpu().numpy()) for t in tiles] == [c["fnv"] for c in want]
 
 
-def test_grouped_kernel_repeats_exactly_with_many_streams_in_the_process(tpt_defaults):
-    """Round 5: a process that holds more hardware queues than the device runs side by side is time-sliced, and the grouped
-    kernel's long launches then came back with 1-4 differing pixels in ~8 % of the 4096-sphere frames (profiles/r05/README.md,
-    calls 11-23: 16 idle torch streams were enough at GPU_MAX_HW_QUEUES=32).  The library, api.py, bench.py and this suite
-    export GPU_MAX_HW_QUEUES=20 since: streams beyond that share queues.  16 extra streams, then the frame three in flight,
-    eight times: every ray count and every image the same."""
-    import torch
+def test_config5_with_the_bounds_on_the_matrix_cores_in_the_hooks_build(tpt_hooks):
+    """hitSpheres variant 4 (the round 3-5 default for grouped scenes, now compiled into the hooks build only): frame 0 of configs[4]
+    in this -- not time-sliced -- process equals the oracle's committed hash."""
     from toypathtracer_amd.scenes import STRESS_CAMERA, stress_scene
-    tpt = tpt_defaults
-    extra = []
-    for _ in range(16):
-        st = torch.cuda.Stream()
-        with torch.cuda.stream(st):
-            torch.zeros(16, device="cuda").add_(1.0)
-        extra.append(st)
-    torch.cuda.synchronize()
+    tpt = tpt_hooks
+    want = [c for c in oracle_goldens() if c["frame"] == 0][0]
     s, m = stress_scene(4096, 64)
-    w, h = 1920, 1080
+    tpt.set_kernel_variant(4, 3, -1)
     tpt.set_scene(s, m)
     tpt.set_camera(**STRESS_CAMERA)
     tpt.set_samples_per_pixel(8)
-    # (a run that exported more than 22 queues itself gets the groups' bounds off the matrix cores: the rule tptInitialize applies)
-    many = int(os.environ.get("GPU_MAX_HW_QUEUES", "0")) > 22
-    assert tpt.scene_info() == dict(spheres=4096, groups=512, bounds_on_matrix_cores=not many)
-    seen = set()
-    for rep in range(8):
-        tiles = [torch.zeros((h, w, 4), dtype=torch.float32, device="cuda") for _ in range(3)]
-        r0 = tpt.ray_counter_read()
-        for f in range(3):
-            tpt.UpdateTest(0.0, f, w, h, 0)
-            tpt.draw_device(0.0, f, w, h, tiles[f].data_ptr(), 0)
-        tpt.synchronize()
-        seen.add((tpt.ray_counter_read() - r0,) + tuple(fnv1a(t.cpu().numpy()) for t in tiles))
-    assert len(seen) == 1, "renders of the same three frames differ: %s" % sorted(seen)
-    del extra
+    assert tpt.scene_info() == dict(spheres=4096, groups=512, bounds_on_matrix_cores=True)
+    rays, bb, _ = gpu_frames(tpt, 1920, 1080, 1)
+    assert rays == want["rays"] and "%08x" % fnv1a(bb) == want["fnv"]
+    tpt.set_scene(None)
+    tpt.set_camera(None)
+
+
+def test_grouped_kernel_is_exact_in_a_time_sliced_process():
+    """Rounds 5-6: a process that holds more hardware queues than the device runs side by side is time-sliced, and the
+    grouped kernel with its groups' bounds ON THE MATRIX CORES then came back with 1-4 wrong pixels in 8-80 % of the renders, depending
+    on the build.  Round 6 localised it -- the masks the matrix cores deliver are right; a per-lane gather of a group's members behind
+    them now and then delivers wrong data to a wave that has executed that path, never to one that has not -- and made the two-level
+    packed VALU filter the default for grouped scenes.  The condition cannot be created inside this process (the HIP runtime reads
+    GPU_MAX_HW_QUEUES when it starts), so a child process starts HIP with 32 queues, opens 16 extra streams and renders frames 0-2 of
+    configs[4] 70 times, three in flight: every one of the 210 renders must equal the oracle's committed hash."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    out = subprocess.run([sys.executable, os.path.join(here, "c5_timeslice_child.py"), "70", "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    res = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    assert res["scene_info"] == dict(spheres=4096, groups=512, bounds_on_matrix_cores=False), res
+    assert res["renders"] == 210 and res["sets_differing_from_the_oracle"] == 0 and res["distinct_results"] == 1, res
 
 
 # ---- phase 1 on the matrix cores
@@ -719,18 +725,22 @@ def test_matrix_filter_hits_equal_the_exact_loop_on_grazing_rays(tpt_hooks, orac
     tpt.set_scene(None)
 
 
-def test_group_matrix_filter_on_the_device(tpt_hooks):
-    """Grouped scenes: the path-queue kernel runs the groups' bounding spheres through the matrix-core filter with doubled slack
-    (hitSpheresGroupedDeal, buildGroupMatrixTable).  On the device, against the reference's discriminant of EVERY member sphere
-    (Maths.cpp:171-178): for 400 000 rays that graze spheres within 1e-8 .. 1e-3 radii plus random ones, no member the
-    reference accepts sits in a group the filter dropped -- 4096 spheres (4 tiles of 64 groups) and 20 000 (20 tiles)."""
+@pytest.mark.parametrize("variant", [0, 4], ids=["two_level_valu", "matrix_cores"])
+def test_group_bounds_filters_on_the_device(tpt_hooks, variant):
+    """Grouped scenes: the groups' bounding spheres go through the two-level packed VALU filter (super-groups of 8 groups, then
+    the groups: groupMasksTwoLevel, the default) or, opt-in, through the matrix-core filter with doubled slack (buildGroupMatrixTable).
+    On the device, against the reference's discriminant of EVERY member sphere (Maths.cpp:171-178): for 400 000 rays that graze
+    spheres within 1e-8 .. 1e-3 radii plus random ones, no member the reference accepts sits in a group the filter dropped --
+    4096 spheres (512 groups, 64 super-groups) and 20 000 (2500 groups)."""
     from common import grazing_rays
     from toypathtracer_amd.scenes import stress_scene
     tpt = tpt_hooks
+    tpt.set_kernel_variant(variant, 3, -1)
     rng = np.random.default_rng(17)
     for n, grid, k in ((4096, 64, 200000), (20000, 160, 50000)):
         s, m = stress_scene(n, grid)
         tpt.set_scene(s, m)
+        assert tpt.scene_info()["bounds_on_matrix_cores"] is (variant == 4)
         tpt.UpdateTest(0.0, 0, 64, 64, 2)
         o = np.stack([rng.uniform(-grid / 2, grid / 2, k), rng.uniform(0.0, 8.0, k), rng.uniform(-grid / 2, grid / 2, k)], 1)
         d = rng.normal(size=(k, 3))

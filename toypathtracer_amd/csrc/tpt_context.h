@@ -74,6 +74,8 @@ struct Context {
         size_t cap = 0, bytes = 0;
         size_t offSph4 = 0, offInvR = 0, offMats = 0, offLights = 0;
         size_t offGPairs = 0, offGSph = 0, offGId = 0, offBSph = 0, offBId = 0; // grouped representation (large scenes)
+        size_t offSPairs = 0;                                                    // ... and the super-group bounds over it
+        int nSuperPairs = 0;
         size_t offAmat = 0; // matrix-core filter table (small scenes)
         int mxR1 = -1;
         size_t offGmat = 0; // the same for the group bounds of a grouped scene
@@ -96,8 +98,7 @@ struct Context {
     int foldMode = FOLD_RECURSIVE;
     int allowGroups = 1; // hitSpheres variant 2 = two-phase, brute force even for large scenes
     int useMatrix = 1;   // phase 1 of HitSpheres on the matrix cores where it applies (hitSpheres variant 3 = VALU filter everywhere)
-    bool manyQueues = false; // GPU_MAX_HW_QUEUES > 22 when tptInitialize ran: the process may be time-sliced by the device; grouped scenes keep their
-                             // bounds off the matrix cores then
+    int groupMatrix = 0; // grouped scenes: the groups' bounds on the matrix cores (hitSpheres variant 4; opt-in: DESIGN.md 2.2) instead of the two-level VALU filter
     int hs = HS_TWO_PHASE, persist = 3, ldsScene = -1; // persist 3 = path queues (falls back to 1 where they do not apply)
     int stripeRows = 0, numParts = 1, part = 0;
     int gridFill = 0;                           // env TPT_GRID_FILL: % of the resident slots all in-flight launches ask for

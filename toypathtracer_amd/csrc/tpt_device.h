@@ -50,6 +50,8 @@ struct KernelArgs {
     unsigned gen;                    // tail helpers: serial of this launch (1, 2, ...; 0: takes no helpers)
     int helperBase;                  // 0: the launch itself; > 0: its helper grid, whose workgroup b plays workgroup helperBase + b (stack columns)
     int helperPct;                   // a helper workgroup joins only while at least this % of the pool is unclaimed
+    int ldsGroupPairs;               // grouped scenes, path-queue kernel, the two-level bounds filter: > 0 pair records of the groups' bounds staged in
+                                     // LDS (whole super-groups), 0 = read them from global memory (too many for the LDS area), < 0 = flat filter over all groups
 };
 
 } // namespace tpt
@@ -60,7 +62,9 @@ int tptTraceOccupancy(int hs, int fold, bool ldsScene, size_t lds);
 size_t tptQueueLdsBytes(const tpt::KernelArgs& a, bool ldsScene);
 hipError_t tptLaunchTraceQueue(const tpt::KernelArgs& a, bool ldsScene, int blocks, size_t lds, hipStream_t stream);
 int tptQueuePathsPerBlock();
+int tptQueueGroupPairsInLds(int nGroups, int nSuperPairs);
 int tptQueueMatrixFilter();
+int tptQueueGroupMatrixBounds(); // 1: this build carries the groups' bounds on the matrix cores (hooks build only)
 int tptQueueThreadsPerBlock();
 hipError_t tptLaunchDisplay(const float* tile, unsigned char* rgba, int width, int height, hipStream_t stream);
 hipError_t tptLaunchAssemble(const float* gathered, float* image, int width, int height, int stripeRows, int nRanks, int padRows, hipStream_t stream);

@@ -53,9 +53,11 @@ int stageScene()
                  offGSph = offGPairs + align256(bGPairs), offGId = offGSph + align256(bGSph), offBSph = offGId + align256(bGId),
                  offBId = offBSph + align256(bBSph), offAmat = offBId + align256(bBId + 32);
     const size_t bAmat = (g.useMatrix && tptQueueMatrixFilter() && P.mxR1 >= 0) ? P.amatH.size() * sizeof(uint32_t) : 0;
-    const size_t offGmat = offAmat + align256(bAmat + 32);
-    // (not in a process that may hold more hardware queues than the device runs side by side: DESIGN.md 2.2)
-    const size_t bGmat = (grouped && g.useMatrix && !g.manyQueues && tptQueueMatrixFilter() && P.gmxTiles > 0) ? P.gmatH.size() * sizeof(uint32_t) : 0;
+    const size_t bSPairs = grouped ? P.spairs.size() * sizeof(float) : 0; // super-group bounds (second level over the groups)
+    const size_t offSPairs = offAmat + align256(bAmat + 32);
+    const size_t offGmat = offSPairs + align256(bSPairs + 32);
+    // (only for a host that asked for it, tptSetKernelVariant(4, ..): DESIGN.md 2.2)
+    const size_t bGmat = (grouped && g.useMatrix && g.groupMatrix && tptQueueGroupMatrixBounds() && P.gmxTiles > 0) ? P.gmatH.size() * sizeof(uint32_t) : 0;
     const size_t total = offGmat + align256(bGmat + 32);
     if (!S.evUploaded) HIPCHK(hipEventCreateWithFlags(&S.evUploaded, kOrderingEvent));
     // the previous copy out of this staging blob (kSceneSets uploads ago) must have left the host before we overwrite it:
@@ -96,6 +98,9 @@ int stageScene()
         if (bBId) memcpy(S.stage + offBId, P.bid.data(), bBId);
     }
     if (bAmat) memcpy(S.stage + offAmat, P.amatH.data(), bAmat);
+    if (bSPairs) memcpy(S.stage + offSPairs, P.spairs.data(), bSPairs);
+    S.offSPairs = offSPairs;
+    S.nSuperPairs = bSPairs ? P.nSuperPairs : 0;
     if (bGmat) memcpy(S.stage + offGmat, P.gmatH.data(), bGmat);
     S.bytes = offGmat + bGmat;
     S.offAmat = offAmat;
@@ -134,6 +139,8 @@ SceneView deviceView()
     sv.nPairs = S->nPairs;
     sv.nLights = S->nLights;
     sv.gpairs = reinterpret_cast<const float*>(S->dev + S->offGPairs);
+    sv.spairs = reinterpret_cast<const float*>(S->dev + S->offSPairs);
+    sv.nSuperPairs = S->nSuperPairs;
     sv.gsph = reinterpret_cast<const f4*>(S->dev + S->offGSph);
     sv.gid = reinterpret_cast<const int*>(S->dev + S->offGId);
     sv.bsph = reinterpret_cast<const f4*>(S->dev + S->offBSph);
@@ -304,16 +311,9 @@ int tptInitialize(void)
     // 20, not more: this library's 18 streams, the null stream and one of the host's each get their own, and the process
     // stays below what the device runs side by side.  A process that holds MORE queues than that (measured on MI355X /
     // ROCm 7.2: 20 and 22 fine, 24 and up not) is time-sliced by the device's scheduler -- running waves are switched out
-    // and back in -- and that (a) halves the frame rate (round 4) and (b) makes the grouped kernel's long launches return
-    // 1-4 wrong pixels in ~8 % of the 4096-sphere frames (round 5: profiles/r05/README.md calls 11-23).
+    // and back in -- which halves the frame rate (round 4).  A PERFORMANCE hint only: nothing the library computes depends on
+    // it (rounds 5-6: the one kernel path that was not safe under time-slicing is no longer taken by default).
     setenv("GPU_MAX_HW_QUEUES", TPT_DEFAULT_HW_QUEUES, 0);
-    {
-        // a host that asked for more queues itself: a time-sliced process has been seen to lose (ray, group) candidates in the
-        // matrix-core filter of the groups' bounds (1-4 pixels in ~8 % of the 4096-sphere frames) -- grouped scenes then take
-        // the packed VALU filter for their bounds (same bits; 6.05 instead of 8.45 Gray/s at C5).  tptGetSceneInfo tells.
-        const char* q = getenv("GPU_MAX_HW_QUEUES");
-        g.manyQueues = q && atoi(q) > 22;
-    }
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count <= 0)
@@ -550,14 +550,20 @@ int tptSetFrameOverlap(int frames)
 
 int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene)
 {
-    if (hitSpheres < 0 || hitSpheres > 3) return fail("tptSetKernelVariant: hitSpheres 0 (two-phase) 1 (simple) 2 (two-phase, no groups) 3 (two-phase, VALU filter)");
+    if (hitSpheres < 0 || hitSpheres > 4)
+        return fail("tptSetKernelVariant: hitSpheres 0 (two-phase) 1 (simple) 2 (two-phase, no groups) 3 (two-phase, VALU filter) 4 (two-phase, groups' bounds on the matrix cores)");
+    if (hitSpheres == 4 && !tptQueueGroupMatrixBounds())
+        return fail("tptSetKernelVariant: hitSpheres 4 (a grouped scene's bounds on the matrix cores) is compiled into the hooks build only "
+                    "(libtoypathtracer_hip_hooks.so): waves that have run that path are not safe in a time-sliced process, DESIGN.md 2.2");
     if (persistent != 1 && persistent != 3)
         return fail("tptSetKernelVariant: persistent 3 (path queues, the default) or 1 (lane refill); the thread-per-pixel (0) and lane-sorting (2) kernels were removed in round 3");
     g.hs = hitSpheres == 1 ? HS_SIMPLE : HS_TWO_PHASE;
     const int allow = hitSpheres == 2 ? 0 : 1, matrix = hitSpheres == 3 ? 0 : 1; // 3: the packed VALU filter everywhere (no matrix-core table)
-    if (allow != g.allowGroups || matrix != g.useMatrix) {
+    const int groupMatrix = hitSpheres == 4 ? 1 : 0; // 4: as 0, and the bounds of a GROUPED scene on the matrix cores too (opt-in)
+    if (allow != g.allowGroups || matrix != g.useMatrix || groupMatrix != g.groupMatrix) {
         g.allowGroups = allow;
         g.useMatrix = matrix;
+        g.groupMatrix = groupMatrix;
         g.sceneDirty = true; // the staged scene set carries (or not) the grouped arrays / the matrix table
     }
     g.persist = persistent; // 3 = path queues (default), 1 = lane-refill kernel
@@ -691,7 +697,7 @@ int tptGetSceneInfo(int* outSpheres, int* outGroups, int* outBoundsOnMatrixCores
     const bool grouped = g.allowGroups && P.nGroups > 0; // (the same decisions stageScene takes for the next upload)
     if (outSpheres) *outSpheres = P.nSpheres;
     if (outGroups) *outGroups = grouped ? P.nGroups : 0;
-    if (outBoundsOnMatrixCores) *outBoundsOnMatrixCores = (grouped && g.useMatrix && !g.manyQueues && tptQueueMatrixFilter() && P.gmxTiles > 0) ? 1 : 0;
+    if (outBoundsOnMatrixCores) *outBoundsOnMatrixCores = (grouped && g.useMatrix && g.groupMatrix && tptQueueGroupMatrixBounds() && P.gmxTiles > 0) ? 1 : 0;
     return 0;
 }
 

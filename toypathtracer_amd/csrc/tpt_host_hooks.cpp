@@ -128,7 +128,7 @@ int tptTestGroupFilter(const float* rays, int n, unsigned long long* outViolatio
     KernelArgs a;
     memset(&a, 0, sizeof(a));
     a.scene = deviceView();
-    if (a.scene.nGroups <= 0 || a.scene.gmxTiles <= 0) return fail("tptTestGroupFilter: the current scene has no group-bound table (not grouped, a group too loose, or hit-spheres variant 2 / 3)");
+    if (a.scene.nGroups <= 0 || (a.scene.gmxTiles <= 0 && a.scene.nSuperPairs <= 0)) return fail("tptTestGroupFilter: the current scene is not grouped (fewer than 256 spheres, a group too loose, or hit-spheres variant 2)");
     const int nPad = (n + 63) / 64 * 64;
     float* dr = nullptr;
     unsigned long long* dout = nullptr;

@@ -129,6 +129,12 @@ int chooseKernel(FramePlan& P)
     // (so does its 64-B path record: 11 bits of sample index, 16 of sphere id)
     P.queued = g.persist == 3 && !P.rowSerial && g.hs == HS_TWO_PHASE && g.foldMode == FOLD_RECURSIVE && a.fc.width <= 65535 &&
                a.fc.height <= 65535 && g.spp <= 2047 && a.scene.nSpheres <= 65534;
+    // grouped scene on the path-queue kernel: the second level of the bounds filter reads the groups' pair records per lane -- from LDS
+    // when they fit the area the grouped instantiation's smaller path pool leaves (<= 544 groups), else from global memory; the host
+    // that asked for the FLAT filter (hitSpheres variant 3: the A/B) or for the matrix cores (variant 4) gets neither
+    a.ldsGroupPairs = -1;
+    if (P.queued && !P.ldsScene && a.scene.nGroups > 0 && a.scene.gmxTiles == 0 && a.scene.nSuperPairs > 0 && g.useMatrix)
+        a.ldsGroupPairs = tptQueueGroupPairsInLds(a.scene.nGroups, a.scene.nSuperPairs);
     P.lds = P.queued ? tptQueueLdsBytes(a, P.ldsScene) : ldsV1;
     if ((size_t)a.scene.nLights * 32 > 96 * 1024)
         return fail("tptDrawDevice: too many emissive spheres for the LDS light table (3072 at most)");

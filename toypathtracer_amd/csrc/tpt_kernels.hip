@@ -410,6 +410,16 @@ __device__ __forceinline__ f4 mk4(float x, float y, float z, float w)
 // 4096-sphere scene, tools/stats_c5.py, profiles/r04/r04_run4.log)
 #define TPT_GROUP_DEAL 1
 #endif
+#ifndef TPT_GROUP_MATRIX_BOUNDS
+// The groups' bounds on the matrix cores (hitSpheres variant 4) are compiled into the HOOKS build only: a wave that has executed that
+// path is not safe in a time-sliced process, it is no faster than the two-level VALU filter any more, and without it
+// the product's grouped instantiation executes no MFMA at all -- and needs fewer registers.
+#if defined(TPT_TEST_HOOKS)
+#define TPT_GROUP_MATRIX_BOUNDS 1
+#else
+#define TPT_GROUP_MATRIX_BOUNDS 0
+#endif
+#endif
 #ifndef TPT_GROUP_DEAL_EXACT
 #define TPT_GROUP_DEAL_EXACT 1 // the members that pass the member filter are dealt out again for their exact tests (see hitSpheresGroupedDeal)
 #endif
@@ -431,6 +441,13 @@ __device__ __forceinline__ f4 mk4(float x, float y, float z, float w)
 // 256-B margin per workgroup: chooseKernel); 960 measured no slower than 1024 (profiles/r03/r03_run10.log)
 #define TPT_Q_PATHS (TPT_MATRIX_FILTER ? 952 : TPT_Q_P)
 #endif
+#ifndef TPT_Q_PATHS_GROUPED
+// ... and of the instantiation for GROUPED scenes (no scene staging, no matrix-filter table): 816, which leaves 8.5 KB of LDS for
+// the groups' bounding spheres (pair records, 16 B per group: up to 544 groups = 68 super-groups) -- the second level of the
+// bounds filter reads them per lane, and from L2 that loop would be latency-bound
+#define TPT_Q_PATHS_GROUPED 816
+#endif
+#define TPT_Q_GROUP_LDS_BYTES ((TPT_Q_PATHS - TPT_Q_PATHS_GROUPED) * TPT_Q_NF4 * 16) /* LDS the smaller pool frees (8 704 B) */
 #ifndef TPT_Q_FUSE_MIN
 #define TPT_Q_FUSE_MIN 48 // a batch intersects its own rays when at least this many lanes still hold one
 #endif
@@ -546,8 +563,47 @@ __device__ __forceinline__ int qPop(LdsRing q, unsigned* head, unsigned* tail, i
 //     reference's first-strictly-less rule made explicit (t > tMin > 0: the bit patterns order like the values);
 //   * pairs that do not fit the list (TPT_GROUP_DEAL_CAP per round) stay in their lane's mask for the next round.
 // One wave, no barrier: a wave's LDS operations execute in order; wave_barrier only pins the compiler.
+// the packed filter of phase1Pair for one pair record read PER LANE (from LDS): two more sign bits shifted into m
+__device__ __forceinline__ void phase1PairLane(const float* rec, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f dz, uint32_t& m)
+{
+    const f4 r0 = *reinterpret_cast<const f4*>(rec), r1 = *reinterpret_cast<const f4*>(rec + 4);
+    const v2f cx = {r0.x, r0.y}, cy = {r0.z, r0.w}, cz = {r1.x, r1.y}, nsq = {r1.z, r1.w};
+    const v2f coX = cx - ox, coY = cy - oy, coZ = cz - oz;
+    const v2f nb = fma2(coZ, dz, fma2(coY, dy, coX * dx));
+    const v2f e = fma2(coZ, coZ, fma2(coY, coY, fma2(coX, coX, nsq)));
+    const v2f discr = fma2(nb, nb, -e);
+    m = alignbit(m, f2u(discr[0]), 31);
+    m = alignbit(m, f2u(discr[1]), 31);
+}
+// The groups' bounds through two levels of the packed filter, for the 256 groups from group pair pb0 on: the super-groups' bounds
+// (TPT_SUPER = 8 consecutive groups each; 16 pair records, wave-uniform scalar loads) first, then per lane the 8 groups (4 pair
+// records at gpairsLane: LDS in the path-queue kernel) of every super-group this lane's ray touches.  Super-group k of the block
+// holds groups pb0 * 2 + 8 k + j: candidate word k / 8, bit 63 - (8 (k % 8) + j).  gpairsLane must be padded to whole super-groups
+// with never-a-candidate records.
+__device__ __forceinline__ void groupMasksTwoLevel(const SceneView& sv, const float* gpairsLane, int pb0, bool go, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f dz,
+                                                   uint64_t& cm0, uint64_t& cm1, uint64_t& cm2, uint64_t& cm3)
+{
+    const int sp0 = pb0 / TPT_SUPER, leftS = sv.nSuperPairs - sp0; // (a super pair = 2 x TPT_SUPER groups = TPT_SUPER group pairs)
+    uint32_t sm = (uint32_t)(phase1Chunk(pairPtr(sv.spairs + (size_t)sp0 * 8), leftS < 16 ? leftS : 16, ox, oy, oz, dx, dy, dz) >> 32);
+    if (!go) sm = 0u;
+    while (sm) {
+        const int k = __builtin_clz(sm);
+        sm &= ~(0x80000000u >> k);
+        const float* rec = gpairsLane + (size_t)(pb0 + (TPT_SUPER / 2) * k) * 8;
+        uint32_t m = 0;
+#pragma unroll
+        for (int q = 0; q < TPT_SUPER / 2; ++q) phase1PairLane(rec + q * 8, ox, oy, oz, dx, dy, dz, m);
+        const uint64_t bits = (uint64_t)(~m & 0xffu) << (56 - 8 * (k & 7));
+        const int w = k >> 3;
+        cm0 |= w == 0 ? bits : 0ull;
+        cm1 |= w == 1 ? bits : 0ull;
+        cm2 |= w == 2 ? bits : 0ull;
+        cm3 |= w == 3 ? bits : 0ull;
+    }
+}
+template <int PATHS>
 __device__ __forceinline__ int hitSpheresGroupedDeal(const SceneView& sv, bool go, f3 o, f3 d, float& outT, LdsList list, unsigned* listCount,
-                                                     f4* st, int p, int lane)
+                                                     f4* st, int p, int lane, const float* ldsGpairs, int boundsMode)
 {
     float hitT = TPT_MAX_T;
     int id = -1;
@@ -567,9 +623,17 @@ __device__ __forceinline__ int hitSpheresGroupedDeal(const SceneView& sv, bool g
     const float gx = d.x * TPT_PG_K, gy = d.y * TPT_PG_K, gz = d.z * TPT_PG_K;
     const v2f dx = {gx, gx}, dy = {gy, gy}, dz = {gz, gz};
     bool parked = false;
-    // the bounding spheres: on the matrix cores when the scene has a table for them (one 4-KB tile pair per 64 groups, read
-    // through the vector cache: every wave of the CU reads the same 16 KB per 256 groups), else the packed VALU filter
-    const bool boundsOnMatrix = TPT_MATRIX_FILTER && sv.gmxTiles > 0;
+    // The bounding spheres of the groups, three ways (the host decides: tptSetKernelVariant / tptGetSceneInfo):
+    //   * two levels on the VALU (the default): the super-groups' bounds (TPT_SUPER = 8 consecutive groups each) through the
+    //     wave-uniform packed filter -- 16 pair records per 256 groups instead of 128 --, then every lane tests the 8 groups of
+    //     each super-group its own ray touches, their pair records read from LDS (from global memory when the scene has more groups
+    //     than the LDS area holds);
+    //   * on the matrix cores (one 4-KB tile pair per 64 groups through the vector cache) -- opt-in: in a time-sliced process
+    //     (more hardware queues than the device runs side by side) a wave that has executed this path now and then sees a
+    //     member gather of the dealing below deliver wrong data (profiles/r06);
+    //   * the flat packed filter over all groups (hitSpheres variant 3: the A/B).
+    const bool boundsOnMatrix = TPT_MATRIX_FILTER && TPT_GROUP_MATRIX_BOUNDS && sv.gmxTiles > 0;
+    const bool twoLevel = !boundsOnMatrix && boundsMode >= 0 && sv.nSuperPairs > 0; // (boundsMode = KernelArgs::ldsGroupPairs)
     MatrixRayOps mops;
     if (boundsOnMatrix) matrixRayOperands(o, d, 1, mops);
     for (int pb0 = 0; pb0 < sv.nGroupPairs; pb0 += 128) {
@@ -582,6 +646,15 @@ __device__ __forceinline__ int hitSpheresGroupedDeal(const SceneView& sv, bool g
             if (left > 64) cm1 = matrixApply(A + TPT_MXH_TABLE_DWORDS / 4, 16, left - 64 < 64 ? left - 64 : 64, mops);
             if (left > 128) cm2 = matrixApply(A + 2 * (TPT_MXH_TABLE_DWORDS / 4), 16, left - 128 < 64 ? left - 128 : 64, mops);
             if (left > 192) cm3 = matrixApply(A + 3 * (TPT_MXH_TABLE_DWORDS / 4), 16, left - 192 < 64 ? left - 192 : 64, mops);
+        } else if (twoLevel) {
+            // 128 group pairs = 256 groups = 32 super-groups: the super-groups' bounds wave-wide, then per lane the 8 groups of
+            // every super-group its ray touches (2.6 of 64 on the 4096-sphere scene), their pair records read from LDS
+            // (two call sites: the LDS pointer must stay an LDS pointer -- merged with the global one it becomes a generic pointer and
+            //  the per-lane reads FLAT loads, which reach LDS through the vector-memory path)
+            if (boundsMode > 0)
+                groupMasksTwoLevel(sv, ldsGpairs, pb0, go, ox, oy, oz, dx, dy, dz, cm0, cm1, cm2, cm3);
+            else
+                groupMasksTwoLevel(sv, sv.gpairs, pb0, go, ox, oy, oz, dx, dy, dz, cm0, cm1, cm2, cm3);
         } else {
             const int left = sv.nGroupPairs - pb0;
             cm0 = phase1Chunk(pairPtr(sv.gpairs + (size_t)pb0 * 8), left < 32 ? left : 32, ox, oy, oz, dx, dy, dz);
@@ -611,7 +684,7 @@ __device__ __forceinline__ int hitSpheresGroupedDeal(const SceneView& sv, bool g
                 }
                 if (!parked) { // (o and d do not change between rounds; the key is kept current by the atomics)
                     st[p] = mk4(u2f((uint32_t)id), hitT, o.x, o.y); // {key lo = sphere id, key hi = t bits, o.x, o.y}
-                    st[TPT_Q_PATHS + p] = mk4(o.z, d.x, d.y, d.z);
+                    st[PATHS + p] = mk4(o.z, d.x, d.y, d.z);
                     parked = true;
                 }
             }
@@ -627,7 +700,7 @@ __device__ __forceinline__ int hitSpheresGroupedDeal(const SceneView& sv, bool g
                 f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0);
                 const f4* mem = sv.gsph + (size_t)g * TPT_GROUP;
                 if (have) {
-                    const f4 r0 = st[po], r1 = st[TPT_Q_PATHS + po];
+                    const f4 r0 = st[po], r1 = st[PATHS + po];
                     ro = mk3(r0.z, r0.w, r1.x);
                     rd = mk3(r1.y, r1.z, r1.w);
                     const f3 dk = mk3(rd.x * TPT_P1_K, rd.y * TPT_P1_K, rd.z * TPT_P1_K);
@@ -664,7 +737,7 @@ __device__ __forceinline__ int hitSpheresGroupedDeal(const SceneView& sv, bool g
                 if ((unsigned)lane < nSurv) {
                     const unsigned e2 = list[base + (unsigned)lane];
                     const int po2 = (int)(e2 >> 20), slot = (int)(e2 & 0xfffffu);
-                    const f4 q0 = st[po2], q1 = st[TPT_Q_PATHS + po2];
+                    const f4 q0 = st[po2], q1 = st[PATHS + po2];
                     float ht2 = TPT_MAX_T;
                     int hid2 = -1;
                     TPT_STAT(ST_PHASE2);
@@ -726,8 +799,9 @@ __device__ __forceinline__ void traceQueueBody(const KernelArgs& a)
     // registers): path records, rings, control block, frame constants; then the scene arrays, whose sizes the launch decides
     // (kernels that stage the scene keep {centre, r^2} of up to 64 spheres -- every scene the matrix filter serves -- at offset
     //  0: phase 2 then addresses a sphere with sphere index x 16 and an immediate, like the path records)
+    constexpr int kPaths = LDS_SCENE ? TPT_Q_PATHS : TPT_Q_PATHS_GROUPED; // paths this workgroup owns
     constexpr int kOffSt = LDS_SCENE ? TPT_Q_SPH_FIXED : 0;
-    constexpr int kOffQ = kOffSt + TPT_Q_NF4 * TPT_Q_PATHS * 16;
+    constexpr int kOffQ = kOffSt + TPT_Q_NF4 * kPaths * 16;
     constexpr int kOffCtl = kOffQ + Q_COUNT * TPT_Q_P * 2;
     constexpr int kOffDeal = kOffCtl + (((int)sizeof(QueueCtl) + 63) & ~63);
     constexpr int kDealBytes = (!LDS_SCENE && TPT_GROUP_DEAL) ? TPT_Q_WAVES * TPT_GROUP_DEAL_WAVE_BYTES : 0; // pair lists of the grouped traversal
@@ -791,6 +865,12 @@ __device__ __forceinline__ void traceQueueBody(const KernelArgs& a)
     }
     for (int i = tid; i < a.scene.nLights * 2; i += TPT_Q_T) ldsLights[i] = a.scene.lights[i];
     sv.lights = ldsLights;
+    // grouped scenes: the groups' bounding spheres (pair records) for the per-lane second level of the bounds filter, padded with
+    // never-a-candidate records to whole super-groups (hitSpheresGroupedDeal); not when they do not fit (the launch says: ldsGroupPairs)
+    // (a.ldsGroupPairs: > 0 records staged in LDS, 0 read from global memory, < 0 flat filter)
+    float* ldsGpairs = reinterpret_cast<float*>(smem + ((off + 15) & ~15));
+    if (!LDS_SCENE && a.ldsGroupPairs > 0)
+        for (int i = tid; i < a.ldsGroupPairs * 8; i += TPT_Q_T) ldsGpairs[i] = a.scene.gpairs[i]; // (the host pads to whole super-groups)
 #if TPT_MATRIX_FILTER
     if (useMatrix)
         for (int i = tid; i < TPT_MXH_TABLE_DWORDS; i += TPT_Q_T) ldsA[i] = a.scene.amatH[i];
@@ -801,10 +881,10 @@ __device__ __forceinline__ void traceQueueBody(const KernelArgs& a)
 #endif
     for (int i = tid; i < (int)(sizeof(FrameConsts) / 4); i += TPT_Q_T) reinterpret_cast<uint32_t*>(ldsFc)[i] = reinterpret_cast<const uint32_t*>(&a.fc)[i];
     // every path starts in the FREE queue; all other queues empty (sentinel everywhere)
-    for (int i = tid; i < Q_COUNT * TPT_Q_P; i += TPT_Q_T) q[i] = (unsigned short)(i < TPT_Q_PATHS ? i : 0xFFFF);
+    for (int i = tid; i < Q_COUNT * TPT_Q_P; i += TPT_Q_T) q[i] = (unsigned short)(i < kPaths ? i : 0xFFFF);
     if (tid < 8) {
         ctl->head[tid] = 0u;
-        ctl->tail[tid] = tid == Q_FREE ? (unsigned)TPT_Q_PATHS : 0u;
+        ctl->tail[tid] = tid == Q_FREE ? (unsigned)kPaths : 0u;
     }
     if (tid == 0) {
         ctl->poolTotal = 0u;
@@ -824,7 +904,7 @@ __device__ __forceinline__ void traceQueueBody(const KernelArgs& a)
     unsigned* dealCount = reinterpret_cast<unsigned*>(smem + kOffDeal + (tid >> 6) * TPT_GROUP_DEAL_WAVE_BYTES + TPT_GROUP_DEAL_CAP * 4);
     const bool groupDeal = !LDS_SCENE && sv.nGroups > 0 && sv.nGroups <= 65536; // (16 bits of group index, 20 of member slot, in a list entry)
 #endif
-    f4* colSum = st + 2 * TPT_Q_PATHS;                        // plane 2: per-path colour sums + pixel coordinates
+    f4* colSum = st + 2 * kPaths;                        // plane 2: per-path colour sums + pixel coordinates
     int chunkNext = 0, chunkEnd = 0; // this wave's private pixel pool
     int chunkFrame = 0;              // batched launch: the frame of the batch that pool belongs to
     bool noMoreChunks = false;
@@ -887,7 +967,7 @@ __device__ __forceinline__ void traceQueueBody(const KernelArgs& a)
             // nothing to do for this wave right now: done if every path is free and no pixel is left anywhere
             const unsigned pool = __hip_atomic_load(&ctl->poolTotal, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const unsigned exhausted = __hip_atomic_load(&ctl->globalExhausted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (avail[Q_FREE] == (unsigned)TPT_Q_PATHS && pool == 0u && exhausted != 0u && !canStart) break;
+            if (avail[Q_FREE] == (unsigned)kPaths && pool == 0u && exhausted != 0u && !canStart) break;
             if (exhausted != 0u && pool == 0u) noMoreChunks = true;
             TPT_STAT(ST_REFILL); // idle polls
 #if defined(TPT_STATS)
@@ -923,14 +1003,14 @@ __device__ __forceinline__ void traceQueueBody(const KernelArgs& a)
         bool toFree = false; // this lane's path goes back to the FREE queue
         bool toEnd = false;  // Metal whose scattered ray points into the surface: the path ends (END class), nothing to intersect
         QStack stack;
-        stack.l0 = (LdsF4Ptr)(st + 3 * TPT_Q_PATHS + p); // level 0 in the path record
+        stack.l0 = (LdsF4Ptr)(st + 3 * kPaths + p); // level 0 in the path record
         stack.spill = a.stackBuf + ((size_t)(blockIdx.x + (unsigned)a.helperBase) * TPT_Q_PATHS + p);
         stack.stride = a.stackStride;
         QLambert lam;
         lam.sdir = lam.nl = lam.albedo = lam.lightE = mk3(0, 0, 0);
         lam.cosAMax = 0.0f;
         if (pick != Q_FREE && mine) {
-            const f4 r0 = st[0 * TPT_Q_PATHS + p], r1 = st[1 * TPT_Q_PATHS + p];
+            const f4 r0 = st[0 * kPaths + p], r1 = st[1 * kPaths + p];
             ro = mk3(r0.x, r0.y, r0.z);
             rng = f2u(r0.w);
             rd = mk3(r1.x, r1.y, r1.z);
@@ -1104,7 +1184,7 @@ __device__ __forceinline__ void traceQueueBody(const KernelArgs& a)
                 int dealId = -1;
                 float dealT = TPT_MAX_T;
                 if (!LDS_SCENE && groupDeal) // (wave-uniform: every lane takes part, lanes without a ray as helpers only)
-                    dealId = hitSpheresGroupedDeal(sv, go, ro, d2, dealT, dealList, dealCount, st, p, lane);
+                    dealId = hitSpheresGroupedDeal<kPaths>(sv, go, ro, d2, dealT, dealList, dealCount, st, p, lane, ldsGpairs, a.ldsGroupPairs);
 #endif
                 if (go) {
                     TPT_STAT(ST_STEP);
@@ -1147,8 +1227,8 @@ __device__ __forceinline__ void traceQueueBody(const KernelArgs& a)
         if (toEnd) cls = Q_END;
         if (ray || toEnd) {
             const uint32_t w = ((uint32_t)sample & 0x7ffu) | (((uint32_t)depth & 15u) << 11) | ((uint32_t)doMatE << 15) | (((uint32_t)recId & 0xffffu) << 16);
-            st[0 * TPT_Q_PATHS + p] = mk4(ro.x, ro.y, ro.z, u2f(rng));
-            st[1 * TPT_Q_PATHS + p] = mk4(rd.x, rd.y, rd.z, u2f(w));
+            st[0 * kPaths + p] = mk4(ro.x, ro.y, ro.z, u2f(rng));
+            st[1 * kPaths + p] = mk4(rd.x, rd.y, rd.z, u2f(w));
         }
         if (toFree) cls = Q_FREE;
         if (BATCH && iterRays != 0u) { // (one LDS atomic per lane and iteration)
@@ -1346,9 +1426,45 @@ __global__ void __launch_bounds__(64) tptGroupFilterTestKernel(const KernelArgs 
         o = mk3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]);
         d = mk3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
     }
+    unsigned long long bad = 0, kept = 0, exact = 0;
+    if (sv.gmxTiles == 0) {
+        // no matrix-core table in the scene set (the default): the two-level packed VALU filter of the path-queue kernel, the groups'
+        // pair records read per lane from global memory here (the kernel stages them in LDS when they fit)
+        const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+        const float gx = d.x * TPT_PG_K, gy = d.y * TPT_PG_K, gz = d.z * TPT_PG_K;
+        const v2f dx = {gx, gx}, dy = {gy, gy}, dz = {gz, gz};
+        for (int pb0 = 0; pb0 < sv.nGroupPairs; pb0 += 128) {
+            uint64_t cm[4] = {0, 0, 0, 0};
+            groupMasksTwoLevel(sv, sv.gpairs, pb0, real, ox, oy, oz, dx, dy, dz, cm[0], cm[1], cm[2], cm[3]);
+            if (!real) continue;
+            for (int w = 0; w < 4; ++w) {
+                kept += (unsigned long long)__popcll(cm[w]);
+                for (int q = 0; q < 64; ++q) {
+                    const int grp = pb0 * 2 + w * 64 + q;
+                    if (grp >= sv.nGroups) break;
+                    const bool keptBit = (cm[w] >> (63 - q)) & 1ull;
+                    const f4* mem = sv.gsph + (size_t)grp * TPT_GROUP;
+                    for (int j = 0; j < TPT_GROUP; ++j) {
+                        const f4 s = mem[j];
+                        const float coX = s.x - o.x, coY = s.y - o.y, coZ = s.z - o.z;
+                        const float nb = coX * d.x + coY * d.y + coZ * d.z;
+                        const float c = coX * coX + coY * coY + coZ * coZ - s.w;
+                        const float discr = nb * nb - c;
+                        if (discr > 0) {
+                            ++exact;
+                            if (!keptBit) ++bad;
+                        }
+                    }
+                }
+            }
+        }
+        if (bad) atomicAdd(&out[0], bad);
+        atomicAdd(&out[1], kept);
+        atomicAdd(&out[2], exact);
+        return;
+    }
     MatrixRayOps mops;
     matrixRayOperands(o, d, 1, mops);
-    unsigned long long bad = 0, kept = 0, exact = 0;
     for (int t = 0; t < sv.gmxTiles; ++t) {
         const int left = sv.nGroups - t * 64;
         const uint64_t m = matrixApply(reinterpret_cast<const uint4*>(sv.gmatH) + (size_t)t * (TPT_MXH_TABLE_DWORDS / 4), 16, left < 64 ? left : 64, mops);
@@ -1475,8 +1591,9 @@ size_t tptQueueLdsBytes(const KernelArgs& a, bool ldsScene)
     size_t bytes = 0;
     if (ldsScene) bytes += TPT_Q_SPH_FIXED + ((size_t)nPad * 16 <= TPT_Q_SPH_FIXED ? 0 : (size_t)nPad * 16) + (((size_t)nPad * 4 + 15) & ~(size_t)15) + (size_t)a.scene.nSpheres * 48;
     bytes += (size_t)a.scene.nLights * 32;
-    bytes += (size_t)TPT_Q_NF4 * TPT_Q_PATHS * 16 + (size_t)Q_COUNT * TPT_Q_P * 2 + ((sizeof(QueueCtl) + 63) & ~(size_t)63) + ((sizeof(FrameConsts) + 15) & ~(size_t)15);
+    bytes += (size_t)TPT_Q_NF4 * (ldsScene ? TPT_Q_PATHS : TPT_Q_PATHS_GROUPED) * 16 + (size_t)Q_COUNT * TPT_Q_P * 2 + ((sizeof(QueueCtl) + 63) & ~(size_t)63) + ((sizeof(FrameConsts) + 15) & ~(size_t)15);
     if (!ldsScene && TPT_GROUP_DEAL) bytes += (size_t)TPT_Q_WAVES * TPT_GROUP_DEAL_WAVE_BYTES;
+    if (!ldsScene && a.ldsGroupPairs > 0) bytes += 16 + (size_t)a.ldsGroupPairs * 32; // the groups' bounds for the second filter level (tptQueueGroupPairsInLds)
 #if TPT_MATRIX_FILTER
     if (ldsScene && a.scene.mxR1 >= 0) bytes += TPT_MXH_TABLE_DWORDS * sizeof(uint32_t) + 64;
 #endif
@@ -1499,8 +1616,17 @@ hipError_t tptLaunchTraceQueue(const KernelArgs& a, bool ldsScene, int blocks, s
     if (e != hipSuccess) return e;
     return hipGetLastError();
 }
-int tptQueuePathsPerBlock() { return TPT_Q_PATHS; }
+int tptQueuePathsPerBlock() { return TPT_Q_PATHS; } // (the larger of the two pools: what per-workgroup buffers are sized for)
+// Pair records of the groups' bounds the grouped instantiation keeps in LDS for a scene of nGroups groups: whole super-groups
+// (padded), or 0 when they do not fit the area the smaller path pool leaves (the flat filter runs over all groups then)
+int tptQueueGroupPairsInLds(int nGroups, int nSuperPairs)
+{
+    if (nGroups <= 0 || nSuperPairs <= 0) return 0;
+    const int pairs = ((nGroups + TPT_SUPER - 1) / TPT_SUPER) * (TPT_SUPER / 2);
+    return (size_t)pairs * 32 + 16 <= (size_t)TPT_Q_GROUP_LDS_BYTES ? pairs : 0;
+}
 int tptQueueMatrixFilter() { return TPT_MATRIX_FILTER; }
+int tptQueueGroupMatrixBounds() { return TPT_MATRIX_FILTER && TPT_GROUP_MATRIX_BOUNDS; }
 int tptQueueThreadsPerBlock() { return TPT_Q_T; }
 
 hipError_t tptLaunchDisplay(const float* tile, unsigned char* rgba, int width, int height, hipStream_t stream)

@@ -125,6 +125,11 @@ struct PackedScene {
     std::vector<f4> bsph;      // the big spheres {centre, r^2} ...
     std::vector<int> bid;      // ... and their original indices (ascending)
     int nGroups = 0, nGroupPairs = 0, nBig = 0;
+    // second level over the groups: super-group k bounds groups [TPT_SUPER k, TPT_SUPER (k + 1)) -- consecutive leaves of the median
+    // splits, i.e. one subtree; same pair-record format and slack as gpairs (a super-group too loose for the filter's slack
+    // carries R^2 = +inf: always a candidate)
+    std::vector<float> spairs; // [nSuperPairs][8]
+    int nSupers = 0, nSuperPairs = 0;
     std::vector<uint32_t> amatH; // [2][2][64][4] A operands of the matrix-core filter (phase1MatrixH); empty: not available
     int mxR1 = -1;
     std::vector<uint32_t> gmatH; // grouped scenes: [tiles of 64 groups][2][2][64][4] A operands for the group bounds; empty: not available
@@ -241,8 +246,8 @@ inline void buildGroupMatrixTable(PackedScene& P, const std::vector<float>& C3, 
 // (tpt_trace.h, hitSpheresGrouped).
 inline void buildGroups(const std::vector<SpherePOD>& S, PackedScene& P)
 {
-    P.gpairs.clear(); P.gsph.clear(); P.gid.clear(); P.bsph.clear(); P.bid.clear(); P.gmatH.clear();
-    P.nGroups = P.nGroupPairs = P.nBig = 0; P.gmxTiles = 0;
+    P.gpairs.clear(); P.gsph.clear(); P.gid.clear(); P.bsph.clear(); P.bid.clear(); P.gmatH.clear(); P.spairs.clear();
+    P.nGroups = P.nGroupPairs = P.nBig = 0; P.gmxTiles = 0; P.nSupers = P.nSuperPairs = 0;
     const int n = (int)S.size();
     if (n < TPT_GROUP_MIN_SPHERES) return;
     std::vector<float> radii(n);
@@ -318,11 +323,13 @@ inline void buildGroups(const std::vector<SpherePOD>& S, PackedScene& P)
     std::sort(big.begin(), big.end());
     const int nGroups = (int)groups.size();
     const int nGroupPairs = (nGroups + 1) / 2;
-    std::vector<float> gpairs((size_t)nGroupPairs * 8, 0.0f);
+    // (records for whole super-groups: the second level of the bounds filter reads TPT_SUPER / 2 pair records per super-group)
+    const int nGroupPairsPadded = ((nGroups + TPT_SUPER - 1) / TPT_SUPER) * (TPT_SUPER / 2);
+    std::vector<float> gpairs((size_t)nGroupPairsPadded * 8, 0.0f);
     std::vector<f4> gsph((size_t)nGroups * TPT_GROUP);
     std::vector<int> gid((size_t)nGroups * TPT_GROUP, -1);
     for (size_t k = 0; k < gsph.size(); ++k) { f4 v = {0, 0, 0, negInf}; gsph[k] = v; }
-    for (int g = 0; g < nGroupPairs * 2; ++g) {
+    for (int g = 0; g < nGroupPairsPadded * 2; ++g) {
         float* rec = &gpairs[(size_t)(g / 2) * 8];
         if (g >= nGroups) { // padding group: never a candidate
             rec[6 + (g & 1)] = posInf;
@@ -347,6 +354,40 @@ inline void buildGroups(const std::vector<SpherePOD>& S, PackedScene& P)
         P.bid.push_back(i);
     }
     P.nGroups = nGroups; P.nGroupPairs = nGroupPairs; P.nBig = (int)big.size();
+    {
+        // super-groups: TPT_SUPER consecutive groups each (the leaves are in the order of the median splits, so they are one
+        // subtree -- spatially compact).  The bound is a sphere around the mean of the MEMBER SPHERES' centres that holds every
+        // member sphere; the filter's slack argument (tpt_trace.h, "Group bounds are looser ...") is the groups' own with a = the
+        // member's distance from the super-group's centre, so it needs rho = max a / r <= 64 here as well -- a super-group that
+        // fails it is always a candidate (-R^2 = -inf).
+        const int nSupers = (nGroups + TPT_SUPER - 1) / TPT_SUPER, nSuperPairs = (nSupers + 1) / 2;
+        std::vector<float> spairs((size_t)nSuperPairs * 8, 0.0f);
+        for (int k = 0; k < nSuperPairs * 2; ++k) {
+            float* rec = &spairs[(size_t)(k / 2) * 8];
+            if (k >= nSupers) { rec[6 + (k & 1)] = posInf; continue; }
+            double c[3] = {0, 0, 0};
+            size_t cnt = 0;
+            for (int g = k * TPT_SUPER; g < (k + 1) * TPT_SUPER && g < nGroups; ++g)
+                for (int i : groups[g].mem) { c[0] += S[i].cx; c[1] += S[i].cy; c[2] += S[i].cz; ++cnt; }
+            float C[3];
+            for (int a = 0; a < 3; ++a) C[a] = (float)(c[a] / (double)cnt);
+            double R = 0, rho = 0;
+            for (int g = k * TPT_SUPER; g < (k + 1) * TPT_SUPER && g < nGroups; ++g)
+                for (int i : groups[g].mem) {
+                    const double dxx = (double)S[i].cx - C[0], dyy = (double)S[i].cy - C[1], dzz = (double)S[i].cz - C[2];
+                    const double a = sqrt(dxx * dxx + dyy * dyy + dzz * dzz), r = radii[i];
+                    R = std::max(R, a + r);
+                    rho = std::max(rho, r > 0 ? a / r : 1e300);
+                }
+            R *= 1.00001;
+            rec[0 + (k & 1)] = C[0];
+            rec[2 + (k & 1)] = C[1];
+            rec[4 + (k & 1)] = C[2];
+            rec[6 + (k & 1)] = rho <= 64.0 ? (float)(-(R * R) * (1.0 + 1.0 / 4096.0)) : negInf;
+        }
+        P.spairs.swap(spairs);
+        P.nSupers = nSupers; P.nSuperPairs = nSuperPairs;
+    }
     {
         std::vector<float> C3((size_t)nGroups * 3);
         std::vector<double> Rg((size_t)nGroups);
@@ -435,6 +476,8 @@ inline SceneView viewOf(const PackedScene& P)
     sv.nGroups = P.nGroups;
     sv.nGroupPairs = P.nGroupPairs;
     sv.nBig = P.nBig;
+    sv.spairs = P.spairs.data();
+    sv.nSuperPairs = P.nSuperPairs;
     sv.amatH = P.amatH.empty() ? nullptr : P.amatH.data();
     sv.mxR1 = P.mxR1;
     sv.gmatH = P.gmatH.empty() ? nullptr : P.gmatH.data();

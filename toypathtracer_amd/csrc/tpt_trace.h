@@ -73,6 +73,9 @@ struct SceneView {
     const f4* bsph;
     const int* bid;
     int nGroups, nGroupPairs, nBig;
+    // second level: bounding spheres of TPT_SUPER consecutive groups each, pair-record format (packScene); 0 pairs: none
+    const float* spairs;
+    int nSuperPairs;
     // Matrix-core form of the phase-1 filter (scenes of <= 64 spheres in binary16 range; see phase1MatrixH): amatH =
     // [2][2][64][4] dwords, the A operands of the 2 x 2 v_mfma_f32_32x32x16_f16 a ray tile needs; mxR1 = rows per half of the
     // second sphere tile that hold spheres (0, 4, ..., 16); mxR1 < 0: no table.
@@ -90,6 +93,7 @@ enum { SCENE_LIGHT_R2_DIV_SAFE = 1 }; // every light's radius^2 lies in [2^-60, 
                        to visit -- 4096-sphere scene: 7.9 / 7.7 / 7.8 / 7.8 / 7.05 / 3.6 Gray/s at 4 / 6 / 8 / 12 / 16 / 32 (profiles/r04/r04_run15-16.log) */
 #endif
 #define TPT_GROUP_MIN_SPHERES 256
+#define TPT_SUPER 8 /* groups per super-group (one 64-bit candidate word holds 8 super-groups' groups) */
 
 struct FrameConsts {
     CameraPOD cam;

@@ -13,11 +13,10 @@ shadow, exactly the reference's counter, Test.cpp:122,199) of the K timed frames
 ranks, divided by the max-over-ranks wall time between two barrier+synchronize brackets.
 For N > 1 the frame's rows are dealt out in 8-row stripes round-robin over the ranks and every step
 includes its exchange -- ONE RCCL gather to rank 0 of each rank's blended tile plus a row carrying its
-64-bit ray counter, software-pipelined against the next frames.  By default that exchange is the
-product's own: the C ABI a Test.h host uses (tptCommGetUniqueId / tptCommInit / tptDrawSharded /
-tptShardedFinish, include/tpt_hip.h section 3; the 128-byte id travels over torch.distributed's
-store) -- "exchange": "cabi" in the JSON line.  --exchange torch drives the torch.distributed twin
-(toypathtracer_amd/sharding.py) instead.  Total work is fixed as N grows -> "scaling": "strong".
+64-bit ray counter, software-pipelined against the next frames.  That exchange is the product's own:
+the C ABI a Test.h host uses (tptCommGetUniqueId / tptCommInit / tptDrawSharded / tptShardedFinish,
+include/tpt_hip.h section 3; torch.distributed only carries the 128-byte id and the timing reductions)
+-- "exchange": "cabi" in the JSON line.  Total work is fixed as N grows -> "scaling": "strong".
 
 One JSON line on rank 0, with
   roofline     : the trace kernel against the HBM roofline the north_star names (algorithmic bytes =
@@ -436,10 +435,10 @@ def main():
                     help="trace kernels of up to this many consecutive frames may be in flight (0 = auto: 16, or 8 when the frame is "
                          "sharded over more than 2 ranks -- with small tiles the per-packet latency of many active queues costs more "
                          "than the extra overlap buys)")
-    ap.add_argument("--exchange", default="auto", choices=["auto", "none", "cabi", "torch"],
+    ap.add_argument("--exchange", default="auto", choices=["auto", "none", "cabi"],
                     help="how a sharded frame is exchanged: cabi = the library's own RCCL gather (tptCommInit / tptDrawSharded / "
-                         "tptShardedFinish, what a C++ Test.h host uses; default for N > 1), torch = toypathtracer_amd/sharding.py over "
-                         "torch.distributed, none = no exchange (default for N = 1: plain tptDrawDevice)")
+                         "tptShardedFinish, what a C++ Test.h host uses; default for N > 1, and at N = 1 a one-rank communicator so that the "
+                         "gather path really runs), none = no exchange (default for N = 1: plain tptDrawDevice on a device tile)")
     ap.add_argument("--parity-frames", type=int, default=64, help="check the final image against the oracle when the run has at most this many frames (0 = never)")
     ap.add_argument("--parity-samples", type=float, default=1.6e8,
                     help="... and at most this many camera samples in total (frames x width x height x spp): bounds the oracle leg to ~10 s "
@@ -471,7 +470,7 @@ def main():
     device = torch.device("cuda", local_rank)
     os.environ.setdefault("TPT_DEVICE", str(local_rank))
     dist = None
-    if world > 1 or args.exchange == "torch":  # (--exchange torch at world size 1: a one-rank process group, so the gather path really runs)
+    if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -485,7 +484,6 @@ def main():
             raise
 
     from toypathtracer_amd import api
-    from toypathtracer_amd.sharding import ShardedFrame
 
     width, height, spp, scene, label = WORKLOADS[args.workload]
     api.InitializeTest()
@@ -541,34 +539,25 @@ def main():
                 dist.barrier()
             torch.cuda.synchronize()
     else:
-        api.set_row_shard(args.stripe_rows, world, rank)
-        sf = ShardedFrame(width, height, args.stripe_rows, rank, world, device, dist)
-        api.set_stream(sf.render_stream.cuda_stream)
-        api.set_ray_counter(sf.ray_counter.data_ptr())
-        tile_ptr = sf.tile.data_ptr()
+        # one GPU, no exchange: the product's plain device path -- tptDrawDevice on a tile that stays resident in HBM, the library's own
+        # (blocking) stream and ray counter
+        api.set_row_shard(0, 1, 0)
+        tile = torch.zeros((height, width, 4), dtype=torch.float32, device=device)  # (filled on torch's default stream: the library's stream is ordered behind it)
+        tile_ptr = tile.data_ptr()
 
         def step(frame):
             t = frame / 60.0 if args.animate else 0.0
-            mirror = sf.mirror_pointers()  # sharded: the resolve kernel also fills the snapshot the gather sends
-            if mirror:
-                sf.begin_frame()
-                api.set_tile_mirror(*mirror)
             api.UpdateTest(t, frame, width, height, flags)
             if args.batch > 1:
                 api.draw_device_batch(t, frame, args.batch, width, height, tile_ptr, flags)
             else:
                 api.draw_device(t, frame, width, height, tile_ptr, flags)
-            sf.exchange(snapshot_done=bool(mirror))
 
         def rays_so_far():
-            return int(sf.ray_counter.item())
+            return api.ray_counter_read()
 
         def fence():
-            sf.render_stream.synchronize()
-            sf.comm_stream.synchronize()
-            torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
+            api.synchronize()
             torch.cuda.synchronize()
 
     if args.prime < 0:
@@ -606,8 +595,8 @@ def main():
         if rank != 0:
             rays_local = 0  # rank 0's difference already is the sum over the ranks (the counters ride in the gathered tiles)
     else:
-        image, _total = sf.finish()
-        rays_all_frames = None
+        image = tile
+        rays_all_frames = rays_end
 
     stats = torch.tensor([dt, float(rays_local), kernel_ms, pipeline_ms], dtype=torch.float64, device=device)
     if dist is not None:
@@ -661,7 +650,7 @@ def main():
             "metric": "Mray/s", "value": rays_total / dt / 1e6, "unit": "Mray/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "exchange": exchange, "rccl_ranks": rccl_ranks if exchange == "cabi" else (world if exchange == "torch" else 0),
+            "exchange": exchange, "rccl_ranks": rccl_ranks if exchange == "cabi" else 0,
             "config": {"workload": label, "width": width, "height": height, "spp": spp, "spheres": n_spheres,
                        "seed_mode": "per_pixel", "fold": "forward" if args.fold else "recursive",
                        "hit_spheres": ["two_phase" + ("+groups+two_level_valu_bounds" if n_spheres >= 256 else "+matrix_core_filter" if n_spheres <= 64 else ""), "simple", "two_phase_brute_force", "two_phase_flat_valu_filter",
@@ -772,7 +761,7 @@ def main():
             api.set_row_shard(0, 1, 0)
             api.set_seed_mode(1)
             out["secondary"] = {}
-            plan = {"c2_steady": ("c2", 36, 200, 16), "c3": ("c3", 4, 9, 16), "c5": ("c5", 2, 10, 16)}
+            plan = {"c2_steady": ("c2", 36, 200, 16), "c3": ("c3", 4, 9, 16), "c5": ("c5", 16, 16, 16)}
             for leg in [x for x in sec.split(",") if x]:
                 wl, untimed, steps, ov = plan[leg]
                 drain_lookahead(api)

@@ -202,6 +202,12 @@ TPT_API int tptCommInitLoopback(int nRanks, int stripeRows);
 TPT_API int tptCommInfo(int* outRanks, int* outRank, int* outLoopback);
 TPT_API int tptCommDestroy(void);
 TPT_API int tptDrawSharded(float time, int frameCount, int screenWidth, int screenHeight, float* deviceImageOnRoot, unsigned testFlags);
+/* How often tptDrawSharded exchanges.  0 (default) = automatic: every frame when a rank's tile is 2.4 M samples per frame or more
+ * (rows x width x spp) and for animated scenes; every 2nd / 4th frame below -- with small tiles the exchange chain (blend + snapshot,
+ * gather, de-interleave: three dispatches beside a machine full of trace workgroups) bounds the frame rate, not the arithmetic.
+ * k >= 1 = every k-th frame.  Frames in between are blended into the rank's resident tile only; the image on rank 0 is current
+ * after an exchanging frame and after tptShardedFinish (which exchanges whatever is outstanding).  EVERY rank must choose the same. */
+TPT_API int tptSetShardExchangeInterval(int everyKFrames);
 /* nFrames (1..32) consecutive frames per call, traced by one launch per rank (tptDrawDeviceBatch) and followed by ONE exchange:
  * rank 0's image is that of the batch's last frame.  Same bits as nFrames tptDrawSharded calls. */
 TPT_API int tptDrawShardedBatch(float time, int firstFrame, int nFrames, int screenWidth, int screenHeight, float* deviceImageOnRoot, unsigned testFlags);

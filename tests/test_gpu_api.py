@@ -411,14 +411,14 @@ def test_bench_runs_on_two_ranks_over_rccl(tmp_path):
 
 
 def test_bench_exchanges_agree_at_world_size_one():
-    """bench.py's three data paths at world size 1 -- no exchange (plain tptDrawDevice), the library's own RCCL exchange
-    (tptCommInit / tptDrawSharded / tptShardedFinish: a real one-rank RCCL communicator) and the torch.distributed twin --
-    give the same final image (FNV-1a of the float buffer) and the same ray total, and each equals the oracle (the bench's
-    own checker leg)."""
+    """bench.py's two data paths at world size 1 -- no exchange (plain tptDrawDevice) and the library's own RCCL exchange
+    (tptCommInit / tptDrawSharded / tptShardedFinish: a real one-rank RCCL communicator; there is no second implementation since
+    round 6) -- give the same final image (FNV-1a of the float buffer) and the same ray total, and each equals the oracle (the
+    bench's own checker leg)."""
     import json
     import sys
     lines = {}
-    for ex in ("none", "cabi", "torch"):
+    for ex in ("none", "cabi"):
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29531", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
         out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--prime", "3",
                                        "--workload", "c1", "--exchange", ex, "--no-cpu-baseline", "--no-extras"], stderr=subprocess.DEVNULL, env=env,

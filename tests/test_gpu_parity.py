@@ -339,57 +339,6 @@ def test_seventy_pipelined_frames_at_config2(tpt_defaults, oracle, persist, over
     assert rays == ro and tile.cpu().numpy().tobytes() == bo.tobytes()
 
 
-@pytest.mark.parametrize("world,stripe", [(2, 8), (3, 4)])
-def test_sharded_frame_exchange_on_device(tpt_defaults, oracle, world, stripe):
-    """The code path bench.py --gpus N runs on every rank (ShardedFrame on CUDA tensors and streams, snapshot written by
-    the resolve kernel through tptSetTileMirror, 4-deep send ring, assemble on rank 0), with the ranks played one after
-    the other in this process and a stand-in for the collective that hands the stashed send buffers to rank 0."""
-    import torch
-    from toypathtracer_amd.sharding import ShardedFrame
-    tpt = tpt_defaults
-    w, h, frames = 160, 100, 7
-    dev = torch.device("cuda", 0)
-    stash = {}
-
-    class Relay:
-        def __init__(self, rank):
-            self.rank, self.step = rank, 0
-
-        def gather(self, tensor, gather_list=None, dst=0):
-            if self.rank != 0:
-                stash[(self.rank, self.step)] = tensor.clone()
-            else:
-                gather_list[0].copy_(tensor)
-                for r in range(1, world):
-                    gather_list[r].copy_(stash[(r, self.step)])
-            self.step += 1
-
-    image = total = None
-    for rank in list(range(1, world)) + [0]:
-        tpt.set_row_shard(stripe, world, rank)
-        sf = ShardedFrame(w, h, stripe, rank, world, dev, Relay(rank))
-        tpt.set_stream(sf.render_stream.cuda_stream)
-        tpt.set_ray_counter(sf.ray_counter.data_ptr())
-        for f in range(frames):
-            sf.begin_frame()
-            tpt.set_tile_mirror(*sf.mirror_pointers())
-            tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
-            tpt.draw_device(0.0, f, w, h, sf.tile.data_ptr(), FLAG_PROGRESSIVE)
-            sf.exchange(snapshot_done=True)
-        img, tot = sf.finish()
-        torch.cuda.synchronize()
-        tpt.set_tile_mirror(None)
-        tpt.set_ray_counter(None)
-        tpt.set_stream(None)
-        if rank == 0:
-            image, total = img.cpu().numpy(), tot
-    tpt.set_row_shard(0, 1, 0)
-    ro, bo, _ = oracle_frames(oracle, w, h, 4, frames, seed_mode=SEED_PER_PIXEL)
-    assert total == ro, (total, ro, tpt.pipeline_info())
-    bad = np.argwhere((image.view(np.uint32) != bo.view(np.uint32)).any(axis=2))
-    assert len(bad) == 0, "%d pixels differ, first rows %s" % (len(bad), sorted(set(bad[:, 0].tolist()))[:12])
-
-
 def test_tile_mirror_snapshot(tpt_defaults, oracle):
     """tptSetTileMirror: the resolve kernel also writes the blended tile (and the ray counter) to a second buffer -- the
     snapshot a sharded host hands to its gather.  Rotating mirrors every frame, as bench.py does."""

@@ -1,6 +1,6 @@
 """Rank 0 of an N-way sharded run on ONE GPU through the C ABI alone (tptCommInitLoopback: same tile, snapshot ring, events and
 assemble kernel as tptCommInit, a device copy instead of ncclGather).  Prints what this GPU sustains as rank 0 and the
-aggregate N x that -- the render + exchange pipeline apart from RCCL itself.  TPT_EMU_N=1,2,4,8 TPT_EMU_FRAMES=300"""
+aggregate N x that -- the render + exchange pipeline apart from RCCL itself.  TPT_EMU_N=1,2,4,8 TPT_EMU_FRAMES=300 TPT_EMU_EVERY=0|1|k"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -18,6 +18,7 @@ torch.cuda.synchronize()
 base = None
 for n in [int(v) for v in os.environ.get("TPT_EMU_N", "1,2,4,8").split(",")]:
     api.comm_init_loopback(n, 8)
+    api.set_shard_exchange_interval(int(os.environ.get("TPT_EMU_EVERY", "0")))  # 0: automatic (every 2nd / 4th frame for small tiles), 1: every frame
     if os.environ.get("TPT_EMU_OV"):
         api.set_frame_overlap(int(os.environ["TPT_EMU_OV"]))
     for f in range(0, warm, batch):

@@ -39,7 +39,7 @@ C_ABI_SYMBOLS = [
     "tptSetSamplesPerPixel", "tptSetConfig", "tptSetSeedMode", "tptSetFoldMode", "tptSetScene", "tptSetCamera", "tptSetStream",
     "tptSetRowShard", "tptLocalRowCount", "tptLocalRowToGlobal", "tptDrawDevice", "tptRayCounterRead", "tptSetRayCounter", "tptSetFrameOverlap", "tptDisplayRGBA8", "tptKernelTimingBegin", "tptKernelTimingEnd",
     "tptSynchronize", "tptTimerBegin", "tptTimerEnd", "tptSetKernelVariant",
-    "tptDrawDeviceBatch", "tptDrawShardedBatch", "tptGetLookaheadHits", "tptCommGetUniqueId", "tptCommInit", "tptCommInitLoopback", "tptCommInfo", "tptCommDestroy", "tptDrawSharded", "tptShardedFinish", "tptGetLaunchInfo", "tptGetPipelineInfo", "tptGetSceneInfo", "tptSetHostBufferMode", "tptSetHostLookahead", "tptSetStreamBatching", "tptSetTileMirror", "tptGetLastError", "tptGetDeviceName",
+    "tptDrawDeviceBatch", "tptDrawShardedBatch", "tptGetLookaheadHits", "tptCommGetUniqueId", "tptCommInit", "tptCommInitLoopback", "tptCommInfo", "tptCommDestroy", "tptDrawSharded", "tptSetShardExchangeInterval", "tptShardedFinish", "tptGetLaunchInfo", "tptGetPipelineInfo", "tptGetSceneInfo", "tptSetHostBufferMode", "tptSetHostLookahead", "tptSetStreamBatching", "tptSetTileMirror", "tptGetLastError", "tptGetDeviceName",
 ]
 # include/tpt_test_hooks.h: exported by the second build (libtoypathtracer_hip_hooks.so) only
 HOOK_SYMBOLS = ["tptTestMath", "tptTestMathExhaustive", "tptTestHitSpheres", "tptTestMatrixFilter", "tptTestGroupFilter", "tptDebugStats", "tptDebugChunkOrder"]
@@ -78,7 +78,7 @@ def _bind(path, hooks):
         "tptSetRayCounter": [p], "tptSetTileMirror": [p, p], "tptSetFrameOverlap": [i], "tptDisplayRGBA8": [p, i, i, p], "tptKernelTimingBegin": [i],
         "tptKernelTimingEnd": [C.POINTER(f), C.POINTER(i)],
         "tptSynchronize": [], "tptTimerBegin": [], "tptTimerEnd": [C.POINTER(f)], "tptSetKernelVariant": [i, i, i],
-        "tptGetLaunchInfo": [C.POINTER(i)] * 4, "tptGetPipelineInfo": [C.POINTER(i)] * 4, "tptGetSceneInfo": [C.POINTER(i)] * 3, "tptCommGetUniqueId": [p], "tptCommInit": [p, i, i, i], "tptCommInitLoopback": [i, i], "tptCommInfo": [C.POINTER(i)] * 3, "tptCommDestroy": [], "tptDrawSharded": [f, i, i, i, p, u], "tptDrawShardedBatch": [f, i, i, i, i, p, u], "tptDrawDeviceBatch": [f, i, i, i, i, p, u], "tptShardedFinish": [C.POINTER(C.c_int64)], "tptSetHostBufferMode": [i], "tptGetLookaheadHits": [C.POINTER(C.c_longlong)], "tptSetHostLookahead": [i], "tptSetStreamBatching": [i],
+        "tptGetLaunchInfo": [C.POINTER(i)] * 4, "tptGetPipelineInfo": [C.POINTER(i)] * 4, "tptGetSceneInfo": [C.POINTER(i)] * 3, "tptCommGetUniqueId": [p], "tptCommInit": [p, i, i, i], "tptCommInitLoopback": [i, i], "tptCommInfo": [C.POINTER(i)] * 3, "tptCommDestroy": [], "tptDrawSharded": [f, i, i, i, p, u], "tptSetShardExchangeInterval": [i], "tptDrawShardedBatch": [f, i, i, i, i, p, u], "tptDrawDeviceBatch": [f, i, i, i, i, p, u], "tptShardedFinish": [C.POINTER(C.c_int64)], "tptSetHostBufferMode": [i], "tptGetLookaheadHits": [C.POINTER(C.c_longlong)], "tptSetHostLookahead": [i], "tptSetStreamBatching": [i],
     }
     if hooks:
         sigs.update({"tptDebugStats": [p, i], "tptDebugChunkOrder": [p, p, i], "tptTestMath": [i, p, p, p, i], "tptTestMathExhaustive": [i, u, u, p, p],
@@ -378,6 +378,11 @@ def comm_destroy():
 
 def draw_sharded(time, frameCount, screenWidth, screenHeight, device_image_ptr, testFlags):
     _chk(load_library().tptDrawSharded(time, frameCount, screenWidth, screenHeight, device_image_ptr, testFlags), "tptDrawSharded")
+
+
+def set_shard_exchange_interval(k):
+    """0 = automatic (every frame for big tiles, every 2nd / 4th for small ones), k >= 1 = every k-th frame; same on every rank"""
+    _chk(load_library().tptSetShardExchangeInterval(k), "tptSetShardExchangeInterval")
 
 
 def draw_sharded_batch(time, firstFrame, nFrames, screenWidth, screenHeight, device_image_ptr, testFlags):

@@ -214,7 +214,14 @@ struct Context {
         float* gathered = nullptr;      // rank 0: [nRanks][padRows + 1][w] f4
         hipEvent_t evSnap[kRing] = {}, evSent[kRing] = {};
         bool sentRecorded[kRing] = {};
-        unsigned long long frames = 0;
+        unsigned long long frames = 0;  // exchanges enqueued (index into the snapshot ring)
+        // exchange interval (tptSetShardExchangeInterval): with small tiles the per-frame exchange chain -- blend + snapshot, gather,
+        // de-interleave: three dispatches, each a ~40 us quantum beside a machine full of trace workgroups -- is what bounds the frame
+        // rate; frames in between are blended into the resident tile only, the image on rank 0 catches up every k-th
+        // frame and at tptShardedFinish
+        int exchangeEvery = 0;          // 0 = automatic (1 for tiles of >= 2.4 M samples per frame, 2 / 4 below), else the host's choice
+        int sinceExchange = 0;          // frames blended into the tile since the last exchange
+        float* lastImage = nullptr;     // the root's image pointer of the most recent call (the catch-up exchange writes there)
         decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
         decltype(&ncclCommInitRank) CommInitRank = nullptr;
         decltype(&ncclCommDestroy) CommDestroy = nullptr;

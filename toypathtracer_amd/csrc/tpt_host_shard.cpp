@@ -53,6 +53,24 @@ int releaseShardBuffers()
     (void)hipFree(S.gathered); S.gathered = nullptr;
     for (int k = 0; k < Context::Shard::kRing; ++k) { (void)hipFree(S.send[k]); S.send[k] = nullptr; S.sentRecorded[k] = false; }
     S.w = S.h = S.padRows = 0;
+    S.sinceExchange = 0;
+    return 0;
+}
+} // namespace
+
+namespace {
+// gather + de-interleave of snapshot k, behind whatever g.stream holds now
+int enqueueExchange(int k)
+{
+    Context::Shard& S = g.shard;
+    HIPCHK(hipEventRecord(S.evSnap[k], g.stream));
+    HIPCHK(hipStreamWaitEvent(S.commStream, S.evSnap[k], 0));
+    const size_t count = shardSnapshotPixels(S.padRows, S.w) * 4;
+    if (S.loopback) HIPCHK(hipMemcpyAsync(S.gathered, S.send[k], count * sizeof(float), hipMemcpyDeviceToDevice, S.commStream));
+    else NCCLCHK(S.Gather(S.send[k], S.gathered, count, ncclFloat32, 0, S.comm, S.commStream));
+    if (S.rank == 0) HIPCHK(tptLaunchAssemble(S.gathered, S.lastImage, S.w, S.h, S.stripeRows, S.nRanks, S.padRows, S.commStream));
+    HIPCHK(hipEventRecord(S.evSent[k], S.commStream));
+    S.sentRecorded[k] = true;
     return 0;
 }
 } // namespace
@@ -183,6 +201,22 @@ int tptDrawShardedBatch(float time, int frameCount, int nFrames, int w, int h, f
         }
         S.w = w; S.h = h;
     }
+    S.lastImage = deviceImageOnRoot;
+    // Exchange every frame, or every k-th when the tile is small (EVERY rank takes the same decision: it depends on the frame's shape
+    // and the flags only).  A frame in between is blended into the resident tile and nothing else; the next exchange -- or
+    // tptShardedFinish -- carries everything blended so far, ray counter included.
+    int every = S.exchangeEvery;
+    if (every <= 0) {
+        const long long samples = (long long)shardPadRows(h, S.stripeRows, S.nRanks) * w * g.spp;
+        every = (S.nRanks <= 1 || (testFlags & TPT_FLAG_ANIMATE) || samples >= 2400000) ? 1 : (samples >= 1200000 ? 2 : 4);
+    }
+    if (nFrames == 1 && S.sinceExchange + 1 < every) {
+        int rc = tptSetTileMirror(nullptr, nullptr);
+        if (rc) return rc;
+        if ((rc = tptDrawDevice(time, frameCount, w, h, S.tile, testFlags))) return rc;
+        S.sinceExchange++;
+        return 0;
+    }
     const int k = shardRingSlot(S.frames, Context::Shard::kRing);
     S.frames++;
     // the snapshot this frame's resolve kernel writes must have left the GPU (gather of the frame that used it last)
@@ -191,14 +225,17 @@ int tptDrawShardedBatch(float time, int frameCount, int nFrames, int w, int h, f
     int rc = tptSetTileMirror(S.send[k], S.send[k] + tileFloats); // blended tile -> snapshot, ray counter -> first 8 bytes of the extra row
     if (rc) return rc;
     if ((rc = nFrames > 1 ? tptDrawDeviceBatch(time, frameCount, nFrames, w, h, S.tile, testFlags) : tptDrawDevice(time, frameCount, w, h, S.tile, testFlags))) return rc;
-    HIPCHK(hipEventRecord(S.evSnap[k], g.stream));
-    HIPCHK(hipStreamWaitEvent(S.commStream, S.evSnap[k], 0));
-    const size_t count = shardSnapshotPixels(S.padRows, w) * 4;
-    if (S.loopback) HIPCHK(hipMemcpyAsync(S.gathered, S.send[k], count * sizeof(float), hipMemcpyDeviceToDevice, S.commStream));
-    else NCCLCHK(S.Gather(S.send[k], S.gathered, count, ncclFloat32, 0, S.comm, S.commStream));
-    if (S.rank == 0) HIPCHK(tptLaunchAssemble(S.gathered, deviceImageOnRoot, w, h, S.stripeRows, S.nRanks, S.padRows, S.commStream));
-    HIPCHK(hipEventRecord(S.evSent[k], S.commStream));
-    S.sentRecorded[k] = true;
+    S.sinceExchange = 0;
+    return enqueueExchange(k);
+}
+
+// How often tptDrawSharded exchanges: 0 = automatic (every frame for tiles of 2.4 M samples or more and for animated scenes, every
+// 2nd / 4th below), k >= 1 = every k-th frame.  Every rank must choose the same.  The image on rank 0 is current after an
+// exchanging frame and after tptShardedFinish.
+int tptSetShardExchangeInterval(int k)
+{
+    if (k < 0 || k > 64) return fail("tptSetShardExchangeInterval: 0 (automatic) or 1..64 frames");
+    g.shard.exchangeEvery = k;
     return 0;
 }
 
@@ -209,6 +246,18 @@ int tptShardedFinish(int64_t* outTotalRays)
     if (requireInit()) return -1;
     Context::Shard& S = g.shard;
     if (!S.active) return fail("tptShardedFinish: call tptCommInit first");
+    if (S.sinceExchange > 0 && S.w) {
+        // frames blended since the last exchange: the catch-up exchange -- a snapshot of the tile and of the ray counter as they are
+        // once everything enqueued on the context's stream has run (every blend waits for its trace: the counter is exact by then)
+        const int k = shardRingSlot(S.frames, Context::Shard::kRing);
+        S.frames++;
+        if (S.sentRecorded[k]) HIPCHK(hipStreamWaitEvent(g.stream, S.evSent[k], 0));
+        const size_t tileBytes = shardCounterPixel(S.padRows, S.w) * sizeof(f4);
+        HIPCHK(hipMemcpyAsync(S.send[k], S.tile, tileBytes, hipMemcpyDeviceToDevice, g.stream));
+        HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(S.send[k]) + tileBytes, g.dRays, sizeof(unsigned long long), hipMemcpyDeviceToDevice, g.stream));
+        S.sinceExchange = 0;
+        if (int rc = enqueueExchange(k)) return rc;
+    }
     if (int rc = launchTailHelpers()) return rc;
     HIPCHK(hipStreamSynchronize(g.stream));
     HIPCHK(hipStreamSynchronize(S.commStream));

@@ -1,4 +1,10 @@
-"""Row-stripe sharding of one frame across ranks + the single gather that reassembles it.
+"""Row-stripe sharding of one frame across ranks: the index arithmetic, and a CPU MODEL of the one gather that reassembles it.
+
+On GPUs the exchange is the library's own (csrc/tpt_host_shard.cpp: tptCommInit / tptDrawSharded / tptShardedFinish over RCCL; api.comm_init,
+api.draw_sharded) -- there is ONE multi-GPU implementation, and this module is not it.  What lives here is what can run without a GPU: the
+row <-> rank index logic (the same functions as csrc/tpt_shard.h, checked against each other by tests/test_sharding.py) and `ShardedFrame`,
+the exchange protocol restated on CPU tensors over a `torch.distributed` group (gloo), which is how the N > 1 path is exercised in this
+repository's CPU test suite at world sizes 2, 3 and 8.
 
 New relative to the reference (which is single-device; its only fan-out is the CPU row task set,
 Test.cpp:357-361, 4-row granules): rows are dealt out in stripes of `stripe_rows`, round-robin over
@@ -65,8 +71,8 @@ def assemble(tiles, height, stripe_rows, num_parts, out=None, row_index=None):
 
 
 class ShardedFrame:
-    """One process per GPU.  The caller renders this rank's rows into `self.tile` (on `render_stream` when
-    on a GPU) and then calls `exchange()`; `finish()` drains the pipeline and returns what rank 0 holds.
+    """One process per rank (CPU tensors).  The caller renders this rank's rows into `self.tile` and then calls `exchange()`;
+    `finish()` returns what rank 0 holds.
 
     Per frame there is exactly ONE collective: a gather of `pad_rows + 1` rows per rank -- the tile plus one
     extra row whose first 8 bytes carry the rank's 64-bit ray counter (exact integer, bit-cast) -- and on
@@ -104,20 +110,9 @@ class ShardedFrame:
             else:
                 self.recv = self.recv_list = None
         if self.on_gpu:
-            # Two streams = two more hardware queues, alive as long as the process (torch hands out pooled streams): create
-            # ONE ShardedFrame per process.  The library already holds 16 trace queues; past ~32 the runtime time-slices
-            # them and everything slows down (eight ShardedFrames in one process: 0.17 -> 0.62 ms per frame).
-            self.render_stream = torch.cuda.Stream(device=self.device)
-            self.comm_stream = torch.cuda.Stream(device=self.device)
-            self.ev_ready = [torch.cuda.Event() for _ in range(depth)]   # send buffer filled (render stream)
-            self.ev_free = [torch.cuda.Event() for _ in range(depth)]    # send buffer consumed (comm stream)
-            # the buffers above were filled on torch's current stream: both streams wait for those fills (a stream dependency, not a
-            # device synchronise; the library works on render_stream once the caller passes it to tptSetStream)
-            cur = torch.cuda.current_stream(self.device)
-            self.render_stream.wait_stream(cur)
-            self.comm_stream.wait_stream(cur)
-        else:
-            self.render_stream = self.comm_stream = None
+            raise RuntimeError("ShardedFrame is the CPU model of the exchange (gloo tests); on GPUs use the library's own: "
+                               "api.comm_init / api.draw_sharded / api.sharded_finish (csrc/tpt_host_shard.cpp)")
+        self.render_stream = self.comm_stream = None
 
     def _fill_send(self, k):
         send = self.send[k]
@@ -126,44 +121,26 @@ class ShardedFrame:
         send[self.pad_rows, 0, :2].view(self.torch.int64).copy_(self.ray_counter, non_blocking=True)
 
     def mirror_pointers(self):
-        """Device addresses (snapshot tile, 8-byte counter slot) of the send buffer the NEXT exchange() will use, for
-        tptSetTileMirror: the library's resolve kernel then fills the snapshot itself and exchange(snapshot_done=True)
-        skips the two copy kernels -- two fewer kernels in every frame's dependency chain.  None when not sharded."""
+        """Addresses (snapshot tile, 8-byte counter slot) of the send buffer the NEXT exchange() will use: the library's blend kernel
+        writes the snapshot itself (tptSetTileMirror; csrc/tpt_host_shard.cpp does the same with its ring of 4), and
+        exchange(snapshot_done=True) then sends it as it is.  None when not sharded."""
         if self.world <= 1:
             return None
         send = self.send[self.steps % self.depth]
         return send.data_ptr(), send[self.pad_rows].data_ptr()
 
     def begin_frame(self):
-        """With mirroring: call BEFORE the frame's draw is enqueued -- makes the render stream wait until the collective
-        that last read the send buffer about to be overwritten has finished."""
-        if self.world > 1 and self.on_gpu and self.steps >= self.depth:
-            # always the stream wait, never an event query as a shortcut: a query on a re-recorded event has been seen to
-            # answer "done" before the new record's work was (DESIGN.md section 2), and a blend that overwrites a snapshot the
-            # gather is still reading would corrupt the exchanged image once in a long while
-            self.render_stream.wait_event(self.ev_free[self.steps % self.depth])
+        """(the library waits here for the gather that last read the send buffer about to be overwritten; nothing is asynchronous on the CPU)"""
 
     def exchange(self, snapshot_done=False):
-        """Call after this frame's render has been enqueued on render_stream."""
-        torch = self.torch
+        """Call after this frame's rows have been rendered into self.tile."""
         k = self.steps % self.depth
         self.steps += 1
         if self.world <= 1:
             return
-        if self.on_gpu:
-            with torch.cuda.stream(self.render_stream):
-                if not snapshot_done:
-                    if self.steps > self.depth:
-                        self.render_stream.wait_event(self.ev_free[k])    # gather of frame f-depth has read this buffer
-                    self._fill_send(k)
-                self.ev_ready[k].record(self.render_stream)
-            with torch.cuda.stream(self.comm_stream):
-                self.comm_stream.wait_event(self.ev_ready[k])
-                self._collect(k)
-                self.ev_free[k].record(self.comm_stream)
-        else:
+        if not snapshot_done:
             self._fill_send(k)
-            self._collect(k)
+        self._collect(k)
 
     def _collect(self, k):
         torch = self.torch
@@ -174,11 +151,8 @@ class ShardedFrame:
             self.last = k
 
     def finish(self):
-        """Drain both streams.  Returns (image, cumulative rays over all ranks) on rank 0, (None, None) elsewhere."""
+        """Returns (image, cumulative rays over all ranks) on rank 0, (None, None) elsewhere."""
         torch = self.torch
-        if self.on_gpu:
-            self.render_stream.synchronize()
-            self.comm_stream.synchronize()
         if self.world <= 1:
             self.image.copy_(self.tile[: self.height])
             self.total_rays.copy_(self.ray_counter)

@@ -16,8 +16,8 @@ using namespace tpt;
 
 namespace {
 // (mirrors of constants that live in tpt_kernels.hip: path records, rings, control block of the path-queue kernel)
-const int kQPaths = 952, kQPathsGrouped = 816, kQRing = 1024, kQClasses = 6, kQThreads = 512, kQWaves = 8;
-const size_t kQCtlBytes = 256, kQDealWaveBytes = 192 * 4 + 64;
+const int kQPaths = 952, kQPathsGrouped = 720, kQRing = 1024, kQClasses = 6, kQThreads = 512, kQWaves = 8;
+const size_t kQCtlBytes = 256, kQDealWaveBytes = 448 * 4 + 16;
 
 bool mapItem(const KernelArgs& a, int idx, int& x, int& ly) // tpt_kernels.hip: mapItem
 {
@@ -341,7 +341,7 @@ int tptQueueGroupPairsInLds(int nGroups, int nSuperPairs) // = tpt_kernels.hip
 {
     if (nGroups <= 0 || nSuperPairs <= 0) return 0;
     const int pairs = ((nGroups + TPT_SUPER - 1) / TPT_SUPER) * (TPT_SUPER / 2);
-    return (size_t)pairs * 32 + 16 <= (size_t)(kQPaths - kQPathsGrouped) * 64 ? pairs : 0;
+    return (size_t)pairs * 32 + 16 <= (size_t)8704 ? pairs : 0;
 }
 int tptQueueMatrixFilter() { return 1; }
 int tptQueueGroupMatrixBounds() { return 1; }

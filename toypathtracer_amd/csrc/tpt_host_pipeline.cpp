@@ -136,6 +136,11 @@ int chooseKernel(FramePlan& P)
     if (P.queued && !P.ldsScene && a.scene.nGroups > 0 && a.scene.gmxTiles == 0 && a.scene.nSuperPairs > 0 && g.useMatrix)
         a.ldsGroupPairs = tptQueueGroupPairsInLds(a.scene.nGroups, a.scene.nSuperPairs);
     P.lds = P.queued ? tptQueueLdsBytes(a, P.ldsScene) : ldsV1;
+    if (P.queued && a.ldsGroupPairs > 0 && 160 * 1024 / (P.lds + 256) < 2) {
+        // the groups' bounds in LDS would cost the second workgroup per CU (many lights beside them): second level from global memory
+        a.ldsGroupPairs = 0;
+        P.lds = tptQueueLdsBytes(a, P.ldsScene);
+    }
     if ((size_t)a.scene.nLights * 32 > 96 * 1024)
         return fail("tptDrawDevice: too many emissive spheres for the LDS light table (3072 at most)");
     if (P.lds > 160 * 1024) return fail("tptDrawDevice: scene too large for LDS staging; use tptSetKernelVariant(.., .., 0)");

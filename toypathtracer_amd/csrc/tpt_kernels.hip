@@ -424,14 +424,17 @@ __device__ __forceinline__ f4 mk4(float x, float y, float z, float w)
 #define TPT_GROUP_DEAL_EXACT 1 // the members that pass the member filter are dealt out again for their exact tests (see hitSpheresGroupedDeal)
 #endif
 #ifndef TPT_MEMBER_UNROLL
-#define TPT_MEMBER_UNROLL 4 // member records requested together in the member filter of a (ray, group) pair
+#define TPT_MEMBER_UNROLL 8 // member records requested together in the member filter of a (ray, group) pair: all eight (a latency-bound gather from L2; 4: -3 %, profiles/r06/r06_run14.log)
 #endif
 // (_Pragma with a stringised macro: `#pragma unroll MACRO` is not expanded when the source is preprocessed separately --
 //  -save-temps, ccache, distcc -- and the build broke there)
 #define TPT_PRAGMA_STR(x) _Pragma(#x)
 #define TPT_PRAGMA_UNROLL(n) TPT_PRAGMA_STR(unroll n)
 #ifndef TPT_GROUP_DEAL_CAP
-#define TPT_GROUP_DEAL_CAP 192 /* pair-list entries per wave and round (a multiple of 64) */
+// pair-list entries per wave and round (a multiple of 64).  A wave's 64 rays touch ~130 groups per 256 on the 4096-sphere scene, with a
+// long tail: a list that overflows costs another round of the whole dealing.  448 entries with 720 paths per workgroup beat 192 with
+// 816 by 11 % (sweep 128 ... 640: profiles/r06/r06_run14-16.log); longer lists take the LDS from the path pool and lose again.
+#define TPT_GROUP_DEAL_CAP 448
 #endif
 #define TPT_GROUP_DEAL_WAVE_BYTES (TPT_GROUP_DEAL_CAP * 4 + 16)
 #define TPT_Q_SPH_FIXED 1024 /* bytes at LDS offset 0 for {centre, r^2} of scenes of <= 64 spheres: DS offsets fold into the instructions */
@@ -442,12 +445,12 @@ __device__ __forceinline__ f4 mk4(float x, float y, float z, float w)
 #define TPT_Q_PATHS (TPT_MATRIX_FILTER ? 952 : TPT_Q_P)
 #endif
 #ifndef TPT_Q_PATHS_GROUPED
-// ... and of the instantiation for GROUPED scenes (no scene staging, no matrix-filter table): 816, which leaves 8.5 KB of LDS for
-// the groups' bounding spheres (pair records, 16 B per group: up to 544 groups = 68 super-groups) -- the second level of the
-// bounds filter reads them per lane, and from L2 that loop would be latency-bound
-#define TPT_Q_PATHS_GROUPED 816
+// ... and of the instantiation for GROUPED scenes (no scene staging, no matrix-filter table): 720.  The LDS the smaller pool frees holds
+// the longer pair lists of the dealing (TPT_GROUP_DEAL_CAP) and the groups' bounding spheres (pair records, 16 B per group, for up to
+// TPT_Q_GROUP_LDS_BYTES: the second level of the bounds filter reads them per lane, and from L2 that loop would be latency-bound)
+#define TPT_Q_PATHS_GROUPED 720
 #endif
-#define TPT_Q_GROUP_LDS_BYTES ((TPT_Q_PATHS - TPT_Q_PATHS_GROUPED) * TPT_Q_NF4 * 16) /* LDS the smaller pool frees (8 704 B) */
+#define TPT_Q_GROUP_LDS_BYTES 8704 /* group pair records in LDS at most: 544 groups = 68 super-groups (a launch that would lose its second workgroup per CU to them reads them from global memory instead: chooseKernel) */
 #ifndef TPT_Q_FUSE_MIN
 #define TPT_Q_FUSE_MIN 48 // a batch intersects its own rays when at least this many lanes still hold one
 #endif

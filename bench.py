@@ -507,7 +507,6 @@ def main():
         sys.exit("--exchange none needs --gpus 1")
     flags = FLAG_PROGRESSIVE | (FLAG_ANIMATE if args.animate else 0)
     rccl_ranks = 0
-    sf = None
     image_on_root = None
     if exchange == "cabi":
         # the product's own multi-GPU path: RCCL inside the library, nothing of torch.distributed in the data path

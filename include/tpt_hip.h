@@ -202,11 +202,13 @@ TPT_API int tptCommInitLoopback(int nRanks, int stripeRows);
 TPT_API int tptCommInfo(int* outRanks, int* outRank, int* outLoopback);
 TPT_API int tptCommDestroy(void);
 TPT_API int tptDrawSharded(float time, int frameCount, int screenWidth, int screenHeight, float* deviceImageOnRoot, unsigned testFlags);
-/* How often tptDrawSharded exchanges.  0 (default) = automatic: every frame when a rank's tile is 2.4 M samples per frame or more
- * (rows x width x spp) and for animated scenes; every 2nd / 4th frame below -- with small tiles the exchange chain (blend + snapshot,
- * gather, de-interleave: three dispatches beside a machine full of trace workgroups) bounds the frame rate, not the arithmetic.
- * k >= 1 = every k-th frame.  Frames in between are blended into the rank's resident tile only; the image on rank 0 is current
- * after an exchanging frame and after tptShardedFinish (which exchanges whatever is outstanding).  EVERY rank must choose the same. */
+/* How many consecutive frames tptDrawSharded collects into ONE trace launch + blend + exchange.  0 (default) = automatic: 1 when a
+ * rank's tile is 2.4 M samples per frame or more (rows x width x spp) and for animated scenes; 2 / 4 below -- with small tiles the
+ * chain behind a frame (trace launch, blend + snapshot, gather, de-interleave: four dispatches beside a machine full of trace
+ * workgroups) bounds the frame rate, not the arithmetic.  k = 1..32 = the host's choice.  A frame that is collected is issued when the
+ * k-th arrives, when anything it depends on is about to change (every setter, tptUpdate with another size), or when the caller waits
+ * (tptShardedFinish, tptSynchronize, tptRayCounterRead): same bits as frame-by-frame calls; the image on rank 0 is current after a
+ * batch has gone out and after tptShardedFinish.  EVERY rank must choose the same. */
 TPT_API int tptSetShardExchangeInterval(int everyKFrames);
 /* nFrames (1..32) consecutive frames per call, traced by one launch per rank (tptDrawDeviceBatch) and followed by ONE exchange:
  * rank 0's image is that of the batch's last frame.  Same bits as nFrames tptDrawSharded calls. */

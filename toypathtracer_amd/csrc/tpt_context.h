@@ -215,13 +215,16 @@ struct Context {
         hipEvent_t evSnap[kRing] = {}, evSent[kRing] = {};
         bool sentRecorded[kRing] = {};
         unsigned long long frames = 0;  // exchanges enqueued (index into the snapshot ring)
-        // exchange interval (tptSetShardExchangeInterval): with small tiles the per-frame exchange chain -- blend + snapshot, gather,
-        // de-interleave: three dispatches, each a ~40 us quantum beside a machine full of trace workgroups -- is what bounds the frame
-        // rate; frames in between are blended into the resident tile only, the image on rank 0 catches up every k-th
-        // frame and at tptShardedFinish
+        // Exchange interval (tptSetShardExchangeInterval): with small tiles the chain behind a frame -- trace launch, blend + snapshot,
+        // gather, de-interleave: four dispatches, each a ~40 us quantum beside a machine full of trace workgroups -- bounds the frame
+        // rate, not the arithmetic.  tptDrawSharded then DEFERS such frames: k consecutive frames of one configuration are
+        // issued as one tptDrawShardedBatch (one trace launch, one blend, one exchange) when the k-th arrives, when anything about the
+        // configuration is about to change, or when the caller waits (tptShardedFinish, tptSynchronize, tptRayCounterRead).
         int exchangeEvery = 0;          // 0 = automatic (1 for tiles of >= 2.4 M samples per frame, 2 / 4 below), else the host's choice
-        int sinceExchange = 0;          // frames blended into the tile since the last exchange
-        float* lastImage = nullptr;     // the root's image pointer of the most recent call (the catch-up exchange writes there)
+        int pendCount = 0, pendFirst = 0, pendW = 0, pendH = 0; // frames accepted but not issued yet: [pendFirst, pendFirst + pendCount)
+        unsigned pendFlags = 0;
+        float pendTime = 0.0f;
+        float* lastImage = nullptr;     // the root's image pointer of the most recent call (a deferred batch writes there)
         decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
         decltype(&ncclCommInitRank) CommInitRank = nullptr;
         decltype(&ncclCommDestroy) CommDestroy = nullptr;
@@ -322,6 +325,7 @@ int syncAllStreams();
 int launchTailHelpers();
 // tpt_host_draw.cpp
 int discardLookahead();
+int flushShardDeferred(); // tpt_host_shard.cpp: issue the sharded frames tptDrawSharded has accepted but deferred (none: nothing happens)
 int takeAhead(TraceTicket& T, int& raySlot);
 int traceAhead(int frameCount, int w, int h, unsigned testFlags, unsigned long long key, int want);
 

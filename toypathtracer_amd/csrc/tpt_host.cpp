@@ -464,6 +464,7 @@ int tptShutdown(void)
 
 int tptSetStream(void* hipStream)
 {
+    if (int rc_ = flushShardDeferred()) return rc_;
     if (requireInit()) return -1;
     if (discardLookahead()) return -2;
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -473,6 +474,7 @@ int tptSetStream(void* hipStream)
 
 int tptSetSamplesPerPixel(int spp)
 {
+    if (int rc_ = flushShardDeferred()) return rc_;
     if (spp < 1 || spp > 65536) return fail("tptSetSamplesPerPixel: spp out of range");
     if (spp == g.spp) return 0; // (a setter that changes nothing must not invalidate frames traced ahead)
     g.spp = spp;
@@ -481,6 +483,7 @@ int tptSetSamplesPerPixel(int spp)
 }
 int tptSetConfig(int lightSampling, float animateSmoothing, int mitsubaCompare)
 {
+    if (int rc_ = flushShardDeferred()) return rc_;
     const int config = (lightSampling ? CFG_LIGHT_SAMPLING : 0) | (mitsubaCompare ? CFG_MITSUBA_COMPARE : 0);
     if (config == g.config && animateSmoothing == g.animateSmoothing) return 0;
     g.config = config;
@@ -490,6 +493,7 @@ int tptSetConfig(int lightSampling, float animateSmoothing, int mitsubaCompare)
 }
 int tptSetSeedMode(int mode)
 {
+    if (int rc_ = flushShardDeferred()) return rc_;
     if (mode != SEED_ROW_SERIAL && mode != SEED_PER_PIXEL) return fail("tptSetSeedMode: 0 (ROW_SERIAL) or 1 (PER_PIXEL)");
     if (mode == g.seedMode) return 0;
     g.seedMode = mode;
@@ -498,6 +502,7 @@ int tptSetSeedMode(int mode)
 }
 int tptSetFoldMode(int mode)
 {
+    if (int rc_ = flushShardDeferred()) return rc_;
     if (mode != FOLD_RECURSIVE && mode != FOLD_FORWARD) return fail("tptSetFoldMode: 0 (RECURSIVE) or 1 (FORWARD)");
     if (mode == g.foldMode) return 0;
     g.foldMode = mode;
@@ -541,6 +546,7 @@ int tptKernelTimingEnd(float* outSumMs, int* outLaunches)
 
 int tptSetFrameOverlap(int frames)
 {
+    if (int rc_ = flushShardDeferred()) return rc_;
     if (frames < 1 || frames > Context::kMaxOverlap) return fail("tptSetFrameOverlap: 1..16");
     int rc = drainPipeline();
     if (rc) return rc;
@@ -550,6 +556,7 @@ int tptSetFrameOverlap(int frames)
 
 int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene)
 {
+    if (int rc_ = flushShardDeferred()) return rc_;
     if (hitSpheres < 0 || hitSpheres > 4)
         return fail("tptSetKernelVariant: hitSpheres 0 (two-phase) 1 (simple) 2 (two-phase, no groups) 3 (two-phase, VALU filter) 4 (two-phase, groups' bounds on the matrix cores)");
     if (hitSpheres == 4 && !tptQueueGroupMatrixBounds())
@@ -574,6 +581,7 @@ int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene)
 
 int tptSetScene(const void* spheres, const void* materials, int count)
 {
+    if (int rc_ = flushShardDeferred()) return rc_;
     if (!spheres || !materials || count <= 0) {
         defaultScene(g.spheres, g.mats);
     } else {
@@ -590,6 +598,7 @@ int tptSetScene(const void* spheres, const void* materials, int count)
 
 int tptSetCamera(const float* lookFrom, const float* lookAt, float vfov, float aperture, float focusDist)
 {
+    if (int rc_ = flushShardDeferred()) return rc_;
     g.configEpoch++;
     if (!lookFrom || !lookAt) {
         g.camSetup = defaultCameraSetup();
@@ -635,6 +644,9 @@ int tptUpdate(float time, int frameCount, int screenWidth, int screenHeight, uns
     (void)frameCount;
     if (requireInit()) return -1;
     if (screenWidth <= 0 || screenHeight <= 0) return fail("tptUpdate: bad size");
+    // sharded frames that were accepted but deferred depend on the camera and the scene as they are NOW: out they go before either changes
+    if (g.shard.pendCount > 0 && (screenWidth != g.shard.pendW || screenHeight != g.shard.pendH || (testFlags & TPT_FLAG_ANIMATE)))
+        if (int rc_ = flushShardDeferred()) return rc_;
     if ((testFlags & TPT_FLAG_ANIMATE) && g.spheres.size() > 8) { // Test.cpp:304-308
         g.spheres[1].cy = cosf(time) + 1.0f;
         g.spheres[8].cz = sinf(time) * 0.3f;

@@ -93,6 +93,7 @@ int tptSetHostLookahead(int frames)
 
 int tptDraw(float time, int frameCount, int w, int h, float* backbuffer, int* outRayCount, unsigned testFlags)
 {
+    if (int rc_ = flushShardDeferred()) return rc_;
     (void)time;
     if (requireInit()) return -1;
     if (!g.updated) return fail("tptDraw: call tptUpdate (UpdateTest) first");

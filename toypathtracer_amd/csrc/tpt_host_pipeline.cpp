@@ -679,6 +679,7 @@ int tptDrawDeviceBatch(float time, int firstFrame, int nFrames, int w, int h, fl
 
 int tptRayCounterRead(int64_t* outTotalRays)
 {
+    if (int rc_ = flushShardDeferred()) return rc_;
     if (requireInit()) return -1;
     unsigned long long v = 0;
     HIPCHK(hipMemcpyAsync(&v, g.dRays, sizeof(v), hipMemcpyDeviceToHost, g.stream));
@@ -696,6 +697,7 @@ int tptSetTileMirror(float* deviceMirror, void* deviceCounterOut)
 
 int tptSetRayCounter(void* deviceU64)
 {
+    if (int rc_ = flushShardDeferred()) return rc_;
     if (requireInit()) return -1;
     if (discardLookahead()) return -2;
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -709,6 +711,7 @@ int tptSetRayCounter(void* deviceU64)
 
 int tptSynchronize(void)
 {
+    if (int rc_ = flushShardDeferred()) return rc_;
     if (requireInit()) return -1;
     if (int rc = launchTailHelpers()) return rc;
     HIPCHK(hipStreamSynchronize(g.stream));
@@ -723,6 +726,7 @@ int tptTimerBegin(void)
 }
 int tptTimerEnd(float* outMs)
 {
+    if (int rc_ = flushShardDeferred()) return rc_;
     if (requireInit()) return -1;
     HIPCHK(hipEventRecord(g.ev1, g.stream));
     if (int rc = launchTailHelpers()) return rc;

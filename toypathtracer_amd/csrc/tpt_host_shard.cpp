@@ -5,6 +5,23 @@
 using namespace tpt;
 using namespace tpth;
 
+namespace tpth {
+// The sharded frames tptDrawSharded has accepted but not issued (exchange interval): as one batch, now.  Called by every entry point that
+// is about to change what a frame depends on, and by the ones that wait.
+int flushShardDeferred()
+{
+    Context::Shard& S = g.shard;
+    if (!S.active || S.pendCount <= 0) return 0;
+    const int first = S.pendFirst, n = S.pendCount;
+    S.pendCount = 0; // (first: the calls below pass through entry points that flush)
+    const int keep = S.exchangeEvery;
+    S.exchangeEvery = 1; // issue exactly these n frames, nothing deferred again
+    const int rc = tptDrawShardedBatch(S.pendTime, first, n, S.pendW, S.pendH, S.lastImage, S.pendFlags);
+    S.exchangeEvery = keep;
+    return rc;
+}
+} // namespace tpth
+
 extern "C" {
 // ---------------------------------------------------------------- multi-GPU inside the library
 // One process per GPU.  The image's rows are dealt out in stripes round-robin (tptSetRowShard); every rank renders its
@@ -53,7 +70,6 @@ int releaseShardBuffers()
     (void)hipFree(S.gathered); S.gathered = nullptr;
     for (int k = 0; k < Context::Shard::kRing; ++k) { (void)hipFree(S.send[k]); S.send[k] = nullptr; S.sentRecorded[k] = false; }
     S.w = S.h = S.padRows = 0;
-    S.sinceExchange = 0;
     return 0;
 }
 } // namespace
@@ -148,6 +164,7 @@ int tptCommDestroy(void)
 {
     Context::Shard& S = g.shard;
     if (!S.active) return 0;
+    S.pendCount = 0; // (frames accepted but never waited for are dropped with the communicator: the collective needs every rank)
     (void)discardLookahead();
     if (g.stream) (void)hipStreamSynchronize(g.stream);
     (void)releaseShardBuffers();
@@ -202,20 +219,23 @@ int tptDrawShardedBatch(float time, int frameCount, int nFrames, int w, int h, f
         S.w = w; S.h = h;
     }
     S.lastImage = deviceImageOnRoot;
-    // Exchange every frame, or every k-th when the tile is small (EVERY rank takes the same decision: it depends on the frame's shape
-    // and the flags only).  A frame in between is blended into the resident tile and nothing else; the next exchange -- or
-    // tptShardedFinish -- carries everything blended so far, ray counter included.
+    // One frame per call: issue it now, or defer it until k frames of the same configuration can go out as one batch (EVERY rank
+    // takes the same decision: it depends on the frame's shape, the flags and the call sequence only).
     int every = S.exchangeEvery;
     if (every <= 0) {
         const long long samples = (long long)shardPadRows(h, S.stripeRows, S.nRanks) * w * g.spp;
         every = (S.nRanks <= 1 || (testFlags & TPT_FLAG_ANIMATE) || samples >= 2400000) ? 1 : (samples >= 1200000 ? 2 : 4);
     }
-    if (nFrames == 1 && S.sinceExchange + 1 < every) {
-        int rc = tptSetTileMirror(nullptr, nullptr);
+    if (every > kMaxBatch) every = kMaxBatch;
+    if (S.pendCount > 0 && !(nFrames == 1 && every > 1 && frameCount == S.pendFirst + S.pendCount && w == S.pendW && h == S.pendH && testFlags == S.pendFlags)) {
+        int rc = flushShardDeferred(); // not the continuation of what is pending: that goes out first
         if (rc) return rc;
-        if ((rc = tptDrawDevice(time, frameCount, w, h, S.tile, testFlags))) return rc;
-        S.sinceExchange++;
-        return 0;
+    }
+    if (nFrames == 1 && every > 1) {
+        if (S.pendCount == 0) { S.pendFirst = frameCount; S.pendW = w; S.pendH = h; S.pendFlags = testFlags; S.pendTime = time; }
+        if (++S.pendCount < every) return 0;
+        frameCount = S.pendFirst; nFrames = S.pendCount; time = S.pendTime; // the k-th frame: the whole batch goes out now
+        S.pendCount = 0;
     }
     const int k = shardRingSlot(S.frames, Context::Shard::kRing);
     S.frames++;
@@ -225,16 +245,15 @@ int tptDrawShardedBatch(float time, int frameCount, int nFrames, int w, int h, f
     int rc = tptSetTileMirror(S.send[k], S.send[k] + tileFloats); // blended tile -> snapshot, ray counter -> first 8 bytes of the extra row
     if (rc) return rc;
     if ((rc = nFrames > 1 ? tptDrawDeviceBatch(time, frameCount, nFrames, w, h, S.tile, testFlags) : tptDrawDevice(time, frameCount, w, h, S.tile, testFlags))) return rc;
-    S.sinceExchange = 0;
     return enqueueExchange(k);
 }
 
-// How often tptDrawSharded exchanges: 0 = automatic (every frame for tiles of 2.4 M samples or more and for animated scenes, every
-// 2nd / 4th below), k >= 1 = every k-th frame.  Every rank must choose the same.  The image on rank 0 is current after an
-// exchanging frame and after tptShardedFinish.
+// How many consecutive frames tptDrawSharded collects into one launch + blend + exchange: 0 = automatic (1 for tiles of 2.4 M samples
+// or more and for animated scenes, 2 / 4 below), k = 1..32.  Every rank must choose the same.
 int tptSetShardExchangeInterval(int k)
 {
-    if (k < 0 || k > 64) return fail("tptSetShardExchangeInterval: 0 (automatic) or 1..64 frames");
+    if (k < 0 || k > kMaxBatch) return fail("tptSetShardExchangeInterval: 0 (automatic) or 1..32 frames");
+    if (int rc = flushShardDeferred()) return rc;
     g.shard.exchangeEvery = k;
     return 0;
 }
@@ -246,18 +265,7 @@ int tptShardedFinish(int64_t* outTotalRays)
     if (requireInit()) return -1;
     Context::Shard& S = g.shard;
     if (!S.active) return fail("tptShardedFinish: call tptCommInit first");
-    if (S.sinceExchange > 0 && S.w) {
-        // frames blended since the last exchange: the catch-up exchange -- a snapshot of the tile and of the ray counter as they are
-        // once everything enqueued on the context's stream has run (every blend waits for its trace: the counter is exact by then)
-        const int k = shardRingSlot(S.frames, Context::Shard::kRing);
-        S.frames++;
-        if (S.sentRecorded[k]) HIPCHK(hipStreamWaitEvent(g.stream, S.evSent[k], 0));
-        const size_t tileBytes = shardCounterPixel(S.padRows, S.w) * sizeof(f4);
-        HIPCHK(hipMemcpyAsync(S.send[k], S.tile, tileBytes, hipMemcpyDeviceToDevice, g.stream));
-        HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(S.send[k]) + tileBytes, g.dRays, sizeof(unsigned long long), hipMemcpyDeviceToDevice, g.stream));
-        S.sinceExchange = 0;
-        if (int rc = enqueueExchange(k)) return rc;
-    }
+    if (int rc = flushShardDeferred()) return rc; // frames accepted but not issued yet go out now
     if (int rc = launchTailHelpers()) return rc;
     HIPCHK(hipStreamSynchronize(g.stream));
     HIPCHK(hipStreamSynchronize(S.commStream));

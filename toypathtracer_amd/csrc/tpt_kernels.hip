@@ -604,6 +604,141 @@ __device__ __forceinline__ void groupMasksTwoLevel(const SceneView& sv, const fl
         cm3 |= w == 3 ? bits : 0ull;
     }
 }
+// One round of the dealing, consumer side: the wave's pair list holds (owner's path id << 16 | group) entries; lane j takes entry j
+// (sub-rounds of 64), reads the owner's parked ray, filters the group's members, deals the survivors out once more for their exact
+// tests and merges hits into the owners' keys (see hitSpheresGroupedDeal).
+template <int PATHS>
+__device__ __forceinline__ void dealProcessList(const SceneView& sv, LdsList list, unsigned* listCount, f4* st, int lane)
+{
+    unsigned total = __hip_atomic_load(listCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    total = total < (unsigned)TPT_GROUP_DEAL_CAP ? total : (unsigned)TPT_GROUP_DEAL_CAP;
+    for (unsigned base = 0; base < total; base += 64u) {
+        const bool have = base + (unsigned)lane < total;
+        unsigned e = 0;
+        if (have) e = list[base + (unsigned)lane];
+        const int po = (int)(e >> 16), g = (int)(e & 0xffffu);
+        uint32_t mm = 0;
+        f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0);
+        const f4* mem = sv.gsph + (size_t)g * TPT_GROUP;
+        if (have) {
+            const f4 r0 = st[po], r1 = st[PATHS + po];
+            ro = mk3(r0.z, r0.w, r1.x);
+            rd = mk3(r1.y, r1.z, r1.w);
+            const f3 dk = mk3(rd.x * TPT_P1_K, rd.y * TPT_P1_K, rd.z * TPT_P1_K);
+            TPT_STAT(ST_SPHERELOOP); // profiling build: group visits
+            TPT_PRAGMA_UNROLL(TPT_MEMBER_UNROLL)
+            for (int j = 0; j < TPT_GROUP; ++j) mm |= (memberFilter(mem[j], ro, dk) ? 1u : 0u) << j;
+        }
+#if TPT_GROUP_DEAL_EXACT
+        // The members that passed -- 0.33 per pair, so a lane-by-lane loop runs 2-3 trips at 8 busy lanes -- are dealt out once
+        // more: (owner's path id << 20 | member slot) entries into the 64 list positions this sub-round has just consumed,
+        // one exact test per lane.  (More than 64 survivors: the surplus is tested in place.)
+        if (lane == 0) listCount[1] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        float ht = TPT_MAX_T;
+        int hid = -1;
+        if (mm) {
+            unsigned pos = atomicAdd(&listCount[1], (unsigned)__popc(mm));
+            while (mm) {
+                const int j = __builtin_ctz(mm);
+                mm &= mm - 1u;
+                if (pos < 64u) {
+                    list[base + pos] = ((unsigned)po << 20) | (unsigned)(g * TPT_GROUP + j);
+                } else {
+                    TPT_STAT(ST_PHASE2);
+                    testSphereTie(mem[j], sv.gid[g * TPT_GROUP + j], ro, rd, TPT_MIN_T, ht, hid);
+                }
+                ++pos;
+            }
+            if (hid >= 0) atomicMin(reinterpret_cast<unsigned long long*>(&st[po]), ((unsigned long long)f2u(ht) << 32) | (unsigned long long)(uint32_t)hid);
+        }
+        __builtin_amdgcn_wave_barrier();
+        unsigned nSurv = __hip_atomic_load(&listCount[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        nSurv = nSurv < 64u ? nSurv : 64u;
+        if ((unsigned)lane < nSurv) {
+            const unsigned e2 = list[base + (unsigned)lane];
+            const int po2 = (int)(e2 >> 20), slot = (int)(e2 & 0xfffffu);
+            const f4 q0 = st[po2], q1 = st[PATHS + po2];
+            float ht2 = TPT_MAX_T;
+            int hid2 = -1;
+            TPT_STAT(ST_PHASE2);
+            testSphereTie(sv.gsph[slot], sv.gid[slot], mk3(q0.z, q0.w, q1.x), mk3(q1.y, q1.z, q1.w), TPT_MIN_T, ht2, hid2);
+            if (hid2 >= 0) atomicMin(reinterpret_cast<unsigned long long*>(&st[po2]), ((unsigned long long)f2u(ht2) << 32) | (unsigned long long)(uint32_t)hid2);
+        }
+        __builtin_amdgcn_wave_barrier();
+#else
+        if (have) {
+            float ht = TPT_MAX_T;
+            int hid = -1;
+            while (mm) {
+                const int j = __builtin_ctz(mm);
+                mm &= mm - 1u;
+                TPT_STAT(ST_PHASE2);
+                testSphereTie(mem[j], sv.gid[g * TPT_GROUP + j], ro, rd, TPT_MIN_T, ht, hid);
+            }
+            if (hid >= 0) atomicMin(reinterpret_cast<unsigned long long*>(&st[po]), ((unsigned long long)f2u(ht) << 32) | (unsigned long long)(uint32_t)hid);
+        }
+#endif
+    }
+}
+// The two-level bounds filter and the producer side of the dealing in ONE pass over the scene (round 6): per chunk of 64 super-groups
+// (512 groups) the super-groups' bounds go through the wave-uniform packed filter (32 pair records, scalar loads); every lane then takes
+// up to 8 of the super-groups ITS ray touches, tests their 8 groups each (4 pair records at gpairsLane: LDS when they fit) and keeps the
+// results as 8 bytes of candidate bits + 8 bytes of super-group indices -- 4 registers instead of the four 64-bit candidate words per
+// 256 groups the flat filters need -- from which it writes its (path, group) entries straight into the wave's pair list.  One round
+// serves the 512 groups of a chunk (two rounds of 256 before), entries that do not fit the list stay in the bytes for the next round.
+template <int PATHS>
+__device__ __forceinline__ void dealTwoLevel(const SceneView& sv, const float* gpairsLane, bool go, f3 o, f3 d, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f dz,
+                                             LdsList list, unsigned* listCount, f4* st, int p, int lane, float hitT, int id, bool& parked)
+{
+    for (int sc0 = 0; sc0 < sv.nSuperPairs; sc0 += 32) {
+        const int leftS = sv.nSuperPairs - sc0;
+        uint64_t sm = phase1Chunk(pairPtr(sv.spairs + (size_t)sc0 * 8), leftS < 32 ? leftS : 32, ox, oy, oz, dx, dy, dz); // super-group k of the chunk: bit 63 - k
+        if (!go) sm = 0ull;
+        uint64_t cb = 0ull, sx = 0ull; // byte q: candidate bits of the q-th super-group taken (bit 7 = its first group) / its index k in the chunk
+        while (__ballot((sm | cb) != 0ull) != 0ull) {
+            if (cb == 0ull) {
+                sx = 0ull;
+                int ns = 0;
+                while (sm != 0ull && ns < 8) {
+                    const int k = __builtin_clzll(sm);
+                    sm &= ~(0x8000000000000000ull >> k);
+                    const float* rec = gpairsLane + (size_t)(sc0 * 2 + k) * (TPT_SUPER / 2) * 8;
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int q = 0; q < TPT_SUPER / 2; ++q) phase1PairLane(rec + q * 8, ox, oy, oz, dx, dy, dz, m);
+                    const uint64_t c8 = (uint64_t)(~m & 0xffu);
+                    if (c8) {
+                        cb |= c8 << (8 * ns);
+                        sx |= (uint64_t)k << (8 * ns);
+                        ++ns;
+                    }
+                }
+            }
+            const unsigned n = (unsigned)__popcll(cb);
+            if (lane == 0) *listCount = 0u;
+            __builtin_amdgcn_wave_barrier();
+            if (n != 0u) {
+                unsigned pos = atomicAdd(listCount, n);
+                while (pos < (unsigned)TPT_GROUP_DEAL_CAP && cb != 0ull) { // write the entries that fit; the rest stay in the bytes
+                    const int b = __builtin_ctzll(cb);
+                    cb &= cb - 1ull;
+                    const int k = (int)((sx >> (b & 56)) & 0xffull);
+                    list[pos] = ((unsigned)p << 16) | (unsigned)((sc0 * 2 + k) * TPT_SUPER + 7 - (b & 7));
+                    ++pos;
+                }
+                if (!parked) { // (o and d do not change between rounds; the key is kept current by the atomics)
+                    st[p] = mk4(u2f((uint32_t)id), hitT, o.x, o.y); // {key lo = sphere id, key hi = t bits, o.x, o.y}
+                    st[PATHS + p] = mk4(o.z, d.x, d.y, d.z);
+                    parked = true;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            dealProcessList<PATHS>(sv, list, listCount, st, lane);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
 template <int PATHS>
 __device__ __forceinline__ int hitSpheresGroupedDeal(const SceneView& sv, bool go, f3 o, f3 d, float& outT, LdsList list, unsigned* listCount,
                                                      f4* st, int p, int lane, const float* ldsGpairs, int boundsMode)
@@ -637,9 +772,17 @@ __device__ __forceinline__ int hitSpheresGroupedDeal(const SceneView& sv, bool g
     //   * the flat packed filter over all groups (hitSpheres variant 3: the A/B).
     const bool boundsOnMatrix = TPT_MATRIX_FILTER && TPT_GROUP_MATRIX_BOUNDS && sv.gmxTiles > 0;
     const bool twoLevel = !boundsOnMatrix && boundsMode >= 0 && sv.nSuperPairs > 0; // (boundsMode = KernelArgs::ldsGroupPairs)
+    if (twoLevel) {
+        // (two call sites: the LDS pointer must stay an LDS pointer -- merged with the global one it becomes a generic pointer and
+        //  the per-lane reads FLAT loads, which reach LDS through the vector-memory path)
+        if (boundsMode > 0)
+            dealTwoLevel<PATHS>(sv, ldsGpairs, go, o, d, ox, oy, oz, dx, dy, dz, list, listCount, st, p, lane, hitT, id, parked);
+        else
+            dealTwoLevel<PATHS>(sv, sv.gpairs, go, o, d, ox, oy, oz, dx, dy, dz, list, listCount, st, p, lane, hitT, id, parked);
+    }
     MatrixRayOps mops;
     if (boundsOnMatrix) matrixRayOperands(o, d, 1, mops);
-    for (int pb0 = 0; pb0 < sv.nGroupPairs; pb0 += 128) {
+    for (int pb0 = 0; !twoLevel && pb0 < sv.nGroupPairs; pb0 += 128) {
         // wave-uniform filter on the bounding spheres of up to 256 groups: four 64-bit candidate masks per lane
         uint64_t cm0 = 0, cm1 = 0, cm2 = 0, cm3 = 0;
         if (boundsOnMatrix) {
@@ -649,15 +792,6 @@ __device__ __forceinline__ int hitSpheresGroupedDeal(const SceneView& sv, bool g
             if (left > 64) cm1 = matrixApply(A + TPT_MXH_TABLE_DWORDS / 4, 16, left - 64 < 64 ? left - 64 : 64, mops);
             if (left > 128) cm2 = matrixApply(A + 2 * (TPT_MXH_TABLE_DWORDS / 4), 16, left - 128 < 64 ? left - 128 : 64, mops);
             if (left > 192) cm3 = matrixApply(A + 3 * (TPT_MXH_TABLE_DWORDS / 4), 16, left - 192 < 64 ? left - 192 : 64, mops);
-        } else if (twoLevel) {
-            // 128 group pairs = 256 groups = 32 super-groups: the super-groups' bounds wave-wide, then per lane the 8 groups of
-            // every super-group its ray touches (2.6 of 64 on the 4096-sphere scene), their pair records read from LDS
-            // (two call sites: the LDS pointer must stay an LDS pointer -- merged with the global one it becomes a generic pointer and
-            //  the per-lane reads FLAT loads, which reach LDS through the vector-memory path)
-            if (boundsMode > 0)
-                groupMasksTwoLevel(sv, ldsGpairs, pb0, go, ox, oy, oz, dx, dy, dz, cm0, cm1, cm2, cm3);
-            else
-                groupMasksTwoLevel(sv, sv.gpairs, pb0, go, ox, oy, oz, dx, dy, dz, cm0, cm1, cm2, cm3);
         } else {
             const int left = sv.nGroupPairs - pb0;
             cm0 = phase1Chunk(pairPtr(sv.gpairs + (size_t)pb0 * 8), left < 32 ? left : 32, ox, oy, oz, dx, dy, dz);
@@ -692,76 +826,7 @@ __device__ __forceinline__ int hitSpheresGroupedDeal(const SceneView& sv, bool g
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            unsigned total = __hip_atomic_load(listCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            total = total < (unsigned)TPT_GROUP_DEAL_CAP ? total : (unsigned)TPT_GROUP_DEAL_CAP;
-            for (unsigned base = 0; base < total; base += 64u) {
-                const bool have = base + (unsigned)lane < total;
-                unsigned e = 0;
-                if (have) e = list[base + (unsigned)lane];
-                const int po = (int)(e >> 16), g = (int)(e & 0xffffu);
-                uint32_t mm = 0;
-                f3 ro = mk3(0, 0, 0), rd = mk3(0, 0, 0);
-                const f4* mem = sv.gsph + (size_t)g * TPT_GROUP;
-                if (have) {
-                    const f4 r0 = st[po], r1 = st[PATHS + po];
-                    ro = mk3(r0.z, r0.w, r1.x);
-                    rd = mk3(r1.y, r1.z, r1.w);
-                    const f3 dk = mk3(rd.x * TPT_P1_K, rd.y * TPT_P1_K, rd.z * TPT_P1_K);
-                    TPT_STAT(ST_SPHERELOOP); // profiling build: group visits
-                    TPT_PRAGMA_UNROLL(TPT_MEMBER_UNROLL)
-                    for (int j = 0; j < TPT_GROUP; ++j) mm |= (memberFilter(mem[j], ro, dk) ? 1u : 0u) << j;
-                }
-#if TPT_GROUP_DEAL_EXACT
-                // The members that passed -- 0.33 per pair, so a lane-by-lane loop runs 2-3 trips at 8 busy lanes -- are dealt out once
-                // more: (owner's path id << 20 | member slot) entries into the 64 list positions this sub-round has just consumed,
-                // one exact test per lane.  (More than 64 survivors: the surplus is tested in place.)
-                if (lane == 0) listCount[1] = 0u;
-                __builtin_amdgcn_wave_barrier();
-                float ht = TPT_MAX_T;
-                int hid = -1;
-                if (mm) {
-                    unsigned pos = atomicAdd(&listCount[1], (unsigned)__popc(mm));
-                    while (mm) {
-                        const int j = __builtin_ctz(mm);
-                        mm &= mm - 1u;
-                        if (pos < 64u) {
-                            list[base + pos] = ((unsigned)po << 20) | (unsigned)(g * TPT_GROUP + j);
-                        } else {
-                            TPT_STAT(ST_PHASE2);
-                            testSphereTie(mem[j], sv.gid[g * TPT_GROUP + j], ro, rd, TPT_MIN_T, ht, hid);
-                        }
-                        ++pos;
-                    }
-                    if (hid >= 0) atomicMin(reinterpret_cast<unsigned long long*>(&st[po]), ((unsigned long long)f2u(ht) << 32) | (unsigned long long)(uint32_t)hid);
-                }
-                __builtin_amdgcn_wave_barrier();
-                unsigned nSurv = __hip_atomic_load(&listCount[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                nSurv = nSurv < 64u ? nSurv : 64u;
-                if ((unsigned)lane < nSurv) {
-                    const unsigned e2 = list[base + (unsigned)lane];
-                    const int po2 = (int)(e2 >> 20), slot = (int)(e2 & 0xfffffu);
-                    const f4 q0 = st[po2], q1 = st[PATHS + po2];
-                    float ht2 = TPT_MAX_T;
-                    int hid2 = -1;
-                    TPT_STAT(ST_PHASE2);
-                    testSphereTie(sv.gsph[slot], sv.gid[slot], mk3(q0.z, q0.w, q1.x), mk3(q1.y, q1.z, q1.w), TPT_MIN_T, ht2, hid2);
-                    if (hid2 >= 0) atomicMin(reinterpret_cast<unsigned long long*>(&st[po2]), ((unsigned long long)f2u(ht2) << 32) | (unsigned long long)(uint32_t)hid2);
-                }
-                __builtin_amdgcn_wave_barrier();
-#else
-                if (have) {
-                    float ht = TPT_MAX_T;
-                    int hid = -1;
-                    while (mm) {
-                        const int j = __builtin_ctz(mm);
-                        mm &= mm - 1u;
-                        TPT_STAT(ST_PHASE2);
-                        testSphereTie(mem[j], sv.gid[g * TPT_GROUP + j], ro, rd, TPT_MIN_T, ht, hid);
-                    }
-                    if (hid >= 0) atomicMin(reinterpret_cast<unsigned long long*>(&st[po]), ((unsigned long long)f2u(ht) << 32) | (unsigned long long)(uint32_t)hid);
-                }
-#endif
-            }
+            dealProcessList<PATHS>(sv, list, listCount, st, lane);
             __builtin_amdgcn_wave_barrier();
         }
     }

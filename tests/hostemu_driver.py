@@ -232,6 +232,51 @@ def sharded_batches(n=4, w=80, h=56, stripe=8, sizes=(3, 1, 4)):
     assert not img[~mine].any()
 
 
+def sharded_deferred_state_changes(n=4, w=80, h=56, stripe=8):
+    """tptDrawSharded collects small tiles into batches (tptSetShardExchangeInterval, automatic: 4 frames here).  Frames that were
+    accepted but not issued yet must be rendered with the configuration they were accepted under: a camera / scene / spp change, a
+    change of the interval itself, a counter read and the closing tptShardedFinish each issue what is pending first."""
+    reset()
+    from toypathtracer_amd.scenes import stress_scene
+    s0, m0 = o.default_scene()
+    cam0 = o.default_camera(w, h)
+    s1, m1 = stress_scene(300, 18)
+    cam1 = o.camera((0, 3, 9), (0, 0, 0), (0, 1, 0), 50.0, w / h, 0.0, 9.0)
+    want = np.zeros((h, w, 4), np.float32)
+    img = np.zeros((h, w, 4), np.float32)
+    total = 0
+    tpt.comm_init_loopback(n, stripe)
+    try:
+        r0 = tpt.sharded_finish()
+        s, m, cam, spp = s0, m0, cam0, SPP
+        for f in range(17):
+            if f == 2:   # two frames pending: the camera moves
+                tpt.set_camera((0, 3, 9), (0, 0, 0), 50.0, 0.0, 9.0)
+                cam = cam1
+            if f == 5:   # three pending: another scene
+                tpt.set_scene(s1, m1)
+                s, m = s1, m1
+            if f == 7:   # two pending: more samples per pixel
+                tpt.set_samples_per_pixel(3)
+                spp = 3
+            if f == 10:  # three pending: the host's own interval
+                tpt.set_shard_exchange_interval(3)
+            if f == 14:  # one pending (10-12 went out as a batch of three): a counter read waits for everything accepted so far
+                assert tpt.ray_counter_read() - r0 == total
+            tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+            tpt.draw_sharded(0.0, f, w, h, ptr(img), FLAG_PROGRESSIVE)
+            for y0 in range(0, h, stripe * n):  # rank 0's stripes
+                r, _ = o.render(s, m, cam, w, h, spp, f, FLAG_PROGRESSIVE, backbuffer=want, seed_mode=SEED_PER_PIXEL, y0=y0, y1=min(y0 + stripe, h))
+                total += r
+        assert tpt.sharded_finish() - r0 == total  # (frames 14-16: two pending at the end)
+    finally:
+        tpt.set_shard_exchange_interval(0)
+        tpt.comm_destroy()
+    mine = (np.arange(h) // stripe) % n == 0
+    same(img[mine], want[mine], "deferred sharded frames across state changes")
+    assert not img[~mine].any()
+
+
 def custom_scene_and_camera():
     """tptSetScene / tptSetCamera between frames of a stream: the frames before see the old scene, the ones after the new one"""
     reset()
@@ -439,6 +484,7 @@ SCENARIOS = [
     ("sharded loopback n=2", lambda: sharded_loopback(2)),
     ("sharded loopback n=4", lambda: sharded_loopback(4)),
     ("sharded batches", sharded_batches),
+    ("sharded frames deferred across state changes", sharded_deferred_state_changes),
     ("custom scene and camera", custom_scene_and_camera),
     ("display, caller's ray counter, tile mirror", display_counter_and_mirror),
     ("reference seed mode, streaming", row_serial_streaming),

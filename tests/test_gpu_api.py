@@ -507,6 +507,55 @@ def test_sharded_batches_match_per_frame_exchange(tpt_defaults, oracle):
     assert got[mine].tobytes() == want[mine].tobytes() and not got[~mine].any(), describe_image_mismatch(got, want, mine)
 
 
+def test_deferred_sharded_frames_keep_the_configuration_they_were_accepted_under(tpt_defaults, oracle):
+    """tptDrawSharded collects small tiles into batches of 4 (tptSetShardExchangeInterval, automatic).  A camera / scene / spp change,
+    a change of the interval, a counter read and tptShardedFinish each issue what is pending first: rank 0's stripes and its ray total
+    equal the oracle's, configuration by configuration (the CPU twin: tests/hostemu_driver.py)."""
+    import numpy as np
+    import torch
+    from toypathtracer_amd.scenes import stress_scene
+    tpt = tpt_defaults
+    o = oracle
+    w, h, stripe, n, spp = 200, 120, 8, 4, 4
+    s, m = o.default_scene()
+    cam = o.default_camera(w, h)
+    s1, m1 = stress_scene(300, 18)
+    cam1 = o.camera((0, 3, 9), (0, 0, 0), (0, 1, 0), 50.0, w / h, 0.0, 9.0)
+    want = np.zeros((h, w, 4), np.float32)
+    total = 0
+    tpt.comm_init_loopback(n, stripe)
+    try:
+        img = torch.zeros((h, w, 4), dtype=torch.float32, device="cuda")
+        r0 = tpt.sharded_finish()
+        for f in range(17):
+            if f == 2:
+                tpt.set_camera((0, 3, 9), (0, 0, 0), 50.0, 0.0, 9.0)
+                cam = cam1
+            if f == 5:
+                tpt.set_scene(s1, m1)
+                s, m = s1, m1
+            if f == 7:
+                tpt.set_samples_per_pixel(3)
+                spp = 3
+            if f == 10:
+                tpt.set_shard_exchange_interval(3)
+            if f == 14:
+                assert tpt.ray_counter_read() - r0 == total
+            tpt.UpdateTest(0.0, f, w, h, FLAG_PROGRESSIVE)
+            tpt.draw_sharded(0.0, f, w, h, img.data_ptr(), FLAG_PROGRESSIVE)
+            for y0 in range(0, h, stripe * n):
+                r, _ = o.render(s, m, cam, w, h, spp, f, FLAG_PROGRESSIVE, backbuffer=want, seed_mode=SEED_PER_PIXEL, y0=y0, y1=min(y0 + stripe, h))
+                total += r
+        assert tpt.sharded_finish() - r0 == total
+        got = img.cpu().numpy()
+    finally:
+        tpt.set_shard_exchange_interval(0)
+        tpt.comm_destroy()
+    mine = (np.arange(h) // stripe) % n == 0
+    from common import describe_image_mismatch
+    assert got[mine].tobytes() == want[mine].tobytes() and not got[~mine].any(), describe_image_mismatch(got, want, mine)
+
+
 def test_synchronous_device_caller_gets_lookahead_and_the_same_bits(tpt_defaults, oracle):
     """tptDrawDevice + a synchronise after every frame (the reference's DrawTest contract on a device tile): from the third
     frame on the next frames are traced ahead; image, per-frame ray counts and totals equal the oracle's.  A caller that

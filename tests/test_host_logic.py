@@ -78,7 +78,7 @@ def runs():
 def test_host_logic_against_the_oracle(runs, schedule):
     rc, text = runs[schedule]
     lines = [ln for ln in text.splitlines() if ln.startswith(("OK", "FAIL"))]
-    assert rc == 0 and len(lines) >= 23 and all(ln.startswith("OK") for ln in lines), text[-3000:]
+    assert rc == 0 and len(lines) >= 24 and all(ln.startswith("OK") for ln in lines), text[-3000:]
     assert "synchronous device caller  " in text  # (look-ahead hits reported)
 
 
@@ -86,7 +86,7 @@ def test_host_logic_against_the_oracle(runs, schedule):
 def test_tail_helpers_against_the_oracle(runs, schedule):
     rc, text = runs[schedule]
     lines = [ln for ln in text.splitlines() if ln.startswith(("OK", "FAIL"))]
-    assert rc == 0 and len(lines) >= 23 and all(ln.startswith("OK") for ln in lines), text[-3000:]
+    assert rc == 0 and len(lines) >= 24 and all(ln.startswith("OK") for ln in lines), text[-3000:]
     import re
     m = re.search(r"helper grids: (\d+) found their launch closed, (\d+) the pool dry, (\d+) took chunks", text)
     assert m and int(m.group(1)) + int(m.group(3)) > 0, "no helper grid was launched: the scenario no longer exercises the tail helpers"

@@ -604,6 +604,125 @@ __device__ __forceinline__ void groupMasksTwoLevel(const SceneView& sv, const fl
         cm3 |= w == 3 ? bits : 0ull;
     }
 }
+// profiling build (-DTPT_STATS=2): s_memtime ticks of the dealing's stages, summed by lane 0 of every wave into g_tptStats[90..99]
+// ([90] big spheres [91] super-groups' bounds, wave-wide [92] groups' bounds per lane + list entries [93] member filter (list, parked
+// ray, gathers) [94] survivors dealt + exact tests; [95] sub-rounds of 64 pairs [96] pairs [97] rounds [98] survivors [99] calls [100] exact passes)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(TPT_STATS) && TPT_STATS >= 2
+#define TPT_DEAL_T(v) TPT_HS_STAMP(v)
+__shared__ unsigned long long g_dealLds[11]; // per-workgroup sums (LDS atomics: global ones made the build 60 x slower), flushed when the workgroup ends
+#define TPT_DEAL_ADD(slot, a, b) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_dealLds[(slot) - 90], (unsigned long long)((b) - (a))); } while (0)
+#define TPT_DEAL_COUNT(slot, n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_dealLds[(slot) - 90], (unsigned long long)(n)); } while (0)
+#else
+#define TPT_DEAL_T(v) do { } while (0)
+#define TPT_DEAL_ADD(slot, a, b) do { } while (0)
+#define TPT_DEAL_COUNT(slot, n) do { } while (0)
+#endif
+// One exact pass of the dealing: lane j < n takes survivor entry list[first + j] = (owner's path id << 20 | member slot), reads the
+// owner's parked ray and the member, runs the reference's test (Maths.cpp:171-190) and merges a hit into the owner's key.
+template <int PATHS>
+__device__ __forceinline__ void dealExactPass(const SceneView& sv, LdsList list, unsigned first, unsigned n, f4* st, int lane)
+{
+    TPT_DEAL_COUNT(100, 1);
+    if ((unsigned)lane < n) {
+        const unsigned e2 = list[first + (unsigned)lane];
+        const int po2 = (int)(e2 >> 20), slot = (int)(e2 & 0xfffffu);
+        const f4 q0 = st[po2], q1 = st[PATHS + po2];
+        float ht2 = TPT_MAX_T;
+        int hid2 = -1;
+        TPT_STAT(ST_PHASE2);
+        testSphereTie(sv.gsph[slot], sv.gid[slot], mk3(q0.z, q0.w, q1.x), mk3(q1.y, q1.z, q1.w), TPT_MIN_T, ht2, hid2);
+        if (hid2 >= 0) atomicMin(reinterpret_cast<unsigned long long*>(&st[po2]), ((unsigned long long)f2u(ht2) << 32) | (unsigned long long)(uint32_t)hid2);
+    }
+}
+#ifndef TPT_DEAL_TEAMS
+#define TPT_DEAL_TEAMS 0 // the member filter by teams of 8 lanes, one member each (dealProcessListTeams); 0: one pair per lane, eight gathers each
+#endif
+#ifndef TPT_TEAM_UNROLL
+#define TPT_TEAM_UNROLL 4 // steps of 8 pairs whose loads are issued together
+#endif
+// The same round with the member filter dealt out by TEAMS: the eight lanes of a team take one (ray, group) pair, one member each.
+// A group's eight members are one 128-byte line, so a step's gather touches 8 lines with all 64 lanes -- the pair-per-lane form
+// touches 64 lines per gather and eight gathers per pair, and the vector cache's tag rate, not the arithmetic, bounded it
+// (profiles/r06: 43 % of the issue rate).  The parked ray is read by the team's lanes from the same LDS address (a broadcast).
+// Survivors go on the same stack (ballot + prefix count: no atomics); TPT_TEAM_UNROLL steps have their loads in flight together.
+template <int PATHS>
+__device__ __forceinline__ void dealProcessListTeams(const SceneView& sv, LdsList list, unsigned* listCount, f4* st, int lane)
+{
+    unsigned total = __hip_atomic_load(listCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    total = total < (unsigned)TPT_GROUP_DEAL_CAP ? total : (unsigned)TPT_GROUP_DEAL_CAP;
+    total = (unsigned)__builtin_amdgcn_readfirstlane((int)total);
+    unsigned pend = 0u; // survivors waiting for their exact test in list[0 .. pend) (wave-uniform)
+    const unsigned team = (unsigned)lane >> 3, member = (unsigned)lane & 7u;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    constexpr int U = TPT_TEAM_UNROLL;
+    for (unsigned base = 0; base < total; base += 8u * U) {
+        TPT_DEAL_T(tA_);
+        TPT_DEAL_COUNT(95, 1);
+        TPT_DEAL_COUNT(96, total - base < 8u * U ? total - base : 8u * U);
+        // every entry of this body is read before the first survivor is pushed: positions [0, base + 8 U) are free from here on
+        unsigned e[U];
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+            const unsigned idx = base + 8u * t + team;
+            e[t] = idx < total ? list[idx] : 0xffffffffu;
+        }
+        const unsigned cap = base + 8u * U;
+        f4 s[U], r0[U], r1[U];
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+            s[t] = r0[t] = r1[t] = mk4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (e[t] != 0xffffffffu) {
+                const unsigned po = e[t] >> 16, g = e[t] & 0xffffu;
+                s[t] = sv.gsph[(size_t)g * TPT_GROUP + member];
+                r0[t] = st[po];
+                r1[t] = st[PATHS + po];
+            }
+        }
+        TPT_DEAL_T(tB_);
+        TPT_DEAL_ADD(93, tA_, tB_);
+#pragma unroll
+        for (int t = 0; t < U; ++t) {
+            const bool have = e[t] != 0xffffffffu;
+            const unsigned po = e[t] >> 16, slot = (e[t] & 0xffffu) * TPT_GROUP + member;
+            const f3 ro = mk3(r0[t].z, r0[t].w, r1[t].x), rd = mk3(r1[t].y, r1[t].z, r1[t].w);
+            const f3 dk = mk3(rd.x * TPT_P1_K, rd.y * TPT_P1_K, rd.z * TPT_P1_K);
+            const bool pass = have && memberFilter(s[t], ro, dk);
+            const unsigned long long m = __ballot(pass);
+            if (m != 0ull) {
+                TPT_DEAL_COUNT(98, __popcll(m));
+                const unsigned pos = pend + (unsigned)__popcll(m & below);
+                if (pass) {
+                    if (pos < cap) {
+                        list[pos] = (po << 20) | slot;
+                    } else { // (the stack is full: this survivor is tested where it was found)
+                        float ht = TPT_MAX_T;
+                        int hid = -1;
+                        TPT_STAT(ST_PHASE2);
+                        testSphereTie(s[t], sv.gid[slot], ro, rd, TPT_MIN_T, ht, hid);
+                        if (hid >= 0) atomicMin(reinterpret_cast<unsigned long long*>(&st[po]), ((unsigned long long)f2u(ht) << 32) | (unsigned long long)(uint32_t)hid);
+                    }
+                }
+                pend += (unsigned)__popcll(m);
+                pend = pend < cap ? pend : cap;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        while (pend >= 64u) {
+            pend -= 64u;
+            dealExactPass<PATHS>(sv, list, pend, 64u, st, lane);
+        }
+        __builtin_amdgcn_wave_barrier();
+        TPT_DEAL_T(tC_);
+        TPT_DEAL_ADD(94, tB_, tC_);
+    }
+    if (pend != 0u) { // the survivors still waiting: one last pass
+        TPT_DEAL_T(tD_);
+        dealExactPass<PATHS>(sv, list, 0u, pend, st, lane);
+        __builtin_amdgcn_wave_barrier();
+        TPT_DEAL_T(tE_);
+        TPT_DEAL_ADD(94, tD_, tE_);
+    }
+}
 // One round of the dealing, consumer side: the wave's pair list holds (owner's path id << 16 | group) entries; lane j takes entry j
 // (sub-rounds of 64), reads the owner's parked ray, filters the group's members, deals the survivors out once more for their exact
 // tests and merges hits into the owners' keys (see hitSpheresGroupedDeal).
@@ -612,7 +731,12 @@ __device__ __forceinline__ void dealProcessList(const SceneView& sv, LdsList lis
 {
     unsigned total = __hip_atomic_load(listCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     total = total < (unsigned)TPT_GROUP_DEAL_CAP ? total : (unsigned)TPT_GROUP_DEAL_CAP;
+    unsigned pend = 0u; // survivors waiting for their exact test in list[0 .. pend) (wave-uniform; listCount[1] is the same number, for the atomics)
+    if (lane == 0) listCount[1] = 0u;
     for (unsigned base = 0; base < total; base += 64u) {
+        TPT_DEAL_T(tA_);
+        TPT_DEAL_COUNT(95, 1);
+        TPT_DEAL_COUNT(96, total - base < 64u ? total - base : 64u);
         const bool have = base + (unsigned)lane < total;
         unsigned e = 0;
         if (have) e = list[base + (unsigned)lane];
@@ -629,11 +753,15 @@ __device__ __forceinline__ void dealProcessList(const SceneView& sv, LdsList lis
             TPT_PRAGMA_UNROLL(TPT_MEMBER_UNROLL)
             for (int j = 0; j < TPT_GROUP; ++j) mm |= (memberFilter(mem[j], ro, dk) ? 1u : 0u) << j;
         }
+        TPT_DEAL_T(tB_);
+        TPT_DEAL_ADD(93, tA_, tB_);
 #if TPT_GROUP_DEAL_EXACT
-        // The members that passed -- 0.33 per pair, so a lane-by-lane loop runs 2-3 trips at 8 busy lanes -- are dealt out once
-        // more: (owner's path id << 20 | member slot) entries into the 64 list positions this sub-round has just consumed,
-        // one exact test per lane.  (More than 64 survivors: the surplus is tested in place.)
-        if (lane == 0) listCount[1] = 0u;
+        // The members that passed -- 0.27 per pair, ~15 per sub-round -- are dealt out once more for their exact tests: (owner's path id
+        // << 20 | member slot) entries, pushed on a stack of survivors that grows in the list positions the sub-rounds have consumed so far
+        // ([0, base + 64)).  An exact pass (45 instructions + two dependent LDS / L2 round trips) runs only when 64 survivors are
+        // waiting, and once at the end for the rest: 1.8 passes per call instead of one per sub-round (5.2 at 15 busy lanes).
+        // (A survivor that finds the stack full is tested in place by the lane that found it.)
+        const unsigned cap = base + 64u;
         __builtin_amdgcn_wave_barrier();
         float ht = TPT_MAX_T;
         int hid = -1;
@@ -642,8 +770,8 @@ __device__ __forceinline__ void dealProcessList(const SceneView& sv, LdsList lis
             while (mm) {
                 const int j = __builtin_ctz(mm);
                 mm &= mm - 1u;
-                if (pos < 64u) {
-                    list[base + pos] = ((unsigned)po << 20) | (unsigned)(g * TPT_GROUP + j);
+                if (pos < cap) {
+                    list[pos] = ((unsigned)po << 20) | (unsigned)(g * TPT_GROUP + j);
                 } else {
                     TPT_STAT(ST_PHASE2);
                     testSphereTie(mem[j], sv.gid[g * TPT_GROUP + j], ro, rd, TPT_MIN_T, ht, hid);
@@ -653,17 +781,15 @@ __device__ __forceinline__ void dealProcessList(const SceneView& sv, LdsList lis
             if (hid >= 0) atomicMin(reinterpret_cast<unsigned long long*>(&st[po]), ((unsigned long long)f2u(ht) << 32) | (unsigned long long)(uint32_t)hid);
         }
         __builtin_amdgcn_wave_barrier();
-        unsigned nSurv = __hip_atomic_load(&listCount[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        nSurv = nSurv < 64u ? nSurv : 64u;
-        if ((unsigned)lane < nSurv) {
-            const unsigned e2 = list[base + (unsigned)lane];
-            const int po2 = (int)(e2 >> 20), slot = (int)(e2 & 0xfffffu);
-            const f4 q0 = st[po2], q1 = st[PATHS + po2];
-            float ht2 = TPT_MAX_T;
-            int hid2 = -1;
-            TPT_STAT(ST_PHASE2);
-            testSphereTie(sv.gsph[slot], sv.gid[slot], mk3(q0.z, q0.w, q1.x), mk3(q1.y, q1.z, q1.w), TPT_MIN_T, ht2, hid2);
-            if (hid2 >= 0) atomicMin(reinterpret_cast<unsigned long long*>(&st[po2]), ((unsigned long long)f2u(ht2) << 32) | (unsigned long long)(uint32_t)hid2);
+        const unsigned counted = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&listCount[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        TPT_DEAL_COUNT(98, counted - pend);
+        pend = counted < cap ? counted : cap;
+        if (pend >= 64u || counted > cap) {
+            while (pend >= 64u) {
+                pend -= 64u;
+                dealExactPass<PATHS>(sv, list, pend, 64u, st, lane);
+            }
+            if (lane == 0) listCount[1] = pend;
         }
         __builtin_amdgcn_wave_barrier();
 #else
@@ -679,7 +805,19 @@ __device__ __forceinline__ void dealProcessList(const SceneView& sv, LdsList lis
             if (hid >= 0) atomicMin(reinterpret_cast<unsigned long long*>(&st[po]), ((unsigned long long)f2u(ht) << 32) | (unsigned long long)(uint32_t)hid);
         }
 #endif
+        TPT_DEAL_T(tC_);
+        TPT_DEAL_ADD(94, tB_, tC_);
     }
+#if TPT_GROUP_DEAL_EXACT
+    if (pend != 0u) { // the survivors still waiting: one last pass (the stack is empty again for the next round)
+        TPT_DEAL_T(tD_);
+        dealExactPass<PATHS>(sv, list, 0u, pend, st, lane);
+        if (lane == 0) listCount[1] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        TPT_DEAL_T(tE_);
+        TPT_DEAL_ADD(94, tD_, tE_);
+    }
+#endif
 }
 // The two-level bounds filter and the producer side of the dealing in ONE pass over the scene (round 6): per chunk of 64 super-groups
 // (512 groups) the super-groups' bounds go through the wave-uniform packed filter (32 pair records, scalar loads); every lane then takes
@@ -693,10 +831,15 @@ __device__ __forceinline__ void dealTwoLevel(const SceneView& sv, const float* g
 {
     for (int sc0 = 0; sc0 < sv.nSuperPairs; sc0 += 32) {
         const int leftS = sv.nSuperPairs - sc0;
+        TPT_DEAL_T(t0_);
         uint64_t sm = phase1Chunk(pairPtr(sv.spairs + (size_t)sc0 * 8), leftS < 32 ? leftS : 32, ox, oy, oz, dx, dy, dz); // super-group k of the chunk: bit 63 - k
         if (!go) sm = 0ull;
+        TPT_DEAL_T(t1_);
+        TPT_DEAL_ADD(91, t0_, t1_);
         uint64_t cb = 0ull, sx = 0ull; // byte q: candidate bits of the q-th super-group taken (bit 7 = its first group) / its index k in the chunk
         while (__ballot((sm | cb) != 0ull) != 0ull) {
+            TPT_DEAL_T(t2_);
+            TPT_DEAL_COUNT(97, 1);
             if (cb == 0ull) {
                 sx = 0ull;
                 int ns = 0;
@@ -734,7 +877,13 @@ __device__ __forceinline__ void dealTwoLevel(const SceneView& sv, const float* g
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            TPT_DEAL_T(t3_);
+            TPT_DEAL_ADD(92, t2_, t3_);
+#if TPT_DEAL_TEAMS
+            dealProcessListTeams<PATHS>(sv, list, listCount, st, lane);
+#else
             dealProcessList<PATHS>(sv, list, listCount, st, lane);
+#endif
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -745,6 +894,8 @@ __device__ __forceinline__ int hitSpheresGroupedDeal(const SceneView& sv, bool g
 {
     float hitT = TPT_MAX_T;
     int id = -1;
+    TPT_DEAL_T(tb0_);
+    TPT_DEAL_COUNT(99, 1);
     if (go) {
         // the big spheres (ground, lights, dissolved groups: at most 64): the per-sphere conservative filter first (memberFilter = phase 1's
         // arithmetic, 12 instructions), the exact test (45) only for what passes -- every ray used to run all of them exactly
@@ -757,6 +908,8 @@ __device__ __forceinline__ int hitSpheresGroupedDeal(const SceneView& sv, bool g
             testSphereTie(sv.bsph[b], sv.bid[b], o, d, TPT_MIN_T, hitT, id);
         }
     }
+    TPT_DEAL_T(tb1_);
+    TPT_DEAL_ADD(90, tb0_, tb1_);
     const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
     const float gx = d.x * TPT_PG_K, gy = d.y * TPT_PG_K, gz = d.z * TPT_PG_K;
     const v2f dx = {gx, gx}, dy = {gy, gy}, dz = {gz, gz};
@@ -826,7 +979,11 @@ __device__ __forceinline__ int hitSpheresGroupedDeal(const SceneView& sv, bool g
                 }
             }
             __builtin_amdgcn_wave_barrier();
+#if TPT_DEAL_TEAMS
+            dealProcessListTeams<PATHS>(sv, list, listCount, st, lane);
+#else
             dealProcessList<PATHS>(sv, list, listCount, st, lane);
+#endif
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -946,6 +1103,9 @@ __device__ __forceinline__ void traceQueueBody(const KernelArgs& a)
 #endif
 #if defined(__HIP_DEVICE_COMPILE__) && defined(TPT_STATS) && TPT_STATS >= 2
     if (tid < 4) g_hsLds[tid] = 0ull;
+#if TPT_GROUP_DEAL
+    if (tid < 11) g_dealLds[tid] = 0ull;
+#endif
 #endif
     for (int i = tid; i < (int)(sizeof(FrameConsts) / 4); i += TPT_Q_T) reinterpret_cast<uint32_t*>(ldsFc)[i] = reinterpret_cast<const uint32_t*>(&a.fc)[i];
     // every path starts in the FREE queue; all other queues empty (sentinel everywhere)
@@ -1359,6 +1519,9 @@ __device__ __forceinline__ void traceQueueBody(const KernelArgs& a)
 #if defined(__HIP_DEVICE_COMPILE__) && defined(TPT_STATS) && TPT_STATS >= 2
     __syncthreads();
     if (tid < 4) TPT_COUNT(120 + tid, g_hsLds[tid]);
+#if TPT_GROUP_DEAL
+    if (tid < 11) TPT_COUNT(90 + tid, g_dealLds[tid]);
+#endif
 #endif
 #if defined(TPT_STATS)
     if (lane == 0) {

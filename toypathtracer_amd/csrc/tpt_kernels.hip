@@ -634,95 +634,6 @@ __device__ __forceinline__ void dealExactPass(const SceneView& sv, LdsList list,
         if (hid2 >= 0) atomicMin(reinterpret_cast<unsigned long long*>(&st[po2]), ((unsigned long long)f2u(ht2) << 32) | (unsigned long long)(uint32_t)hid2);
     }
 }
-#ifndef TPT_DEAL_TEAMS
-#define TPT_DEAL_TEAMS 0 // the member filter by teams of 8 lanes, one member each (dealProcessListTeams); 0: one pair per lane, eight gathers each
-#endif
-#ifndef TPT_TEAM_UNROLL
-#define TPT_TEAM_UNROLL 4 // steps of 8 pairs whose loads are issued together
-#endif
-// The same round with the member filter dealt out by TEAMS: the eight lanes of a team take one (ray, group) pair, one member each.
-// A group's eight members are one 128-byte line, so a step's gather touches 8 lines with all 64 lanes -- the pair-per-lane form
-// touches 64 lines per gather and eight gathers per pair, and the vector cache's tag rate, not the arithmetic, bounded it
-// (profiles/r06: 43 % of the issue rate).  The parked ray is read by the team's lanes from the same LDS address (a broadcast).
-// Survivors go on the same stack (ballot + prefix count: no atomics); TPT_TEAM_UNROLL steps have their loads in flight together.
-template <int PATHS>
-__device__ __forceinline__ void dealProcessListTeams(const SceneView& sv, LdsList list, unsigned* listCount, f4* st, int lane)
-{
-    unsigned total = __hip_atomic_load(listCount, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    total = total < (unsigned)TPT_GROUP_DEAL_CAP ? total : (unsigned)TPT_GROUP_DEAL_CAP;
-    total = (unsigned)__builtin_amdgcn_readfirstlane((int)total);
-    unsigned pend = 0u; // survivors waiting for their exact test in list[0 .. pend) (wave-uniform)
-    const unsigned team = (unsigned)lane >> 3, member = (unsigned)lane & 7u;
-    const unsigned long long below = (1ull << lane) - 1ull;
-    constexpr int U = TPT_TEAM_UNROLL;
-    for (unsigned base = 0; base < total; base += 8u * U) {
-        TPT_DEAL_T(tA_);
-        TPT_DEAL_COUNT(95, 1);
-        TPT_DEAL_COUNT(96, total - base < 8u * U ? total - base : 8u * U);
-        // every entry of this body is read before the first survivor is pushed: positions [0, base + 8 U) are free from here on
-        unsigned e[U];
-#pragma unroll
-        for (int t = 0; t < U; ++t) {
-            const unsigned idx = base + 8u * t + team;
-            e[t] = idx < total ? list[idx] : 0xffffffffu;
-        }
-        const unsigned cap = base + 8u * U;
-        f4 s[U], r0[U], r1[U];
-#pragma unroll
-        for (int t = 0; t < U; ++t) {
-            s[t] = r0[t] = r1[t] = mk4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (e[t] != 0xffffffffu) {
-                const unsigned po = e[t] >> 16, g = e[t] & 0xffffu;
-                s[t] = sv.gsph[(size_t)g * TPT_GROUP + member];
-                r0[t] = st[po];
-                r1[t] = st[PATHS + po];
-            }
-        }
-        TPT_DEAL_T(tB_);
-        TPT_DEAL_ADD(93, tA_, tB_);
-#pragma unroll
-        for (int t = 0; t < U; ++t) {
-            const bool have = e[t] != 0xffffffffu;
-            const unsigned po = e[t] >> 16, slot = (e[t] & 0xffffu) * TPT_GROUP + member;
-            const f3 ro = mk3(r0[t].z, r0[t].w, r1[t].x), rd = mk3(r1[t].y, r1[t].z, r1[t].w);
-            const f3 dk = mk3(rd.x * TPT_P1_K, rd.y * TPT_P1_K, rd.z * TPT_P1_K);
-            const bool pass = have && memberFilter(s[t], ro, dk);
-            const unsigned long long m = __ballot(pass);
-            if (m != 0ull) {
-                TPT_DEAL_COUNT(98, __popcll(m));
-                const unsigned pos = pend + (unsigned)__popcll(m & below);
-                if (pass) {
-                    if (pos < cap) {
-                        list[pos] = (po << 20) | slot;
-                    } else { // (the stack is full: this survivor is tested where it was found)
-                        float ht = TPT_MAX_T;
-                        int hid = -1;
-                        TPT_STAT(ST_PHASE2);
-                        testSphereTie(s[t], sv.gid[slot], ro, rd, TPT_MIN_T, ht, hid);
-                        if (hid >= 0) atomicMin(reinterpret_cast<unsigned long long*>(&st[po]), ((unsigned long long)f2u(ht) << 32) | (unsigned long long)(uint32_t)hid);
-                    }
-                }
-                pend += (unsigned)__popcll(m);
-                pend = pend < cap ? pend : cap;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        while (pend >= 64u) {
-            pend -= 64u;
-            dealExactPass<PATHS>(sv, list, pend, 64u, st, lane);
-        }
-        __builtin_amdgcn_wave_barrier();
-        TPT_DEAL_T(tC_);
-        TPT_DEAL_ADD(94, tB_, tC_);
-    }
-    if (pend != 0u) { // the survivors still waiting: one last pass
-        TPT_DEAL_T(tD_);
-        dealExactPass<PATHS>(sv, list, 0u, pend, st, lane);
-        __builtin_amdgcn_wave_barrier();
-        TPT_DEAL_T(tE_);
-        TPT_DEAL_ADD(94, tD_, tE_);
-    }
-}
 // One round of the dealing, consumer side: the wave's pair list holds (owner's path id << 16 | group) entries; lane j takes entry j
 // (sub-rounds of 64), reads the owner's parked ray, filters the group's members, deals the survivors out once more for their exact
 // tests and merges hits into the owners' keys (see hitSpheresGroupedDeal).
@@ -879,11 +790,7 @@ __device__ __forceinline__ void dealTwoLevel(const SceneView& sv, const float* g
             __builtin_amdgcn_wave_barrier();
             TPT_DEAL_T(t3_);
             TPT_DEAL_ADD(92, t2_, t3_);
-#if TPT_DEAL_TEAMS
-            dealProcessListTeams<PATHS>(sv, list, listCount, st, lane);
-#else
             dealProcessList<PATHS>(sv, list, listCount, st, lane);
-#endif
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -896,16 +803,30 @@ __device__ __forceinline__ int hitSpheresGroupedDeal(const SceneView& sv, bool g
     int id = -1;
     TPT_DEAL_T(tb0_);
     TPT_DEAL_COUNT(99, 1);
-    if (go) {
-        // the big spheres (ground, lights, dissolved groups: at most 64): the per-sphere conservative filter first (memberFilter = phase 1's
-        // arithmetic, 12 instructions), the exact test (45) only for what passes -- every ray used to run all of them exactly
+    {
+        // The big spheres (ground, lights, dissolved groups: at most 64), wave-uniform in b: {centre, r^2} and the original index come
+        // through SCALAR loads (constant address space, like the pair records) and feed the VALU as scalar operands; the per-sphere
+        // conservative filter first (memberFilter = phase 1's arithmetic, 12 instructions), the exact test (45) under the lanes' mask only
+        // where it passes (skipped when no lane is left).  Until round 6 this was a vector load per sphere with a full wait behind each --
+        // five L2 round trips in a row per call, 10.7 % of the wave time at configs[4] (profiles/r06/r06_run22.log).
+#if defined(__HIP_DEVICE_COMPILE__)
+        typedef const f4 __attribute__((address_space(4))) * BigPtr;
+        typedef const int __attribute__((address_space(4))) * BigIdPtr;
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+        const BigPtr bs = (BigPtr)(sv.bsph);
+        const BigIdPtr bi = (BigIdPtr)(sv.bid);
+#pragma clang diagnostic pop
+#else
+        const f4* bs = sv.bsph;
+        const int* bi = sv.bid;
+#endif
         const f3 dk1 = mk3(d.x * TPT_P1_K, d.y * TPT_P1_K, d.z * TPT_P1_K);
-        uint64_t bm = 0ull;
-        for (int b = 0; b < sv.nBig; ++b) bm |= (uint64_t)(memberFilter(sv.bsph[b], o, dk1) ? 1u : 0u) << b;
-        while (bm) {
-            const int b = __builtin_ctzll(bm);
-            bm &= bm - 1ull;
-            testSphereTie(sv.bsph[b], sv.bid[b], o, d, TPT_MIN_T, hitT, id);
+#pragma unroll 4
+        for (int b = 0; b < sv.nBig; ++b) {
+            const f4 s = bs[b];
+            const int sid = bi[b];
+            if (go && memberFilter(s, o, dk1)) testSphereTie(s, sid, o, d, TPT_MIN_T, hitT, id);
         }
     }
     TPT_DEAL_T(tb1_);
@@ -979,11 +900,7 @@ __device__ __forceinline__ int hitSpheresGroupedDeal(const SceneView& sv, bool g
                 }
             }
             __builtin_amdgcn_wave_barrier();
-#if TPT_DEAL_TEAMS
-            dealProcessListTeams<PATHS>(sv, list, listCount, st, lane);
-#else
             dealProcessList<PATHS>(sv, list, listCount, st, lane);
-#endif
             __builtin_amdgcn_wave_barrier();
         }
     }

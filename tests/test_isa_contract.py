@@ -113,6 +113,15 @@ def test_register_budget_of_the_queue_kernels(code_object):
     assert meta[QUEUE % (0, 1)]["vgpr_spill_count"] <= 4 and meta[QUEUE % (0, 1)]["private_segment_fixed_size"] <= 16, meta[QUEUE % (0, 1)]
 
 
+def test_big_spheres_of_a_grouped_scene_come_through_scalar_loads(code_object):
+    """hitSpheresGroupedDeal reads {centre, r^2} and the index of every big sphere (ground, lights) wave-uniformly: as s_load_dwordx4 through
+    the constant address space.  As vector loads with a wait behind each they were five serial L2 round trips per call (10.7 % of the wave
+    time at configs[4], profiles/r06/r06_run22.log / r06_run24.log)."""
+    bodies, _ = code_object
+    for batch in (0, 1):
+        assert count(bodies[QUEUE % (0, batch)], r"s_load_dwordx4") >= 6, count(bodies[QUEUE % (0, batch)], r"s_load_dwordx4")
+
+
 def test_divisions_of_the_hot_path_are_the_short_forms(code_object):
     bodies, _ = code_object
     for lds in (0, 1):

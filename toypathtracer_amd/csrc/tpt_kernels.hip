@@ -630,7 +630,14 @@ __device__ __forceinline__ void dealExactPass(const SceneView& sv, LdsList list,
         float ht2 = TPT_MAX_T;
         int hid2 = -1;
         TPT_STAT(ST_PHASE2);
-        testSphereTie(sv.gsph[slot], sv.gid[slot], mk3(q0.z, q0.w, q1.x), mk3(q1.y, q1.z, q1.w), TPT_MIN_T, ht2, hid2);
+        // (both gathers requested together: left to itself the compiler asks for the original index only once the discriminant is known to
+        //  be positive -- a second L2 round trip behind the first)
+        const f4 sph = sv.gsph[slot];
+        int sid = sv.gid[slot];
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(sid));
+#endif
+        testSphereTie(sph, sid, mk3(q0.z, q0.w, q1.x), mk3(q1.y, q1.z, q1.w), TPT_MIN_T, ht2, hid2);
         if (hid2 >= 0) atomicMin(reinterpret_cast<unsigned long long*>(&st[po2]), ((unsigned long long)f2u(ht2) << 32) | (unsigned long long)(uint32_t)hid2);
     }
 }

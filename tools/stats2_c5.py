@@ -30,9 +30,11 @@ for rep in range(2):
     tot = float(sum(st[112:117])) or 1.0
     print("  wave time: pick+pop %.1f %%  class code %.1f %%  intersect %.1f %%  push %.1f %%  idle %.1f %%" % tuple(100.0 * st[112 + k] / tot for k in range(5)))
     calls = max(st[99], 1)
-    names = ["big spheres", "super-groups' bounds (wave-wide)", "groups' bounds per lane + list entries", "member filter (list, parked ray, gathers)", "survivors dealt + exact tests"]
+    names = ["big spheres", "super-groups' bounds (wave-wide)", "groups' bounds + group entries (stage B)", "member filter (list, parked ray, gathers)", "survivors dealt + exact tests"]
     for k, nm in enumerate(names):
         print("    %-44s %5.1f %% of wave time, %7.0f ticks per call" % (nm, 100.0 * st[90 + k] / tot, st[90 + k] / calls))
+    print("    %-44s %5.1f %% of wave time, %7.0f ticks per call" % ("super-group entries written (stage A)", 100.0 * st[104] / tot, st[104] / calls))
     print("  per call (64 lanes): rounds %.2f, sub-rounds of 64 pairs %.2f, pairs %.1f, survivors %.1f, exact passes %.2f; rays per call %.1f" % (
         st[97] / calls, st[95] / calls, st[96] / calls, st[98] / calls, st[100] / calls, rays / calls))
+    print("  wave trips per call: stage A entry loop %.2f, stage B entry loop %.2f, survivors' push loop %.2f" % (st[101] / calls, st[102] / calls, st[103] / calls))
 api.ShutdownTest()

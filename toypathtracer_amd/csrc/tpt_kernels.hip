@@ -436,7 +436,21 @@ __device__ __forceinline__ f4 mk4(float x, float y, float z, float w)
 // 816 by 11 % (sweep 128 ... 640: profiles/r06/r06_run14-16.log); longer lists take the LDS from the path pool and lose again.
 #define TPT_GROUP_DEAL_CAP 448
 #endif
-#define TPT_GROUP_DEAL_WAVE_BYTES (TPT_GROUP_DEAL_CAP * 4 + 16)
+// The three-stage dealing (dealThreeStage) cuts the wave's list area into (path, super-group) entries of a round, the stack of (path,
+// group) entries waiting for a member pass and the stack of survivors waiting for an exact pass; the flat / matrix-core variants use the
+// first TPT_GROUP_DEAL_CAP entries as one pair list.  Four counters behind the entries.
+#ifndef TPT_DEAL_CA
+#define TPT_DEAL_CA 256
+#endif
+#ifndef TPT_DEAL_CB
+#define TPT_DEAL_CB 256 // (a sub-round of 64 super-group entries leaves 93 group entries on average, 512 at most; fewer than 64 wait when it starts)
+#endif
+#ifndef TPT_DEAL_CS
+#define TPT_DEAL_CS 128 // (a member pass leaves 17 survivors on average, 512 at most; fewer than 64 wait when it starts)
+#endif
+#define TPT_GROUP_DEAL_ENTRIES (TPT_DEAL_CA + TPT_DEAL_CB + TPT_DEAL_CS)
+static_assert(TPT_GROUP_DEAL_ENTRIES >= TPT_GROUP_DEAL_CAP, "the flat variants' pair list lives in the same area");
+#define TPT_GROUP_DEAL_WAVE_BYTES (TPT_GROUP_DEAL_ENTRIES * 4 + 16)
 #define TPT_Q_SPH_FIXED 1024 /* bytes at LDS offset 0 for {centre, r^2} of scenes of <= 64 spheres: DS offsets fold into the instructions */
 #ifndef TPT_Q_PATHS
 // paths per workgroup (<= TPT_Q_P): what the path records in LDS are sized for.  960 with the matrix filter: its 4-KB operand
@@ -448,9 +462,15 @@ __device__ __forceinline__ f4 mk4(float x, float y, float z, float w)
 // ... and of the instantiation for GROUPED scenes (no scene staging, no matrix-filter table): 720.  The LDS the smaller pool frees holds
 // the longer pair lists of the dealing (TPT_GROUP_DEAL_CAP) and the groups' bounding spheres (pair records, 16 B per group, for up to
 // TPT_Q_GROUP_LDS_BYTES: the second level of the bounds filter reads them per lane, and from L2 that loop would be latency-bound)
-#define TPT_Q_PATHS_GROUPED 720
+#define TPT_Q_PATHS_GROUPED 608
 #endif
-#define TPT_Q_GROUP_LDS_BYTES 8704 /* group pair records in LDS at most: 544 groups = 68 super-groups (a launch that would lose its second workgroup per CU to them reads them from global memory instead: chooseKernel) */
+// The groups' pair records in LDS: a super-group's four records (128 B) are read per lane by lanes that hold DIFFERENT super-groups. At a
+// stride of 128 B every lane's read of "record q, half h" lands on one of two 16-byte bank groups of the 16 -- an 8-way conflict on
+// every read (68 % of the LDS's active cycles were conflict cycles, profiles/r06/r06_run30.log).  Nine bank groups per super-group
+// (144 B: 16 B of padding) spread consecutive super-groups over all sixteen.
+#define TPT_GPAIR_LDS_STRIDE 36 /* floats per super-group in LDS (32 of data) */
+static_assert((TPT_SUPER / 2) * 8 == 32, "the padded LDS layout of the groups' pair records is written for super-groups of 8 groups");
+#define TPT_Q_GROUP_LDS_BYTES 9808 /* group pair records in LDS at most: 68 super-groups x 144 B + 16 (a launch that would lose its second workgroup per CU to them reads them from global memory instead: chooseKernel) */
 #ifndef TPT_Q_FUSE_MIN
 #define TPT_Q_FUSE_MIN 48 // a batch intersects its own rays when at least this many lanes still hold one
 #endif
@@ -606,13 +626,15 @@ __device__ __forceinline__ void groupMasksTwoLevel(const SceneView& sv, const fl
 }
 // profiling build (-DTPT_STATS=2): s_memtime ticks of the dealing's stages, summed by lane 0 of every wave into g_tptStats[90..99]
 // ([90] big spheres [91] super-groups' bounds, wave-wide [92] groups' bounds per lane + list entries [93] member filter (list, parked
-// ray, gathers) [94] survivors dealt + exact tests; [95] sub-rounds of 64 pairs [96] pairs [97] rounds [98] survivors [99] calls [100] exact passes)
+// ray, gathers) [94] survivors dealt + exact tests; [95] sub-rounds of 64 pairs [96] pairs [97] rounds [98] survivors [99] calls [100] exact passes [101] wave trips of the per-lane super-group loop [102] of the entry-writing loop [103] of the survivors' push loop)
 #if defined(__HIP_DEVICE_COMPILE__) && defined(TPT_STATS) && TPT_STATS >= 2
 #define TPT_DEAL_T(v) TPT_HS_STAMP(v)
-__shared__ unsigned long long g_dealLds[11]; // per-workgroup sums (LDS atomics: global ones made the build 60 x slower), flushed when the workgroup ends
+__shared__ unsigned long long g_dealLds[15]; // per-workgroup sums (LDS atomics: global ones made the build 60 x slower), flushed when the workgroup ends
 #define TPT_DEAL_ADD(slot, a, b) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_dealLds[(slot) - 90], (unsigned long long)((b) - (a))); } while (0)
 #define TPT_DEAL_COUNT(slot, n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_dealLds[(slot) - 90], (unsigned long long)(n)); } while (0)
+#define TPT_DEAL_TRIP(slot) do { if (TPT_HS_FIRST()) atomicAdd(&g_dealLds[(slot) - 90], 1ull); } while (0) /* inside divergent loops: the first active lane counts the wave's trip */
 #else
+#define TPT_DEAL_TRIP(slot) do { } while (0)
 #define TPT_DEAL_T(v) do { } while (0)
 #define TPT_DEAL_ADD(slot, a, b) do { } while (0)
 #define TPT_DEAL_COUNT(slot, n) do { } while (0)
@@ -686,6 +708,7 @@ __device__ __forceinline__ void dealProcessList(const SceneView& sv, LdsList lis
         if (mm) {
             unsigned pos = atomicAdd(&listCount[1], (unsigned)__popc(mm));
             while (mm) {
+                TPT_DEAL_TRIP(103);
                 const int j = __builtin_ctz(mm);
                 mm &= mm - 1u;
                 if (pos < cap) {
@@ -737,16 +760,108 @@ __device__ __forceinline__ void dealProcessList(const SceneView& sv, LdsList lis
     }
 #endif
 }
-// The two-level bounds filter and the producer side of the dealing in ONE pass over the scene (round 6): per chunk of 64 super-groups
-// (512 groups) the super-groups' bounds go through the wave-uniform packed filter (32 pair records, scalar loads); every lane then takes
-// up to 8 of the super-groups ITS ray touches, tests their 8 groups each (4 pair records at gpairsLane: LDS when they fit) and keeps the
-// results as 8 bytes of candidate bits + 8 bytes of super-group indices -- 4 registers instead of the four 64-bit candidate words per
-// 256 groups the flat filters need -- from which it writes its (path, group) entries straight into the wave's pair list.  One round
-// serves the 512 groups of a chunk (two rounds of 256 before), entries that do not fit the list stay in the bytes for the next round.
+// A (ray, group) pair that found the list of waiting pairs full: its lane filters and tests the group's members itself (rare; slow).
 template <int PATHS>
-__device__ __forceinline__ void dealTwoLevel(const SceneView& sv, const float* gpairsLane, bool go, f3 o, f3 d, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f dz,
-                                             LdsList list, unsigned* listCount, f4* st, int p, int lane, float hitT, int id, bool& parked)
+__device__ __forceinline__ void dealPairInPlace(const SceneView& sv, int po, int g, f4* st)
 {
+    const f4 r0 = st[po], r1 = st[PATHS + po]; // (read again here: the rare path must not keep the ray's six registers alive in the common one)
+    const f3 ro = mk3(r0.z, r0.w, r1.x), rd = mk3(r1.y, r1.z, r1.w);
+    const f3 dk = mk3(rd.x * TPT_P1_K, rd.y * TPT_P1_K, rd.z * TPT_P1_K);
+    const f4* mem = sv.gsph + (size_t)g * TPT_GROUP;
+    float ht = TPT_MAX_T;
+    int hid = -1;
+    for (int j = 0; j < TPT_GROUP; ++j) {
+        const f4 s = mem[j];
+        if (memberFilter(s, ro, dk)) {
+            TPT_STAT(ST_PHASE2);
+            testSphereTie(s, sv.gid[g * TPT_GROUP + j], ro, rd, TPT_MIN_T, ht, hid);
+        }
+    }
+    if (hid >= 0) atomicMin(reinterpret_cast<unsigned long long*>(&st[po]), ((unsigned long long)f2u(ht) << 32) | (unsigned long long)(uint32_t)hid);
+}
+// One member pass of the three-stage dealing: lane j < n takes the (owner's path id << 16 | group) entry B[first + j], reads the owner's
+// parked ray, filters the group's eight members and pushes the survivors -- (owner << 20 | member slot) -- on the stack S; an exact pass
+// runs whenever 64 survivors are waiting.  pendS: survivors on the stack (wave-uniform; *cntS holds the same number for the atomics).
+template <int PATHS>
+__device__ __forceinline__ void dealMemberPass(const SceneView& sv, LdsList B, unsigned first, unsigned n, LdsList S, unsigned* cntS, unsigned& pendS, f4* st, int lane)
+{
+    TPT_DEAL_T(tA_);
+    TPT_DEAL_COUNT(95, 1);
+    TPT_DEAL_COUNT(96, n);
+    const bool have = (unsigned)lane < n;
+    unsigned e = 0;
+    if (have) e = B[first + (unsigned)lane];
+    const int po = (int)(e >> 16), g = (int)(e & 0xffffu);
+    uint32_t mm = 0;
+    const f4* mem = sv.gsph + (size_t)g * TPT_GROUP;
+    if (have) {
+        const f4 r0 = st[po], r1 = st[PATHS + po];
+        const f3 ro = mk3(r0.z, r0.w, r1.x), rd = mk3(r1.y, r1.z, r1.w);
+        const f3 dk = mk3(rd.x * TPT_P1_K, rd.y * TPT_P1_K, rd.z * TPT_P1_K);
+        TPT_STAT(ST_SPHERELOOP); // profiling build: group visits
+        TPT_PRAGMA_UNROLL(TPT_MEMBER_UNROLL)
+        for (int j = 0; j < TPT_GROUP; ++j) mm |= (memberFilter(mem[j], ro, dk) ? 1u : 0u) << j;
+    }
+    TPT_DEAL_T(tB_);
+    TPT_DEAL_ADD(93, tA_, tB_);
+    __builtin_amdgcn_wave_barrier();
+    if (mm) {
+        float ht = TPT_MAX_T;
+        int hid = -1;
+        unsigned pos = atomicAdd(cntS, (unsigned)__popc(mm));
+        while (mm) {
+            TPT_DEAL_TRIP(103);
+            const int j = __builtin_ctz(mm);
+            mm &= mm - 1u;
+            if (pos < (unsigned)TPT_DEAL_CS) {
+                S[pos] = ((unsigned)po << 20) | (unsigned)(g * TPT_GROUP + j);
+            } else { // (the stack is full: this survivor is tested where it was found; the ray is read again -- see dealPairInPlace)
+                TPT_STAT(ST_PHASE2);
+                const f4 q0 = st[po], q1 = st[PATHS + po];
+                testSphereTie(mem[j], sv.gid[g * TPT_GROUP + j], mk3(q0.z, q0.w, q1.x), mk3(q1.y, q1.z, q1.w), TPT_MIN_T, ht, hid);
+            }
+            ++pos;
+        }
+        if (hid >= 0) atomicMin(reinterpret_cast<unsigned long long*>(&st[po]), ((unsigned long long)f2u(ht) << 32) | (unsigned long long)(uint32_t)hid);
+    }
+    __builtin_amdgcn_wave_barrier();
+    const unsigned counted = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cntS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+    TPT_DEAL_COUNT(98, counted - pendS);
+    pendS = counted < (unsigned)TPT_DEAL_CS ? counted : (unsigned)TPT_DEAL_CS;
+    if (pendS >= 64u || counted > (unsigned)TPT_DEAL_CS) {
+        while (pendS >= 64u) {
+            pendS -= 64u;
+            dealExactPass<PATHS>(sv, S, pendS, 64u, st, lane);
+        }
+        if (lane == 0) *cntS = pendS;
+    }
+    __builtin_amdgcn_wave_barrier();
+    TPT_DEAL_T(tC_);
+    TPT_DEAL_ADD(94, tB_, tC_);
+}
+// The grouped traversal as THREE dealt stages (round 6, final form).  Per chunk of 64 super-groups (512 groups) the super-groups' bounds
+// go through the wave-uniform packed filter (32 pair records, scalar loads); from there on nothing is done by "the lane that owns the
+// ray" any more -- a ray touches 3.5 super-groups, 4.9 groups and 1.3 members on the 4096-sphere scene, the busiest lane of a wave 8.4,
+// 15.5 and 10.5 (profiles/r06/r06_run28.log), so every per-owner loop ran at a third of the lanes:
+//   A  every lane writes one (path, super-group) entry per super-group its ray touches (and parks its ray);
+//   B  lane j takes A entry j (sub-rounds of 64): the owner's ray against the 8 groups of the super-group (4 pair records at gpairsLane:
+//      LDS when they fit), one (path, group) entry per group touched, pushed on the stack B; whenever 64 entries are waiting there:
+//   C  a member pass (dealMemberPass): 8 member filters per entry, survivors pushed on the stack S; whenever 64 are waiting: an exact pass.
+// What is left on B and S when the last chunk is through is drained by one partial pass each.  Order is irrelevant: hits merge into the
+// owners' keys with ds_min_u64 on (t bits, original index).  An entry that finds its stack full is served in place by the lane holding it.
+template <int PATHS>
+__device__ __forceinline__ void dealThreeStage(const SceneView& sv, const float* gpairsLane, int recStride, bool go, f3 o, f3 d, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f dz,
+                                               LdsList list, unsigned* cnt, f4* st, int p, int lane, float hitT, int id, bool& parked)
+{
+    LdsList A = list, B = list + TPT_DEAL_CA, S = list + TPT_DEAL_CA + TPT_DEAL_CB;
+    unsigned* const cntA = cnt;
+    unsigned* const cntB = cnt + 2;
+    unsigned* const cntS = cnt + 3;
+    unsigned nB = 0u, pendS = 0u; // entries waiting on B / S (wave-uniform)
+    if (lane == 0) {
+        *cntB = 0u;
+        *cntS = 0u;
+    }
     for (int sc0 = 0; sc0 < sv.nSuperPairs; sc0 += 32) {
         const int leftS = sv.nSuperPairs - sc0;
         TPT_DEAL_T(t0_);
@@ -754,53 +869,98 @@ __device__ __forceinline__ void dealTwoLevel(const SceneView& sv, const float* g
         if (!go) sm = 0ull;
         TPT_DEAL_T(t1_);
         TPT_DEAL_ADD(91, t0_, t1_);
-        uint64_t cb = 0ull, sx = 0ull; // byte q: candidate bits of the q-th super-group taken (bit 7 = its first group) / its index k in the chunk
-        while (__ballot((sm | cb) != 0ull) != 0ull) {
+        while (__ballot(sm != 0ull) != 0ull) { // rounds: until every touched super-group of every lane has been entered (TPT_DEAL_CA per round)
             TPT_DEAL_T(t2_);
             TPT_DEAL_COUNT(97, 1);
-            if (cb == 0ull) {
-                sx = 0ull;
-                int ns = 0;
-                while (sm != 0ull && ns < 8) {
+            // ---- A: (path, super-group) entries
+            if (lane == 0) *cntA = 0u;
+            __builtin_amdgcn_wave_barrier();
+            if (sm != 0ull) {
+                unsigned pos = atomicAdd(cntA, (unsigned)__popcll(sm));
+                while (pos < (unsigned)TPT_DEAL_CA && sm != 0ull) { // the entries that fit; the rest stay in the mask for the next round
+                    TPT_DEAL_TRIP(101);
                     const int k = __builtin_clzll(sm);
                     sm &= ~(0x8000000000000000ull >> k);
-                    const float* rec = gpairsLane + (size_t)(sc0 * 2 + k) * (TPT_SUPER / 2) * 8;
-                    uint32_t m = 0;
-#pragma unroll
-                    for (int q = 0; q < TPT_SUPER / 2; ++q) phase1PairLane(rec + q * 8, ox, oy, oz, dx, dy, dz, m);
-                    const uint64_t c8 = (uint64_t)(~m & 0xffu);
-                    if (c8) {
-                        cb |= c8 << (8 * ns);
-                        sx |= (uint64_t)k << (8 * ns);
-                        ++ns;
-                    }
-                }
-            }
-            const unsigned n = (unsigned)__popcll(cb);
-            if (lane == 0) *listCount = 0u;
-            __builtin_amdgcn_wave_barrier();
-            if (n != 0u) {
-                unsigned pos = atomicAdd(listCount, n);
-                while (pos < (unsigned)TPT_GROUP_DEAL_CAP && cb != 0ull) { // write the entries that fit; the rest stay in the bytes
-                    const int b = __builtin_ctzll(cb);
-                    cb &= cb - 1ull;
-                    const int k = (int)((sx >> (b & 56)) & 0xffull);
-                    list[pos] = ((unsigned)p << 16) | (unsigned)((sc0 * 2 + k) * TPT_SUPER + 7 - (b & 7));
+                    A[pos] = ((unsigned)p << 16) | (unsigned)(sc0 * 2 + k);
                     ++pos;
                 }
-                if (!parked) { // (o and d do not change between rounds; the key is kept current by the atomics)
+                if (!parked) { // (o and d do not change during the call; the key is kept current by the atomics)
                     st[p] = mk4(u2f((uint32_t)id), hitT, o.x, o.y); // {key lo = sphere id, key hi = t bits, o.x, o.y}
                     st[PATHS + p] = mk4(o.z, d.x, d.y, d.z);
                     parked = true;
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            TPT_DEAL_T(t3_);
-            TPT_DEAL_ADD(92, t2_, t3_);
-            dealProcessList<PATHS>(sv, list, listCount, st, lane);
-            __builtin_amdgcn_wave_barrier();
+            TPT_DEAL_T(tR_);
+            TPT_DEAL_ADD(104, t2_, tR_);
+            unsigned nA = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cntA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+            nA = nA < (unsigned)TPT_DEAL_CA ? nA : (unsigned)TPT_DEAL_CA;
+            // ---- B: lane j takes (path, super-group) entry j
+            for (unsigned a0 = 0; a0 < nA; a0 += 64u) {
+                TPT_DEAL_T(tS_);
+                const bool have = a0 + (unsigned)lane < nA;
+                unsigned e = 0;
+                if (have) e = A[a0 + (unsigned)lane];
+                const int po = (int)(e >> 16), sg = (int)(e & 0xffffu);
+                uint32_t c8 = 0;
+                if (have) {
+                    const f4 r0 = st[po], r1 = st[PATHS + po];
+                    const f3 ro = mk3(r0.z, r0.w, r1.x), rd = mk3(r1.y, r1.z, r1.w);
+                    // the owner's operands, made the way the owner makes them (hitSpheresGroupedDeal): the same bits, whoever computes
+                    const v2f qx = {ro.x, ro.x}, qy = {ro.y, ro.y}, qz = {ro.z, ro.z};
+                    const float gx = rd.x * TPT_PG_K, gy = rd.y * TPT_PG_K, gz = rd.z * TPT_PG_K;
+                    const v2f ex = {gx, gx}, ey = {gy, gy}, ez = {gz, gz};
+                    const float* rec = gpairsLane + sg * recStride; // (recStride: floats per super-group -- 32, or TPT_GPAIR_LDS_STRIDE in LDS)
+                    uint32_t m = 0;
+#pragma unroll
+                    for (int q = 0; q < TPT_SUPER / 2; ++q) phase1PairLane(rec + q * 8, qx, qy, qz, ex, ey, ez, m);
+                    c8 = ~m & 0xffu; // bit 7 = the super-group's first group
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (c8) {
+                    unsigned pos = atomicAdd(cntB, (unsigned)__popc(c8));
+                    while (c8) {
+                        TPT_DEAL_TRIP(102);
+                        const int b = __builtin_ctz(c8);
+                        c8 &= c8 - 1u;
+                        const int g = sg * TPT_SUPER + 7 - b;
+                        if (pos < (unsigned)TPT_DEAL_CB)
+                            B[pos] = ((unsigned)po << 16) | (unsigned)g;
+                        else
+                            dealPairInPlace<PATHS>(sv, po, g, st);
+                        ++pos;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                const unsigned counted = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cntB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+                nB = counted < (unsigned)TPT_DEAL_CB ? counted : (unsigned)TPT_DEAL_CB;
+                TPT_DEAL_T(t3_);
+                TPT_DEAL_ADD(92, tS_, t3_);
+                if (nB >= 64u || counted > (unsigned)TPT_DEAL_CB) {
+                    // ---- C: member passes while 64 (path, group) entries are waiting
+                    while (nB >= 64u) {
+                        nB -= 64u;
+                        dealMemberPass<PATHS>(sv, B, nB, 64u, S, cntS, pendS, st, lane);
+                    }
+                    if (lane == 0) *cntB = nB;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
         }
     }
+    // what is still waiting: one partial member pass, one partial exact pass (both stacks are empty again for the next call)
+    if (nB != 0u) {
+        dealMemberPass<PATHS>(sv, B, 0u, nB, S, cntS, pendS, st, lane);
+        if (lane == 0) *cntB = 0u;
+    }
+    if (pendS != 0u) {
+        TPT_DEAL_T(tD_);
+        dealExactPass<PATHS>(sv, S, 0u, pendS, st, lane);
+        if (lane == 0) *cntS = 0u;
+        TPT_DEAL_T(tE_);
+        TPT_DEAL_ADD(94, tD_, tE_);
+    }
+    __builtin_amdgcn_wave_barrier();
 }
 template <int PATHS>
 __device__ __forceinline__ int hitSpheresGroupedDeal(const SceneView& sv, bool go, f3 o, f3 d, float& outT, LdsList list, unsigned* listCount,
@@ -857,9 +1017,9 @@ __device__ __forceinline__ int hitSpheresGroupedDeal(const SceneView& sv, bool g
         // (two call sites: the LDS pointer must stay an LDS pointer -- merged with the global one it becomes a generic pointer and
         //  the per-lane reads FLAT loads, which reach LDS through the vector-memory path)
         if (boundsMode > 0)
-            dealTwoLevel<PATHS>(sv, ldsGpairs, go, o, d, ox, oy, oz, dx, dy, dz, list, listCount, st, p, lane, hitT, id, parked);
+            dealThreeStage<PATHS>(sv, ldsGpairs, TPT_GPAIR_LDS_STRIDE, go, o, d, ox, oy, oz, dx, dy, dz, list, listCount, st, p, lane, hitT, id, parked);
         else
-            dealTwoLevel<PATHS>(sv, sv.gpairs, go, o, d, ox, oy, oz, dx, dy, dz, list, listCount, st, p, lane, hitT, id, parked);
+            dealThreeStage<PATHS>(sv, sv.gpairs, (TPT_SUPER / 2) * 8, go, o, d, ox, oy, oz, dx, dy, dz, list, listCount, st, p, lane, hitT, id, parked);
     }
     MatrixRayOps mops;
     if (boundsOnMatrix) matrixRayOperands(o, d, 1, mops);
@@ -1018,8 +1178,8 @@ __device__ __forceinline__ void traceQueueBody(const KernelArgs& a)
     // never-a-candidate records to whole super-groups (hitSpheresGroupedDeal); not when they do not fit (the launch says: ldsGroupPairs)
     // (a.ldsGroupPairs: > 0 records staged in LDS, 0 read from global memory, < 0 flat filter)
     float* ldsGpairs = reinterpret_cast<float*>(smem + ((off + 15) & ~15));
-    if (!LDS_SCENE && a.ldsGroupPairs > 0)
-        for (int i = tid; i < a.ldsGroupPairs * 8; i += TPT_Q_T) ldsGpairs[i] = a.scene.gpairs[i]; // (the host pads to whole super-groups)
+    if (!LDS_SCENE && a.ldsGroupPairs > 0) // (the host pads to whole super-groups; in LDS each super-group's 32 floats sit at a stride of TPT_GPAIR_LDS_STRIDE)
+        for (int i = tid; i < a.ldsGroupPairs * 8; i += TPT_Q_T) ldsGpairs[(i >> 5) * TPT_GPAIR_LDS_STRIDE + (i & 31)] = a.scene.gpairs[i];
 #if TPT_MATRIX_FILTER
     if (useMatrix)
         for (int i = tid; i < TPT_MXH_TABLE_DWORDS; i += TPT_Q_T) ldsA[i] = a.scene.amatH[i];
@@ -1028,7 +1188,7 @@ __device__ __forceinline__ void traceQueueBody(const KernelArgs& a)
 #if defined(__HIP_DEVICE_COMPILE__) && defined(TPT_STATS) && TPT_STATS >= 2
     if (tid < 4) g_hsLds[tid] = 0ull;
 #if TPT_GROUP_DEAL
-    if (tid < 11) g_dealLds[tid] = 0ull;
+    if (tid < 15) g_dealLds[tid] = 0ull;
 #endif
 #endif
     for (int i = tid; i < (int)(sizeof(FrameConsts) / 4); i += TPT_Q_T) reinterpret_cast<uint32_t*>(ldsFc)[i] = reinterpret_cast<const uint32_t*>(&a.fc)[i];
@@ -1053,7 +1213,7 @@ __device__ __forceinline__ void traceQueueBody(const KernelArgs& a)
 #endif
 #if TPT_GROUP_DEAL
     LdsList dealList = (LdsList)(smem + kOffDeal + (tid >> 6) * TPT_GROUP_DEAL_WAVE_BYTES);
-    unsigned* dealCount = reinterpret_cast<unsigned*>(smem + kOffDeal + (tid >> 6) * TPT_GROUP_DEAL_WAVE_BYTES + TPT_GROUP_DEAL_CAP * 4);
+    unsigned* dealCount = reinterpret_cast<unsigned*>(smem + kOffDeal + (tid >> 6) * TPT_GROUP_DEAL_WAVE_BYTES + TPT_GROUP_DEAL_ENTRIES * 4);
     const bool groupDeal = !LDS_SCENE && sv.nGroups > 0 && sv.nGroups <= 65536; // (16 bits of group index, 20 of member slot, in a list entry)
 #endif
     f4* colSum = st + 2 * kPaths;                        // plane 2: per-path colour sums + pixel coordinates
@@ -1444,7 +1604,7 @@ __device__ __forceinline__ void traceQueueBody(const KernelArgs& a)
     __syncthreads();
     if (tid < 4) TPT_COUNT(120 + tid, g_hsLds[tid]);
 #if TPT_GROUP_DEAL
-    if (tid < 11) TPT_COUNT(90 + tid, g_dealLds[tid]);
+    if (tid < 15) TPT_COUNT(90 + tid, g_dealLds[tid]);
 #endif
 #endif
 #if defined(TPT_STATS)
@@ -1748,7 +1908,7 @@ size_t tptQueueLdsBytes(const KernelArgs& a, bool ldsScene)
     bytes += (size_t)a.scene.nLights * 32;
     bytes += (size_t)TPT_Q_NF4 * (ldsScene ? TPT_Q_PATHS : TPT_Q_PATHS_GROUPED) * 16 + (size_t)Q_COUNT * TPT_Q_P * 2 + ((sizeof(QueueCtl) + 63) & ~(size_t)63) + ((sizeof(FrameConsts) + 15) & ~(size_t)15);
     if (!ldsScene && TPT_GROUP_DEAL) bytes += (size_t)TPT_Q_WAVES * TPT_GROUP_DEAL_WAVE_BYTES;
-    if (!ldsScene && a.ldsGroupPairs > 0) bytes += 16 + (size_t)a.ldsGroupPairs * 32; // the groups' bounds for the second filter level (tptQueueGroupPairsInLds)
+    if (!ldsScene && a.ldsGroupPairs > 0) bytes += 16 + (size_t)(a.ldsGroupPairs / (TPT_SUPER / 2)) * TPT_GPAIR_LDS_STRIDE * 4; // the groups' bounds for the second filter level (tptQueueGroupPairsInLds), padded stride
 #if TPT_MATRIX_FILTER
     if (ldsScene && a.scene.mxR1 >= 0) bytes += TPT_MXH_TABLE_DWORDS * sizeof(uint32_t) + 64;
 #endif
@@ -1778,7 +1938,7 @@ int tptQueueGroupPairsInLds(int nGroups, int nSuperPairs)
 {
     if (nGroups <= 0 || nSuperPairs <= 0) return 0;
     const int pairs = ((nGroups + TPT_SUPER - 1) / TPT_SUPER) * (TPT_SUPER / 2);
-    return (size_t)pairs * 32 + 16 <= (size_t)TPT_Q_GROUP_LDS_BYTES ? pairs : 0;
+    return (size_t)(pairs / (TPT_SUPER / 2)) * TPT_GPAIR_LDS_STRIDE * 4 + 16 <= (size_t)TPT_Q_GROUP_LDS_BYTES ? pairs : 0;
 }
 int tptQueueMatrixFilter() { return TPT_MATRIX_FILTER; }
 int tptQueueGroupMatrixBounds() { return TPT_MATRIX_FILTER && TPT_GROUP_MATRIX_BOUNDS; }

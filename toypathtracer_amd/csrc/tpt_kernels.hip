@@ -639,6 +639,26 @@ __shared__ unsigned long long g_dealLds[15]; // per-workgroup sums (LDS atomics:
 #define TPT_DEAL_ADD(slot, a, b) do { } while (0)
 #define TPT_DEAL_COUNT(slot, n) do { } while (0)
 #endif
+// Exclusive prefix sum of v over the wave's 64 lanes (all of them must be executing), and the total: six DPP additions -- row shifts
+// by 1, 2, 4, 8 inside the rows of 16, then the rows' totals broadcast onward -- instead of a returning LDS atomic on one counter, which
+// the LDS serialises lane by lane and every wave of the CU waits behind (half of the remaining LDS conflict cycles, r06_run31.log).
+__device__ __forceinline__ unsigned wavePrefix(unsigned v, unsigned& total)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    int x = (int)v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, false); // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, false); // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, false); // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, false); // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false); // row_bcast:15 into rows 1 and 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false); // row_bcast:31 into rows 2 and 3
+    total = (unsigned)__builtin_amdgcn_readlane(x, 63);
+    return (unsigned)x - v;
+#else
+    total = v;
+    return 0u;
+#endif
+}
 // One exact pass of the dealing: lane j < n takes survivor entry list[first + j] = (owner's path id << 20 | member slot), reads the
 // owner's parked ray and the member, runs the reference's test (Maths.cpp:171-190) and merges a hit into the owner's key.
 template <int PATHS>
@@ -781,9 +801,9 @@ __device__ __forceinline__ void dealPairInPlace(const SceneView& sv, int po, int
 }
 // One member pass of the three-stage dealing: lane j < n takes the (owner's path id << 16 | group) entry B[first + j], reads the owner's
 // parked ray, filters the group's eight members and pushes the survivors -- (owner << 20 | member slot) -- on the stack S; an exact pass
-// runs whenever 64 survivors are waiting.  pendS: survivors on the stack (wave-uniform; *cntS holds the same number for the atomics).
+// runs whenever 64 survivors are waiting.  pendS: survivors on the stack (wave-uniform; positions come from a prefix sum over the lanes).
 template <int PATHS>
-__device__ __forceinline__ void dealMemberPass(const SceneView& sv, LdsList B, unsigned first, unsigned n, LdsList S, unsigned* cntS, unsigned& pendS, f4* st, int lane)
+__device__ __forceinline__ void dealMemberPass(const SceneView& sv, LdsList B, unsigned first, unsigned n, LdsList S, unsigned& pendS, f4* st, int lane)
 {
     TPT_DEAL_T(tA_);
     TPT_DEAL_COUNT(95, 1);
@@ -805,10 +825,12 @@ __device__ __forceinline__ void dealMemberPass(const SceneView& sv, LdsList B, u
     TPT_DEAL_T(tB_);
     TPT_DEAL_ADD(93, tA_, tB_);
     __builtin_amdgcn_wave_barrier();
+    unsigned nSurv;
+    unsigned pos = pendS + wavePrefix((unsigned)__popc(mm), nSurv);
+    TPT_DEAL_COUNT(98, nSurv);
     if (mm) {
         float ht = TPT_MAX_T;
         int hid = -1;
-        unsigned pos = atomicAdd(cntS, (unsigned)__popc(mm));
         while (mm) {
             TPT_DEAL_TRIP(103);
             const int j = __builtin_ctz(mm);
@@ -825,15 +847,11 @@ __device__ __forceinline__ void dealMemberPass(const SceneView& sv, LdsList B, u
         if (hid >= 0) atomicMin(reinterpret_cast<unsigned long long*>(&st[po]), ((unsigned long long)f2u(ht) << 32) | (unsigned long long)(uint32_t)hid);
     }
     __builtin_amdgcn_wave_barrier();
-    const unsigned counted = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cntS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-    TPT_DEAL_COUNT(98, counted - pendS);
-    pendS = counted < (unsigned)TPT_DEAL_CS ? counted : (unsigned)TPT_DEAL_CS;
-    if (pendS >= 64u || counted > (unsigned)TPT_DEAL_CS) {
-        while (pendS >= 64u) {
-            pendS -= 64u;
-            dealExactPass<PATHS>(sv, S, pendS, 64u, st, lane);
-        }
-        if (lane == 0) *cntS = pendS;
+    pendS += nSurv;
+    pendS = pendS < (unsigned)TPT_DEAL_CS ? pendS : (unsigned)TPT_DEAL_CS;
+    while (pendS >= 64u) {
+        pendS -= 64u;
+        dealExactPass<PATHS>(sv, S, pendS, 64u, st, lane);
     }
     __builtin_amdgcn_wave_barrier();
     TPT_DEAL_T(tC_);
@@ -854,14 +872,8 @@ __device__ __forceinline__ void dealThreeStage(const SceneView& sv, const float*
                                                LdsList list, unsigned* cnt, f4* st, int p, int lane, float hitT, int id, bool& parked)
 {
     LdsList A = list, B = list + TPT_DEAL_CA, S = list + TPT_DEAL_CA + TPT_DEAL_CB;
-    unsigned* const cntA = cnt;
-    unsigned* const cntB = cnt + 2;
-    unsigned* const cntS = cnt + 3;
+    (void)cnt; // (the counters behind the entries serve the flat variants; here every position comes from a prefix sum over the lanes)
     unsigned nB = 0u, pendS = 0u; // entries waiting on B / S (wave-uniform)
-    if (lane == 0) {
-        *cntB = 0u;
-        *cntS = 0u;
-    }
     for (int sc0 = 0; sc0 < sv.nSuperPairs; sc0 += 32) {
         const int leftS = sv.nSuperPairs - sc0;
         TPT_DEAL_T(t0_);
@@ -873,27 +885,27 @@ __device__ __forceinline__ void dealThreeStage(const SceneView& sv, const float*
             TPT_DEAL_T(t2_);
             TPT_DEAL_COUNT(97, 1);
             // ---- A: (path, super-group) entries
-            if (lane == 0) *cntA = 0u;
-            __builtin_amdgcn_wave_barrier();
-            if (sm != 0ull) {
-                unsigned pos = atomicAdd(cntA, (unsigned)__popcll(sm));
-                while (pos < (unsigned)TPT_DEAL_CA && sm != 0ull) { // the entries that fit; the rest stay in the mask for the next round
-                    TPT_DEAL_TRIP(101);
-                    const int k = __builtin_clzll(sm);
-                    sm &= ~(0x8000000000000000ull >> k);
-                    A[pos] = ((unsigned)p << 16) | (unsigned)(sc0 * 2 + k);
-                    ++pos;
-                }
-                if (!parked) { // (o and d do not change during the call; the key is kept current by the atomics)
-                    st[p] = mk4(u2f((uint32_t)id), hitT, o.x, o.y); // {key lo = sphere id, key hi = t bits, o.x, o.y}
-                    st[PATHS + p] = mk4(o.z, d.x, d.y, d.z);
-                    parked = true;
+            unsigned nA;
+            {
+                unsigned pos = wavePrefix((unsigned)__popcll(sm), nA);
+                if (sm != 0ull) {
+                    while (pos < (unsigned)TPT_DEAL_CA && sm != 0ull) { // the entries that fit; the rest stay in the mask for the next round
+                        TPT_DEAL_TRIP(101);
+                        const int k = __builtin_clzll(sm);
+                        sm &= ~(0x8000000000000000ull >> k);
+                        A[pos] = ((unsigned)p << 16) | (unsigned)(sc0 * 2 + k);
+                        ++pos;
+                    }
+                    if (!parked) { // (o and d do not change during the call; the key is kept current by the atomics)
+                        st[p] = mk4(u2f((uint32_t)id), hitT, o.x, o.y); // {key lo = sphere id, key hi = t bits, o.x, o.y}
+                        st[PATHS + p] = mk4(o.z, d.x, d.y, d.z);
+                        parked = true;
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
             TPT_DEAL_T(tR_);
             TPT_DEAL_ADD(104, t2_, tR_);
-            unsigned nA = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cntA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
             nA = nA < (unsigned)TPT_DEAL_CA ? nA : (unsigned)TPT_DEAL_CA;
             // ---- B: lane j takes (path, super-group) entry j
             for (unsigned a0 = 0; a0 < nA; a0 += 64u) {
@@ -917,46 +929,38 @@ __device__ __forceinline__ void dealThreeStage(const SceneView& sv, const float*
                     c8 = ~m & 0xffu; // bit 7 = the super-group's first group
                 }
                 __builtin_amdgcn_wave_barrier();
-                if (c8) {
-                    unsigned pos = atomicAdd(cntB, (unsigned)__popc(c8));
-                    while (c8) {
-                        TPT_DEAL_TRIP(102);
-                        const int b = __builtin_ctz(c8);
-                        c8 &= c8 - 1u;
-                        const int g = sg * TPT_SUPER + 7 - b;
-                        if (pos < (unsigned)TPT_DEAL_CB)
-                            B[pos] = ((unsigned)po << 16) | (unsigned)g;
-                        else
-                            dealPairInPlace<PATHS>(sv, po, g, st);
-                        ++pos;
-                    }
+                unsigned nNew;
+                unsigned pos = nB + wavePrefix((unsigned)__popc(c8), nNew);
+                while (c8) {
+                    TPT_DEAL_TRIP(102);
+                    const int b = __builtin_ctz(c8);
+                    c8 &= c8 - 1u;
+                    const int g = sg * TPT_SUPER + 7 - b;
+                    if (pos < (unsigned)TPT_DEAL_CB)
+                        B[pos] = ((unsigned)po << 16) | (unsigned)g;
+                    else
+                        dealPairInPlace<PATHS>(sv, po, g, st);
+                    ++pos;
                 }
                 __builtin_amdgcn_wave_barrier();
-                const unsigned counted = (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cntB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-                nB = counted < (unsigned)TPT_DEAL_CB ? counted : (unsigned)TPT_DEAL_CB;
+                nB += nNew;
+                nB = nB < (unsigned)TPT_DEAL_CB ? nB : (unsigned)TPT_DEAL_CB;
                 TPT_DEAL_T(t3_);
                 TPT_DEAL_ADD(92, tS_, t3_);
-                if (nB >= 64u || counted > (unsigned)TPT_DEAL_CB) {
-                    // ---- C: member passes while 64 (path, group) entries are waiting
-                    while (nB >= 64u) {
-                        nB -= 64u;
-                        dealMemberPass<PATHS>(sv, B, nB, 64u, S, cntS, pendS, st, lane);
-                    }
-                    if (lane == 0) *cntB = nB;
+                // ---- C: member passes while 64 (path, group) entries are waiting
+                while (nB >= 64u) {
+                    nB -= 64u;
+                    dealMemberPass<PATHS>(sv, B, nB, 64u, S, pendS, st, lane);
                 }
                 __builtin_amdgcn_wave_barrier();
             }
         }
     }
     // what is still waiting: one partial member pass, one partial exact pass (both stacks are empty again for the next call)
-    if (nB != 0u) {
-        dealMemberPass<PATHS>(sv, B, 0u, nB, S, cntS, pendS, st, lane);
-        if (lane == 0) *cntB = 0u;
-    }
+    if (nB != 0u) dealMemberPass<PATHS>(sv, B, 0u, nB, S, pendS, st, lane);
     if (pendS != 0u) {
         TPT_DEAL_T(tD_);
         dealExactPass<PATHS>(sv, S, 0u, pendS, st, lane);
-        if (lane == 0) *cntS = 0u;
         TPT_DEAL_T(tE_);
         TPT_DEAL_ADD(94, tD_, tE_);
     }

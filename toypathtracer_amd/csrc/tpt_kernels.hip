@@ -431,9 +431,9 @@ __device__ __forceinline__ f4 mk4(float x, float y, float z, float w)
 #define TPT_PRAGMA_STR(x) _Pragma(#x)
 #define TPT_PRAGMA_UNROLL(n) TPT_PRAGMA_STR(unroll n)
 #ifndef TPT_GROUP_DEAL_CAP
-// pair-list entries per wave and round (a multiple of 64).  A wave's 64 rays touch ~130 groups per 256 on the 4096-sphere scene, with a
-// long tail: a list that overflows costs another round of the whole dealing.  448 entries with 720 paths per workgroup beat 192 with
-// 816 by 11 % (sweep 128 ... 640: profiles/r06/r06_run14-16.log); longer lists take the LDS from the path pool and lose again.
+// pair-list entries per wave and round of the FLAT variants (hitSpheres 3 / 4: one (path, group) list filled by the owners, a multiple
+// of 64).  The sweeps that chose 448 (128 ... 640 entries against the path pool they leave: profiles/r06/r06_run14-16.log, r06_run26.log)
+// were made while the default traversal used this list too; it deals in three stages now (TPT_DEAL_CA / CB / CS below).
 #define TPT_GROUP_DEAL_CAP 448
 #endif
 // The three-stage dealing (dealThreeStage) cuts the wave's list area into (path, super-group) entries of a round, the stack of (path,
@@ -459,9 +459,10 @@ static_assert(TPT_GROUP_DEAL_ENTRIES >= TPT_GROUP_DEAL_CAP, "the flat variants' 
 #define TPT_Q_PATHS (TPT_MATRIX_FILTER ? 952 : TPT_Q_P)
 #endif
 #ifndef TPT_Q_PATHS_GROUPED
-// ... and of the instantiation for GROUPED scenes (no scene staging, no matrix-filter table): 720.  The LDS the smaller pool frees holds
-// the longer pair lists of the dealing (TPT_GROUP_DEAL_CAP) and the groups' bounding spheres (pair records, 16 B per group, for up to
-// TPT_Q_GROUP_LDS_BYTES: the second level of the bounds filter reads them per lane, and from L2 that loop would be latency-bound)
+// ... and of the instantiation for GROUPED scenes (no scene staging, no matrix-filter table): 608.  The LDS the smaller pool frees holds
+// the entry areas of the three-stage dealing (640 entries per wave) and the groups' bounding spheres (pair records, 144 B per super-group
+// of 8 groups, for up to TPT_Q_GROUP_LDS_BYTES: stage B reads them per lane, and from L2 that stage would be latency-bound).  624 ... 752
+// paths measured within 1 % of each other (profiles/r06/r06_run26.log).
 #define TPT_Q_PATHS_GROUPED 608
 #endif
 // The groups' pair records in LDS: a super-group's four records (128 B) are read per lane by lanes that hold DIFFERENT super-groups. At a
@@ -574,17 +575,17 @@ __device__ __forceinline__ int qPop(LdsRing q, unsigned* head, unsigned* tail, i
 
 #if TPT_GROUP_DEAL
 // HitWorld over a GROUPED scene for a whole wave (every lane calls it; lanes without a ray pass go = false): the same tests
-// as tpt_trace.h's hitSpheresGrouped -- big spheres exactly, the groups' bounding spheres through the wave-uniform packed filter,
-// the members of every touched group through the per-member filter, the reference's exact test (Maths.cpp:171-190) for what
-// passes, lowest original index among equal t -- but the (ray, group) pairs are dealt out evenly over the lanes instead of every
-// lane walking its own ray's groups (on the 4096-sphere scene a ray touches 4.0 groups, the busiest lane of a wave 10.5):
-//   * a lane whose ray touches k groups reserves k entries of the wave's pair list with one LDS atomic and writes
-//     (its path id << 16 | group) pairs; its ray {o, d} and its best hit so far -- the 64-bit key (t bits << 32 | sphere id) --
-//     are parked in planes 0 / 1 of its own path record, which are dead while this wave holds the path;
-//   * lane j takes entry j (rounds of 64): reads the ray, filters the group's members, runs the exact test on what passes and merges
-//     its best hit into the owner's key with ds_min_u64: smaller t wins, equal t: the lower ORIGINAL sphere index -- the
-//     reference's first-strictly-less rule made explicit (t > tMin > 0: the bit patterns order like the values);
-//   * pairs that do not fit the list (TPT_GROUP_DEAL_CAP per round) stay in their lane's mask for the next round.
+// as tpt_trace.h's hitSpheresGrouped -- big spheres exactly, the super-groups' and groups' bounding spheres through the packed
+// conservative filter, the members of every touched group through the per-member filter, the reference's exact test
+// (Maths.cpp:171-190) for what passes, lowest original index among equal t -- but nothing below the first level is done by "the lane
+// that owns the ray": (ray, super-group), (ray, group) and (ray, member) pairs are DEALT OUT evenly over the lanes through entry lists
+// in LDS (dealThreeStage; on the 4096-sphere scene a ray touches 3.5 super-groups, 4.9 groups and 1.3 members, the busiest lane of a
+// wave 8.4, 15.5 and 10.5).  A lane's ray {o, d} and its best hit so far -- the 64-bit key (t bits << 32 | sphere id) -- are parked in
+// planes 0 / 1 of its own path record, which are dead while this wave holds the path; whoever finds a hit merges it into the owner's
+// key with ds_min_u64: smaller t wins, equal t: the lower ORIGINAL sphere index -- the reference's first-strictly-less rule made
+// explicit (t > tMin > 0: the bit patterns order like the values).  The flat variants (hitSpheres 3: one packed filter over all
+// groups; 4, hooks build: the groups' bounds on the matrix cores) deal the (ray, group) pairs only: owners reserve list entries with one
+// LDS atomic, lane j takes entry j, pairs that do not fit the list (TPT_GROUP_DEAL_CAP per round) stay in their lane's mask.
 // One wave, no barrier: a wave's LDS operations execute in order; wave_barrier only pins the compiler.
 // the packed filter of phase1Pair for one pair record read PER LANE (from LDS): two more sign bits shifted into m
 __device__ __forceinline__ void phase1PairLane(const float* rec, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f dz, uint32_t& m)

@@ -37,4 +37,6 @@ for rep in range(2):
     print("  per call (64 lanes): rounds %.2f, sub-rounds of 64 pairs %.2f, pairs %.1f, survivors %.1f, exact passes %.2f; rays per call %.1f" % (
         st[97] / calls, st[95] / calls, st[96] / calls, st[98] / calls, st[100] / calls, rays / calls))
     print("  wave trips per call: stage A entry loop %.2f, stage B entry loop %.2f, survivors' push loop %.2f" % (st[101] / calls, st[102] / calls, st[103] / calls))
+    print("  behind the origin (centre behind, origin outside the bound): %.1f %% of the (ray, super-group) entries, %.1f %% of the (ray, group) candidates they produce" % (
+        100.0 * st[124] / max(st[126], 1), 100.0 * st[125] / max(st[96], 1)))
 api.ShutdownTest()

@@ -630,7 +630,7 @@ __device__ __forceinline__ void groupMasksTwoLevel(const SceneView& sv, const fl
 // ray, gathers) [94] survivors dealt + exact tests; [95] sub-rounds of 64 pairs [96] pairs [97] rounds [98] survivors [99] calls [100] exact passes [101] wave trips of the per-lane super-group loop [102] of the entry-writing loop [103] of the survivors' push loop)
 #if defined(__HIP_DEVICE_COMPILE__) && defined(TPT_STATS) && TPT_STATS >= 2
 #define TPT_DEAL_T(v) TPT_HS_STAMP(v)
-__shared__ unsigned long long g_dealLds[15]; // per-workgroup sums (LDS atomics: global ones made the build 60 x slower), flushed when the workgroup ends
+__shared__ unsigned long long g_dealLds[18]; // per-workgroup sums (LDS atomics: global ones made the build 60 x slower), flushed when the workgroup ends
 #define TPT_DEAL_ADD(slot, a, b) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_dealLds[(slot) - 90], (unsigned long long)((b) - (a))); } while (0)
 #define TPT_DEAL_COUNT(slot, n) do { if ((threadIdx.x & 63) == 0) atomicAdd(&g_dealLds[(slot) - 90], (unsigned long long)(n)); } while (0)
 #define TPT_DEAL_TRIP(slot) do { if (TPT_HS_FIRST()) atomicAdd(&g_dealLds[(slot) - 90], 1ull); } while (0) /* inside divergent loops: the first active lane counts the wave's trip */
@@ -820,8 +820,11 @@ __device__ __forceinline__ void dealMemberPass(const SceneView& sv, LdsList B, u
         const f3 ro = mk3(r0.z, r0.w, r1.x), rd = mk3(r1.y, r1.z, r1.w);
         const f3 dk = mk3(rd.x * TPT_P1_K, rd.y * TPT_P1_K, rd.z * TPT_P1_K);
         TPT_STAT(ST_SPHERELOOP); // profiling build: group visits
+        // (the filter's sign bits shifted in one v_alignbit each, like phase1PairLane: member j ends at bit 7 - j, set = rejected)
+        uint32_t rej = 0;
         TPT_PRAGMA_UNROLL(TPT_MEMBER_UNROLL)
-        for (int j = 0; j < TPT_GROUP; ++j) mm |= (memberFilter(mem[j], ro, dk) ? 1u : 0u) << j;
+        for (int j = 0; j < TPT_GROUP; ++j) rej = alignbit(rej, f2u(memberFilterValue(mem[j], ro, dk)), 31);
+        mm = ~rej & ((1u << TPT_GROUP) - 1u);
     }
     TPT_DEAL_T(tB_);
     TPT_DEAL_ADD(93, tA_, tB_);
@@ -834,7 +837,7 @@ __device__ __forceinline__ void dealMemberPass(const SceneView& sv, LdsList B, u
         int hid = -1;
         while (mm) {
             TPT_DEAL_TRIP(103);
-            const int j = __builtin_ctz(mm);
+            const int j = TPT_GROUP - 1 - __builtin_ctz(mm);
             mm &= mm - 1u;
             if (pos < (unsigned)TPT_DEAL_CS) {
                 S[pos] = ((unsigned)po << 20) | (unsigned)(g * TPT_GROUP + j);
@@ -916,6 +919,9 @@ __device__ __forceinline__ void dealThreeStage(const SceneView& sv, const float*
                 if (have) e = A[a0 + (unsigned)lane];
                 const int po = (int)(e >> 16), sg = (int)(e & 0xffffu);
                 uint32_t c8 = 0;
+#if defined(TPT_STATS) && TPT_STATS >= 2
+                unsigned statSgBehind = 0u, statGBehind = 0u;
+#endif
                 if (have) {
                     const f4 r0 = st[po], r1 = st[PATHS + po];
                     const f3 ro = mk3(r0.z, r0.w, r1.x), rd = mk3(r1.y, r1.z, r1.w);
@@ -928,7 +934,35 @@ __device__ __forceinline__ void dealThreeStage(const SceneView& sv, const float*
 #pragma unroll
                     for (int q = 0; q < TPT_SUPER / 2; ++q) phase1PairLane(rec + q * 8, qx, qy, qz, ex, ey, ez, m);
                     c8 = ~m & 0xffu; // bit 7 = the super-group's first group
+#if defined(TPT_STATS) && TPT_STATS >= 2
+                    // profiling build: how many of these candidates lie wholly BEHIND the ray's origin (centre behind: nb < 0; origin
+                    // outside the bound by a margin: e' > 2^-11 R'^2) -- what a half-line test on top of the line test would take away
+                    {
+                        auto behind = [&](float cx, float cy, float cz, float nsq) {
+                            const float ax = cx - ro.x, ay = cy - ro.y, az = cz - ro.z;
+                            const float nb = fma1(az, gz, fma1(ay, gy, ax * gx));
+                            const float ee = fma1(az, az, fma1(ay, ay, fma1(ax, ax, nsq)));
+                            const float w = fma1(nsq, 0.00049316406f, ee);
+                            return nb < 0.0f && w > 0.0f;
+                        };
+                        const float* sp = sv.spairs + (size_t)(sg >> 1) * 8 + (sg & 1);
+                        statSgBehind = behind(sp[0], sp[2], sp[4], sp[6]) ? 1u : 0u;
+                        for (int q = 0; q < TPT_SUPER / 2; ++q)
+                            for (int h = 0; h < 2; ++h)
+                                if (((c8 >> (7 - (2 * q + h))) & 1u) && behind(rec[q * 8 + h], rec[q * 8 + 2 + h], rec[q * 8 + 4 + h], rec[q * 8 + 6 + h])) statGBehind++;
+                    }
+#endif
                 }
+#if defined(TPT_STATS) && TPT_STATS >= 2
+                {
+                    unsigned t0_, t1_;
+                    (void)wavePrefix(statSgBehind, t0_);
+                    (void)wavePrefix(statGBehind, t1_);
+                    TPT_DEAL_COUNT(105, t0_);
+                    TPT_DEAL_COUNT(106, t1_);
+                    TPT_DEAL_COUNT(107, nA - a0 < 64u ? nA - a0 : 64u);
+                }
+#endif
                 __builtin_amdgcn_wave_barrier();
                 unsigned nNew;
                 unsigned pos = nB + wavePrefix((unsigned)__popc(c8), nNew);
@@ -1193,7 +1227,7 @@ __device__ __forceinline__ void traceQueueBody(const KernelArgs& a)
 #if defined(__HIP_DEVICE_COMPILE__) && defined(TPT_STATS) && TPT_STATS >= 2
     if (tid < 4) g_hsLds[tid] = 0ull;
 #if TPT_GROUP_DEAL
-    if (tid < 15) g_dealLds[tid] = 0ull;
+    if (tid < 18) g_dealLds[tid] = 0ull;
 #endif
 #endif
     for (int i = tid; i < (int)(sizeof(FrameConsts) / 4); i += TPT_Q_T) reinterpret_cast<uint32_t*>(ldsFc)[i] = reinterpret_cast<const uint32_t*>(&a.fc)[i];
@@ -1610,6 +1644,7 @@ __device__ __forceinline__ void traceQueueBody(const KernelArgs& a)
     if (tid < 4) TPT_COUNT(120 + tid, g_hsLds[tid]);
 #if TPT_GROUP_DEAL
     if (tid < 15) TPT_COUNT(90 + tid, g_dealLds[tid]);
+    if (tid >= 15 && tid < 18) TPT_COUNT(124 + tid - 15, g_dealLds[tid]); // (slots 105-110 belong to the wave statistics)
 #endif
 #endif
 #if defined(TPT_STATS)

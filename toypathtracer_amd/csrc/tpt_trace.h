@@ -618,17 +618,18 @@ TPT_HD void testSphereTie(f4 s, int i, f3 o, f3 d, float tMin, float& hitT, int&
         }
     }
 }
-// per-lane version of phase1Pair's conservative filter for one sphere (dk = direction scaled by TPT_P1_K)
-TPT_HD bool memberFilter(f4 s, f3 o, f3 dk)
+// per-lane version of phase1Pair's conservative filter for one sphere (dk = direction scaled by TPT_P1_K): the value whose SIGN BIT
+// decides (clear: the sphere stays a candidate)
+TPT_HD float memberFilterValue(f4 s, f3 o, f3 dk)
 {
     float coX = s.x - o.x;
     float coY = s.y - o.y;
     float coZ = s.z - o.z;
     float nb = fma1(coZ, dk.z, fma1(coY, dk.y, coX * dk.x));
     float e = fma1(coZ, coZ, fma1(coY, coY, fma1(coX, coX, s.w * -1.0000152587890625f))); // S - r^2 (1 + 2^-16); padding: +inf
-    float v = fma1(nb, nb, -e);
-    return (f2u(v) >> 31) == 0u;
+    return fma1(nb, nb, -e);
 }
+TPT_HD bool memberFilter(f4 s, f3 o, f3 dk) { return (f2u(memberFilterValue(s, o, dk)) >> 31) == 0u; }
 // Group bounds are looser than sphere bounds on purpose.  A member the reference accepts lies within
 // sqrt(r^2 + 13 u (S + r^2)) of the ray's line (the reference's own rounding error), and its centre at most a = |c - C|
 // from the group centre C: against R = max(a + r) the squared distance to C overshoots R^2 by up to

@@ -25,6 +25,10 @@ TPT_API int tptTestMatrixFilter(const float* rays, unsigned long long* outMask, 
  * discriminant for every member sphere: violations = (ray, member) pairs with discr > 0 whose group the filter dropped (must be
  * 0); touched = groups kept, exact = members with discr > 0, both summed over the rays.  n host rays ([n][6], unit direction). */
 TPT_API int tptTestGroupFilter(const float* rays, int n, unsigned long long* outViolations, unsigned long long* outTouched, unsigned long long* outExact);
+/* the entry areas of the grouped traversal's three dealt stages (tpt_kernels.hip dealThreeStage: (path, super-group) entries per round,
+ * (path, group) entries waiting, survivors waiting) shrunk at run time: each between 64 and its compiled size; 0, 0, 0 restores them.
+ * With 64-entry areas every overflow path runs (further rounds, entries served in place): same bits, a fraction of the rate. */
+TPT_API int tptTestSetDealCapacities(int superGroupEntries, int groupEntries, int survivorEntries);
 /* profiling builds only (-DTPT_STATS): 128 counters, wave-level entries [i] / lane counts [32+i] of the
  * state machine's blocks (enum ST_* in tpt_trace.h); the shipped build returns an error. */
 TPT_API int tptDebugStats(unsigned long long* out128, int reset);

@@ -321,6 +321,113 @@ void emu_group_matrix_check(const void* spheres, const void* mats, int count, co
         }
     }
 }
+// The two-level packed VALU filter over the groups' bounds in its HALF-LINE form (tpt_trace.h phase1PairT<true>: what the path-queue
+// kernel's three-stage dealing evaluates) against the reference's WHOLE acceptance of every member (Maths.cpp:171-190: positive
+// discriminant and a root beyond tMin): out[0] = accepted (ray, member) pairs whose group or super-group the filter dropped (must be 0),
+// out[1] = groups kept by the half-line form, out[2] = groups kept by the line form, out[3] = accepted pairs, out[4] = groups the
+// half-line form keeps that the line form drops (must be 0: it only ever drops more).
+static void groupHalfCheckRay(const PackedScene& P, f3 o, f3 d, long long* out)
+{
+    {
+        const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+        const float gx = d.x * TPT_PG_K, gy = d.y * TPT_PG_K, gz = d.z * TPT_PG_K;
+        const v2f dx = {gx, gx}, dy = {gy, gy}, dz = {gz, gz};
+        for (int sg = 0; sg < P.nSupers; ++sg) {
+            uint32_t mh = 0, ml = 0;
+            phase1PairT<true>(P.spairs.data() + (size_t)(sg / 2) * 8, ox, oy, oz, dx, dy, dz, mh);
+            phase1PairT<false>(P.spairs.data() + (size_t)(sg / 2) * 8, ox, oy, oz, dx, dy, dz, ml);
+            const bool sgHalf = !((mh >> (1 - (sg & 1))) & 1u), sgLine = !((ml >> (1 - (sg & 1))) & 1u);
+            for (int q = 0; q < TPT_SUPER / 2; ++q) {
+                const float* rec = P.gpairs.data() + ((size_t)sg * (TPT_SUPER / 2) + q) * 8;
+                uint32_t gh = 0, gl = 0;
+                phase1PairT<true>(rec, ox, oy, oz, dx, dy, dz, gh);
+                phase1PairT<false>(rec, ox, oy, oz, dx, dy, dz, gl);
+                for (int hIdx = 0; hIdx < 2; ++hIdx) {
+                    const int g = sg * TPT_SUPER + q * 2 + hIdx;
+                    if (g >= P.nGroups) continue;
+                    const bool keptHalf = sgHalf && !((gh >> (1 - hIdx)) & 1u), keptLine = sgLine && !((gl >> (1 - hIdx)) & 1u);
+                    out[1] += keptHalf;
+                    out[2] += keptLine;
+                    out[4] += keptHalf && !keptLine;
+                    for (int j = 0; j < TPT_GROUP; ++j) {
+                        const f4 s = P.gsph[(size_t)g * TPT_GROUP + j];
+                        const float coX = s.x - o.x, coY = s.y - o.y, coZ = s.z - o.z;
+                        const float nb = coX * d.x + coY * d.y + coZ * d.z;
+                        const float c = coX * coX + coY * coY + coZ * coZ - s.w;
+                        const float discr = nb * nb - c;
+                        if (discr > 0) {
+                            const float sq = tsqrt(discr);
+                            float t = nb - sq;
+                            if (t <= TPT_MIN_T) t = nb + sq;
+                            if (t > TPT_MIN_T) {
+                                out[3]++;
+                                if (!keptHalf) out[0]++;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+void emu_group_half_check(const void* spheres, const void* mats, int count, const float* rays, int nRays, long long* out)
+{
+    std::vector<SpherePOD> S((const SpherePOD*)spheres, (const SpherePOD*)spheres + count);
+    std::vector<MaterialPOD> M((const MaterialPOD*)mats, (const MaterialPOD*)mats + count);
+    PackedScene P;
+    packScene(S, M, P);
+    for (int k = 0; k < 5; ++k) out[k] = 0;
+    for (int i = 0; i < nRays && P.nSuperPairs > 0; ++i)
+        groupHalfCheckRay(P, mk3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]), mk3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]), out);
+}
+// The same check for rays made to sit ON THE EDGE of the half-line rule: origins at (1 + delta) x the bound's radius from the centre of
+// a group's or a super-group's bound (delta from -1e-3 to +1e-2 through 0 and through the rule's own margin 2^-12), directions
+// tangential, a hair to either side of tangential, pointing away, and random.  perBound rays per bound and delta.
+void emu_group_half_adversarial(const void* spheres, const void* mats, int count, unsigned seed, int perBound, long long* out)
+{
+    std::vector<SpherePOD> S((const SpherePOD*)spheres, (const SpherePOD*)spheres + count);
+    std::vector<MaterialPOD> M((const MaterialPOD*)mats, (const MaterialPOD*)mats + count);
+    PackedScene P;
+    packScene(S, M, P);
+    for (int k = 0; k < 5; ++k) out[k] = 0;
+    if (P.nSuperPairs <= 0) return;
+    uint32_t st = seed | 1u;
+    auto rnd = [&]() { st ^= st << 13; st ^= st >> 17; st ^= st << 5; return (double)(st & 0xffffffu) / 16777216.0; };
+    auto unit = [&](double* v) {
+        double n2;
+        do { for (int a = 0; a < 3; ++a) v[a] = 2.0 * rnd() - 1.0; n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2]; } while (n2 > 1.0 || n2 < 1e-4);
+        const double inv = 1.0 / sqrt(n2);
+        for (int a = 0; a < 3; ++a) v[a] *= inv;
+    };
+    const double deltas[] = {-1e-3, -1e-5, -1e-7, 0.0, 1e-7, 1e-5, 1.2e-4, 2.44e-4, 3.7e-4, 4.9e-4, 6e-4, 1e-3, 1e-2};
+    auto sweep = [&](const std::vector<float>& recs, int nBounds, int stride) {
+        for (int b = 0; b < nBounds; b += stride) {
+            const float* rec = recs.data() + (size_t)(b / 2) * 8;
+            const double C[3] = {rec[0 + (b & 1)], rec[2 + (b & 1)], rec[4 + (b & 1)]}, nsq = rec[6 + (b & 1)];
+            if (!(nsq < 0) || !(nsq > -1e30)) continue; // padding / always-a-candidate records
+            const double R = sqrt(-nsq / (1.0 + 1.0 / 4096.0));
+            for (double dl : deltas)
+                for (int k = 0; k < perBound; ++k) {
+                    double u[3], t[3];
+                    unit(u);
+                    unit(t);
+                    const double ut = u[0] * t[0] + u[1] * t[1] + u[2] * t[2];
+                    for (int a = 0; a < 3; ++a) t[a] -= ut * u[a]; // tangential part
+                    const double tn = sqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2]);
+                    if (tn < 1e-3) continue;
+                    const double tilt = (k % 5 == 0) ? 1.0 : (k % 5 == 1) ? 0.0 : (k % 5 == 2) ? 1e-4 : (k % 5 == 3) ? -1e-4 : (2.0 * rnd() - 1.0);
+                    double dd[3], n2 = 0;
+                    for (int a = 0; a < 3; ++a) { dd[a] = t[a] / tn + tilt * u[a]; n2 += dd[a] * dd[a]; }
+                    const double inv = 1.0 / sqrt(n2);
+                    const f3 o = mk3((float)(C[0] + u[0] * R * (1.0 + dl)), (float)(C[1] + u[1] * R * (1.0 + dl)), (float)(C[2] + u[2] * R * (1.0 + dl)));
+                    const f3 d = normalize(mk3((float)(dd[0] * inv), (float)(dd[1] * inv), (float)(dd[2] * inv)));
+                    groupHalfCheckRay(P, o, d, out);
+                }
+        }
+    };
+    sweep(P.gpairs, P.nGroups, P.nGroups > 600 ? 7 : 1);
+    sweep(P.spairs, P.nSupers, 1);
+}
 float emu_sinf(float x) { return tsinf(x); }
 float emu_cosf(float x) { return tcosf(x); }
 float emu_pow5f(float x) { return tpow5f(x); }

@@ -165,6 +165,34 @@ def test_custom_scene_camera_stress(tpt_defaults, oracle):
     assert m2.tobytes() == m.tobytes() and list(em) == [1, 2, 3, 4] and cam2.tobytes() == cam.tobytes()
 
 
+def test_grouped_traversal_with_64_entry_areas_takes_every_overflow_path(tpt_hooks, oracle):
+    """The grouped traversal deals (ray, super-group), (ray, group) and (ray, member) pairs through three entry areas in LDS (256 / 256 / 128
+    entries per wave).  At those sizes a frame almost never overflows them; with 64 entries each (hooks build: tptTestSetDealCapacities)
+    super-group entries spill into further rounds and group entries / survivors that find their stack full are served in place by the lane
+    holding them -- and the frames must stay bit-identical to the oracle's, for the 4096-sphere scene and a dense 1000-sphere one."""
+    from toypathtracer_amd.scenes import STRESS_CAMERA, stress_scene
+    tpt = tpt_hooks
+    w, h, spp = 128, 72, 2
+    cam = oracle.camera(STRESS_CAMERA["look_from"], STRESS_CAMERA["look_at"], (0, 1, 0), STRESS_CAMERA["vfov"], w / h,
+                        STRESS_CAMERA["aperture"], STRESS_CAMERA["focus_dist"])
+    try:
+        for n, grid in ((4096, 64), (1000, 20)):
+            s, m = stress_scene(n, grid)
+            tpt.set_scene(s, m)
+            tpt.set_camera(**STRESS_CAMERA)
+            tpt.set_samples_per_pixel(spp)
+            assert tpt.scene_info()["groups"] > 0
+            ro, bo, pero = oracle_frames(oracle, w, h, spp, 2, spheres=s, mats=m, cam=cam, seed_mode=SEED_PER_PIXEL)
+            for caps in ((64, 64, 64), (64, 256, 128), (256, 64, 64), (0, 0, 0)):
+                tpt.test_set_deal_capacities(*caps)
+                rays, bb, per = gpu_frames(tpt, w, h, 2)
+                assert per == pero and bb.tobytes() == bo.tobytes(), (n, caps)
+    finally:
+        tpt.test_set_deal_capacities(0, 0, 0)
+        tpt.set_scene(None)
+        tpt.set_camera(None)
+
+
 @pytest.mark.parametrize("n", [1, 2, 7, 63, 64, 65, 129])
 def test_sphere_count_edges(tpt_defaults, oracle, n):
     from toypathtracer_amd.scenes import stress_scene

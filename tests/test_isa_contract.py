@@ -108,12 +108,14 @@ def test_register_budget_of_the_queue_kernels(code_object):
     assert head["sgpr_spill_count"] <= 36, head  # round 5: 63 -> 33 (scalars made where they are used: uniformHere)
     assert meta[QUEUE % (1, 1)]["vgpr_count"] <= 120 and meta[QUEUE % (1, 1)]["vgpr_spill_count"] <= 2
     # the grouped-scene kernels hold the dealing state on top: 128 registers since round 5; since round 6 (no matrix-core
-    # path in them) nothing is spilled inside the traversal -- what is left are two binary64 constants of pow5 / sin-cos that LLVM hoists
-    # to the kernel's entry and parks in scratch (4 registers, 2 stores at the entry, 2 loads in the class code)
+    # path in them) nothing is spilled inside the traversal -- what is left are two or three binary64 constants of pow5 / sin-cos that LLVM
+    # hoists to the kernel's entry and parks in scratch (4-6 registers: a store each at the entry, a load each in the class code)
     for batch in (0, 1):
         m = meta[QUEUE % (0, batch)]
-        assert m["vgpr_spill_count"] <= 4 and m["private_segment_fixed_size"] <= 20, m
-        assert count(bodies[QUEUE % (0, batch)], r"scratch_") <= 4, count(bodies[QUEUE % (0, batch)], r"scratch_")
+        assert m["vgpr_spill_count"] <= 6 and m["private_segment_fixed_size"] <= 28, m
+        body = bodies[QUEUE % (0, batch)]
+        assert count(body, r"scratch_") <= 6, count(body, r"scratch_")
+        assert count(body, r"scratch_store") == count(body, r"scratch_load") <= 3  # (dwordx2 each: one per constant)
 
 
 def test_big_spheres_of_a_grouped_scene_come_through_scalar_loads(code_object):

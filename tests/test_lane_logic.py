@@ -315,6 +315,49 @@ def test_group_bound_matrix_filter_keeps_every_group_with_an_accepted_member(emu
     assert out[1] / len(rays) < 40  # (and the filter filters: a few groups per ray, not hundreds)
 
 
+@pytest.mark.parametrize("n,grid", [(4096, 64), (1000, 20), (20000, 160)])
+def test_half_line_bounds_filter_keeps_every_group_with_an_accepted_member(emu, n, grid):
+    """The three-stage dealing drops a group / super-group whose bound lies wholly behind the ray's origin (tpt_trace.h phase1PairT<true>:
+    centre behind, origin outside the bound by a margin) on top of the line test.  Against the reference's whole acceptance of every
+    member (positive discriminant AND a root beyond tMin), for the rays that matter: rays that graze spheres, random rays, and rays that
+    LEAVE a sphere's surface into the hemisphere above it, below it and tangentially (what a bounce or a shadow ray is), also from a
+    hair outside the surface.  No accepted member sits in a dropped group; the half-line form only ever drops more than the line form;
+    and it does drop a good part of what the line form keeps."""
+    import ctypes as C
+    from common import grazing_rays
+    from toypathtracer_amd.scenes import stress_scene
+    s, m = stress_scene(n, grid)
+    rng = np.random.default_rng(23)
+    k = 1200 if n <= 4096 else 250
+    o = np.stack([rng.uniform(-grid / 2, grid / 2, k), rng.uniform(0.0, 8.0, k), rng.uniform(-grid / 2, grid / 2, k)], 1)
+    d = rng.normal(size=(k, 3))
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    # rays leaving the surfaces of random spheres
+    idx = rng.integers(1, n, 3 * k)
+    c = np.stack([s["cx"][idx], s["cy"][idx], s["cz"][idx]], 1).astype(np.float64)
+    r = s["radius"][idx].astype(np.float64)
+    nrm = rng.normal(size=(3 * k, 3))
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    eps = np.repeat(np.array([0.0, 1e-6, 1e-3]), k)[:, None]
+    po = c + nrm * (r[:, None] * (1.0 + eps))
+    dd = rng.normal(size=(3 * k, 3))
+    dd /= np.linalg.norm(dd, axis=1, keepdims=True)
+    leave = np.concatenate([po, dd], 1).astype(np.float32)
+    leave[:, 3:] /= np.linalg.norm(leave[:, 3:], axis=1, keepdims=True)
+    rays = np.concatenate([grazing_rays(s, k, seed=5), np.concatenate([o.astype(np.float32), d], 1), leave], 0).astype(np.float32)
+    out = np.zeros(5, np.int64)
+    emu.emu_group_half_check.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    emu.emu_group_half_check(s.ctypes.data, m.ctypes.data, n, rays.ctypes.data, len(rays), out.ctypes.data)
+    assert out[3] > len(rays) // 4 and out[0] == 0 and out[4] == 0, out
+    assert out[1] < 0.9 * out[2], out  # (it filters: at least a tenth of the line form's groups go)
+    # ... and rays placed on the rule's own edge: origins at (1 + delta) x the radius of a group's / super-group's bound around its centre,
+    # delta from -1e-3 to +1e-2 through 0 and through the rule's margin 2^-12, directions tangential and a hair to either side
+    adv = np.zeros(5, np.int64)
+    emu.emu_group_half_adversarial.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint, C.c_int, C.c_void_p]
+    emu.emu_group_half_adversarial(s.ctypes.data, m.ctypes.data, n, 0x5bd1e995, 10 if n <= 4096 else 5, adv.ctypes.data)
+    assert adv[3] > 3000 and adv[0] == 0 and adv[4] == 0, adv
+
+
 def _queue_frames(emu, s, m, cam, w, h, spp, frames, flags, hs):
     import ctypes as C
     fn = emu.emu_render_queue_classes

@@ -42,7 +42,7 @@ C_ABI_SYMBOLS = [
     "tptDrawDeviceBatch", "tptDrawShardedBatch", "tptGetLookaheadHits", "tptCommGetUniqueId", "tptCommInit", "tptCommInitLoopback", "tptCommInfo", "tptCommDestroy", "tptDrawSharded", "tptSetShardExchangeInterval", "tptShardedFinish", "tptGetLaunchInfo", "tptGetPipelineInfo", "tptGetSceneInfo", "tptSetHostBufferMode", "tptSetHostLookahead", "tptSetStreamBatching", "tptSetTileMirror", "tptGetLastError", "tptGetDeviceName",
 ]
 # include/tpt_test_hooks.h: exported by the second build (libtoypathtracer_hip_hooks.so) only
-HOOK_SYMBOLS = ["tptTestMath", "tptTestMathExhaustive", "tptTestHitSpheres", "tptTestMatrixFilter", "tptTestGroupFilter", "tptDebugStats", "tptDebugChunkOrder"]
+HOOK_SYMBOLS = ["tptTestMath", "tptTestMathExhaustive", "tptTestHitSpheres", "tptTestMatrixFilter", "tptTestGroupFilter", "tptTestSetDealCapacities", "tptDebugStats", "tptDebugChunkOrder"]
 # the reference's own C++ symbols (nm of the compiled Test.cpp), exported for link-level drop-in
 CXX_ABI_SYMBOLS = [
     "_Z14InitializeTestv", "_Z12ShutdownTestv", "_Z10UpdateTestfiiij", "_Z8DrawTestfiiiPfRij",
@@ -82,7 +82,7 @@ def _bind(path, hooks):
     }
     if hooks:
         sigs.update({"tptDebugStats": [p, i], "tptDebugChunkOrder": [p, p, i], "tptTestMath": [i, p, p, p, i], "tptTestMathExhaustive": [i, u, u, p, p],
-                     "tptTestHitSpheres": [i, p, p, p, i], "tptTestMatrixFilter": [p, p, p, p, i], "tptTestGroupFilter": [p, i, p, p, p]})
+                     "tptTestHitSpheres": [i, p, p, p, i], "tptTestMatrixFilter": [p, p, p, p, i], "tptTestGroupFilter": [p, i, p, p, p], "tptTestSetDealCapacities": [i, i, i]})
     for name, args in sigs.items():
         fn = getattr(lib, name)
         fn.argtypes = args
@@ -492,6 +492,11 @@ def test_matrix_filter(rays, hits=False):
     _chk(_hook("tptTestMatrixFilter")(rays.ctypes.data, masks.ctypes.data, ids.ctypes.data if hits else None,
                                             ts.ctypes.data if hits else None, n), "tptTestMatrixFilter")
     return (masks, ids, ts) if hits else masks
+
+
+def test_set_deal_capacities(super_group_entries=0, group_entries=0, survivor_entries=0):
+    """hooks build: run-time sizes of the three entry areas of the grouped traversal (0, 0, 0: the compiled ones)"""
+    _chk(_hook("tptTestSetDealCapacities")(super_group_entries, group_entries, survivor_entries), "tptTestSetDealCapacities")
 
 
 def test_group_filter(rays):

@@ -78,6 +78,7 @@ hipError_t tptLaunchResolve(float* tile, const tpt::f4* frameColour, int nPixels
 hipError_t tptLaunchMathTest(int op, const float* a, const float* b, float* out, int n, hipStream_t stream);
 hipError_t tptLaunchMathExhaustive(int op, unsigned lo, unsigned hi, unsigned long long* nBad, unsigned* firstBad, hipStream_t stream);
 hipError_t tptLaunchMatrixFilterTest(const tpt::KernelArgs& a, const float* rays, unsigned long long* outMask, int* outId, float* outT, int n, hipStream_t stream);
+hipError_t tptSetDealCapacitiesForTest(int ca, int cb, int cs); // (hooks build)
 hipError_t tptLaunchGroupFilterTest(const tpt::KernelArgs& a, const float* rays, int n, int nPad, unsigned long long* out4, hipStream_t stream);
 hipError_t tptLaunchHitTest(const tpt::KernelArgs& a, int hs, const float* rays, int* outId, float* outT, int n, hipStream_t stream);
 int tptReadStats(unsigned long long* out64);  // profiling build (-DTPT_STATS) only, else -1

@@ -148,6 +148,15 @@ int tptTestGroupFilter(const float* rays, int n, unsigned long long* outViolatio
     return 0;
 }
 
+int tptTestSetDealCapacities(int superGroupEntries, int groupEntries, int survivorEntries)
+{
+    if (requireInit()) return -1;
+    if (int rc = tptSynchronize()) return rc; // (no launch in flight may see the sizes change)
+    if (tptSetDealCapacitiesForTest(superGroupEntries, groupEntries, survivorEntries) != hipSuccess)
+        return fail("tptTestSetDealCapacities: each size between 64 and its compiled value, or 0, 0, 0 for the compiled ones");
+    return 0;
+}
+
 int tptTestHitSpheres(int hitSpheres, const float* rays, int* outId, float* outT, int n)
 {
     if (requireInit()) return -1;

@@ -423,6 +423,9 @@ __device__ __forceinline__ f4 mk4(float x, float y, float z, float w)
 #ifndef TPT_GROUP_DEAL_EXACT
 #define TPT_GROUP_DEAL_EXACT 1 // the members that pass the member filter are dealt out again for their exact tests (see hitSpheresGroupedDeal)
 #endif
+#ifndef TPT_DEAL_HALF_LINE
+#define TPT_DEAL_HALF_LINE 1 // the three-stage dealing drops bounds that lie wholly behind the ray's origin (tpt_trace.h phase1PairT<true>); 0: line test only
+#endif
 #ifndef TPT_MEMBER_UNROLL
 #define TPT_MEMBER_UNROLL 8 // member records requested together in the member filter of a (ray, group) pair: all eight (a latency-bound gather from L2; 4: -3 %, profiles/r06/r06_run14.log)
 #endif
@@ -447,6 +450,19 @@ __device__ __forceinline__ f4 mk4(float x, float y, float z, float w)
 #endif
 #ifndef TPT_DEAL_CS
 #define TPT_DEAL_CS 128 // (a member pass leaves 17 survivors on average, 512 at most; fewer than 64 wait when it starts)
+#endif
+// The hooks build can SHRINK the three areas at run time (tptTestSetDealCapacities): the suite renders a grouped scene with 64-entry
+// areas, where super-group entries spill into further rounds and group entries / survivors that find their stack full are served in
+// place -- paths a frame at the shipped sizes almost never takes.  The product build uses the constants.
+#if defined(TPT_TEST_HOOKS)
+__device__ unsigned g_dealCaps[3] = {TPT_DEAL_CA, TPT_DEAL_CB, TPT_DEAL_CS};
+#define TPT_DEAL_CA_RT (g_dealCaps[0])
+#define TPT_DEAL_CB_RT (g_dealCaps[1])
+#define TPT_DEAL_CS_RT (g_dealCaps[2])
+#else
+#define TPT_DEAL_CA_RT ((unsigned)TPT_DEAL_CA)
+#define TPT_DEAL_CB_RT ((unsigned)TPT_DEAL_CB)
+#define TPT_DEAL_CS_RT ((unsigned)TPT_DEAL_CS)
 #endif
 #define TPT_GROUP_DEAL_ENTRIES (TPT_DEAL_CA + TPT_DEAL_CB + TPT_DEAL_CS)
 static_assert(TPT_GROUP_DEAL_ENTRIES >= TPT_GROUP_DEAL_CAP, "the flat variants' pair list lives in the same area");
@@ -588,7 +604,9 @@ __device__ __forceinline__ int qPop(LdsRing q, unsigned* head, unsigned* tail, i
 // LDS atomic, lane j takes entry j, pairs that do not fit the list (TPT_GROUP_DEAL_CAP per round) stay in their lane's mask.
 // One wave, no barrier: a wave's LDS operations execute in order; wave_barrier only pins the compiler.
 // the packed filter of phase1Pair for one pair record read PER LANE (from LDS): two more sign bits shifted into m
-__device__ __forceinline__ void phase1PairLane(const float* rec, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f dz, uint32_t& m)
+// (HALF: the half-line form of tpt_trace.h's phase1PairT -- bounds whose centre is behind the ray's origin, the origin outside them)
+template <bool HALF>
+__device__ __forceinline__ void phase1PairLaneT(const float* rec, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f dz, uint32_t& m)
 {
     const f4 r0 = *reinterpret_cast<const f4*>(rec), r1 = *reinterpret_cast<const f4*>(rec + 4);
     const v2f cx = {r0.x, r0.y}, cy = {r0.z, r0.w}, cz = {r1.x, r1.y}, nsq = {r1.z, r1.w};
@@ -596,19 +614,31 @@ __device__ __forceinline__ void phase1PairLane(const float* rec, v2f ox, v2f oy,
     const v2f nb = fma2(coZ, dz, fma2(coY, dy, coX * dx));
     const v2f e = fma2(coZ, coZ, fma2(coY, coY, fma2(coX, coX, nsq)));
     const v2f discr = fma2(nb, nb, -e);
-    m = alignbit(m, f2u(discr[0]), 31);
-    m = alignbit(m, f2u(discr[1]), 31);
+    if (HALF) {
+        const v2f hc = {-TPT_HALF_C, -TPT_HALF_C};
+        const v2f wn = fma2(nsq, hc, -e);
+        m = alignbit(m, (f2u(nb[0]) & f2u(wn[0])) | f2u(discr[0]), 31);
+        m = alignbit(m, (f2u(nb[1]) & f2u(wn[1])) | f2u(discr[1]), 31);
+    } else {
+        m = alignbit(m, f2u(discr[0]), 31);
+        m = alignbit(m, f2u(discr[1]), 31);
+    }
+}
+__device__ __forceinline__ void phase1PairLane(const float* rec, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f dz, uint32_t& m)
+{
+    phase1PairLaneT<false>(rec, ox, oy, oz, dx, dy, dz, m);
 }
 // The groups' bounds through two levels of the packed filter, for the 256 groups from group pair pb0 on: the super-groups' bounds
 // (TPT_SUPER = 8 consecutive groups each; 16 pair records, wave-uniform scalar loads) first, then per lane the 8 groups (4 pair
 // records at gpairsLane: LDS in the path-queue kernel) of every super-group this lane's ray touches.  Super-group k of the block
 // holds groups pb0 * 2 + 8 k + j: candidate word k / 8, bit 63 - (8 (k % 8) + j).  gpairsLane must be padded to whole super-groups
 // with never-a-candidate records.
+template <bool HALF = false>
 __device__ __forceinline__ void groupMasksTwoLevel(const SceneView& sv, const float* gpairsLane, int pb0, bool go, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f dz,
                                                    uint64_t& cm0, uint64_t& cm1, uint64_t& cm2, uint64_t& cm3)
 {
     const int sp0 = pb0 / TPT_SUPER, leftS = sv.nSuperPairs - sp0; // (a super pair = 2 x TPT_SUPER groups = TPT_SUPER group pairs)
-    uint32_t sm = (uint32_t)(phase1Chunk(pairPtr(sv.spairs + (size_t)sp0 * 8), leftS < 16 ? leftS : 16, ox, oy, oz, dx, dy, dz) >> 32);
+    uint32_t sm = (uint32_t)(phase1ChunkT<HALF>(pairPtr(sv.spairs + (size_t)sp0 * 8), leftS < 16 ? leftS : 16, ox, oy, oz, dx, dy, dz) >> 32);
     if (!go) sm = 0u;
     while (sm) {
         const int k = __builtin_clz(sm);
@@ -616,7 +646,7 @@ __device__ __forceinline__ void groupMasksTwoLevel(const SceneView& sv, const fl
         const float* rec = gpairsLane + (size_t)(pb0 + (TPT_SUPER / 2) * k) * 8;
         uint32_t m = 0;
 #pragma unroll
-        for (int q = 0; q < TPT_SUPER / 2; ++q) phase1PairLane(rec + q * 8, ox, oy, oz, dx, dy, dz, m);
+        for (int q = 0; q < TPT_SUPER / 2; ++q) phase1PairLaneT<HALF>(rec + q * 8, ox, oy, oz, dx, dy, dz, m);
         const uint64_t bits = (uint64_t)(~m & 0xffu) << (56 - 8 * (k & 7));
         const int w = k >> 3;
         cm0 |= w == 0 ? bits : 0ull;
@@ -809,6 +839,7 @@ __device__ __forceinline__ void dealMemberPass(const SceneView& sv, LdsList B, u
     TPT_DEAL_T(tA_);
     TPT_DEAL_COUNT(95, 1);
     TPT_DEAL_COUNT(96, n);
+    const unsigned capS = TPT_DEAL_CS_RT;
     const bool have = (unsigned)lane < n;
     unsigned e = 0;
     if (have) e = B[first + (unsigned)lane];
@@ -839,7 +870,7 @@ __device__ __forceinline__ void dealMemberPass(const SceneView& sv, LdsList B, u
             TPT_DEAL_TRIP(103);
             const int j = TPT_GROUP - 1 - __builtin_ctz(mm);
             mm &= mm - 1u;
-            if (pos < (unsigned)TPT_DEAL_CS) {
+            if (pos < capS) {
                 S[pos] = ((unsigned)po << 20) | (unsigned)(g * TPT_GROUP + j);
             } else { // (the stack is full: this survivor is tested where it was found; the ray is read again -- see dealPairInPlace)
                 TPT_STAT(ST_PHASE2);
@@ -852,7 +883,7 @@ __device__ __forceinline__ void dealMemberPass(const SceneView& sv, LdsList B, u
     }
     __builtin_amdgcn_wave_barrier();
     pendS += nSurv;
-    pendS = pendS < (unsigned)TPT_DEAL_CS ? pendS : (unsigned)TPT_DEAL_CS;
+    pendS = pendS < capS ? pendS : capS;
     while (pendS >= 64u) {
         pendS -= 64u;
         dealExactPass<PATHS>(sv, S, pendS, 64u, st, lane);
@@ -876,12 +907,13 @@ __device__ __forceinline__ void dealThreeStage(const SceneView& sv, const float*
                                                LdsList list, unsigned* cnt, f4* st, int p, int lane, float hitT, int id, bool& parked)
 {
     LdsList A = list, B = list + TPT_DEAL_CA, S = list + TPT_DEAL_CA + TPT_DEAL_CB;
+    const unsigned capA = TPT_DEAL_CA_RT, capB = TPT_DEAL_CB_RT;
     (void)cnt; // (the counters behind the entries serve the flat variants; here every position comes from a prefix sum over the lanes)
     unsigned nB = 0u, pendS = 0u; // entries waiting on B / S (wave-uniform)
     for (int sc0 = 0; sc0 < sv.nSuperPairs; sc0 += 32) {
         const int leftS = sv.nSuperPairs - sc0;
         TPT_DEAL_T(t0_);
-        uint64_t sm = phase1Chunk(pairPtr(sv.spairs + (size_t)sc0 * 8), leftS < 32 ? leftS : 32, ox, oy, oz, dx, dy, dz); // super-group k of the chunk: bit 63 - k
+        uint64_t sm = phase1ChunkT<TPT_DEAL_HALF_LINE != 0>(pairPtr(sv.spairs + (size_t)sc0 * 8), leftS < 32 ? leftS : 32, ox, oy, oz, dx, dy, dz); // super-group k of the chunk: bit 63 - k
         if (!go) sm = 0ull;
         TPT_DEAL_T(t1_);
         TPT_DEAL_ADD(91, t0_, t1_);
@@ -893,7 +925,7 @@ __device__ __forceinline__ void dealThreeStage(const SceneView& sv, const float*
             {
                 unsigned pos = wavePrefix((unsigned)__popcll(sm), nA);
                 if (sm != 0ull) {
-                    while (pos < (unsigned)TPT_DEAL_CA && sm != 0ull) { // the entries that fit; the rest stay in the mask for the next round
+                    while (pos < capA && sm != 0ull) { // the entries that fit; the rest stay in the mask for the next round
                         TPT_DEAL_TRIP(101);
                         const int k = __builtin_clzll(sm);
                         sm &= ~(0x8000000000000000ull >> k);
@@ -910,7 +942,7 @@ __device__ __forceinline__ void dealThreeStage(const SceneView& sv, const float*
             __builtin_amdgcn_wave_barrier();
             TPT_DEAL_T(tR_);
             TPT_DEAL_ADD(104, t2_, tR_);
-            nA = nA < (unsigned)TPT_DEAL_CA ? nA : (unsigned)TPT_DEAL_CA;
+            nA = nA < capA ? nA : capA;
             // ---- B: lane j takes (path, super-group) entry j
             for (unsigned a0 = 0; a0 < nA; a0 += 64u) {
                 TPT_DEAL_T(tS_);
@@ -932,7 +964,7 @@ __device__ __forceinline__ void dealThreeStage(const SceneView& sv, const float*
                     const float* rec = gpairsLane + sg * recStride; // (recStride: floats per super-group -- 32, or TPT_GPAIR_LDS_STRIDE in LDS)
                     uint32_t m = 0;
 #pragma unroll
-                    for (int q = 0; q < TPT_SUPER / 2; ++q) phase1PairLane(rec + q * 8, qx, qy, qz, ex, ey, ez, m);
+                    for (int q = 0; q < TPT_SUPER / 2; ++q) phase1PairLaneT<TPT_DEAL_HALF_LINE != 0>(rec + q * 8, qx, qy, qz, ex, ey, ez, m);
                     c8 = ~m & 0xffu; // bit 7 = the super-group's first group
 #if defined(TPT_STATS) && TPT_STATS >= 2
                     // profiling build: how many of these candidates lie wholly BEHIND the ray's origin (centre behind: nb < 0; origin
@@ -971,7 +1003,7 @@ __device__ __forceinline__ void dealThreeStage(const SceneView& sv, const float*
                     const int b = __builtin_ctz(c8);
                     c8 &= c8 - 1u;
                     const int g = sg * TPT_SUPER + 7 - b;
-                    if (pos < (unsigned)TPT_DEAL_CB)
+                    if (pos < capB)
                         B[pos] = ((unsigned)po << 16) | (unsigned)g;
                     else
                         dealPairInPlace<PATHS>(sv, po, g, st);
@@ -979,7 +1011,7 @@ __device__ __forceinline__ void dealThreeStage(const SceneView& sv, const float*
                 }
                 __builtin_amdgcn_wave_barrier();
                 nB += nNew;
-                nB = nB < (unsigned)TPT_DEAL_CB ? nB : (unsigned)TPT_DEAL_CB;
+                nB = nB < capB ? nB : capB;
                 TPT_DEAL_T(t3_);
                 TPT_DEAL_ADD(92, tS_, t3_);
                 // ---- C: member passes while 64 (path, group) entries are waiting
@@ -1781,7 +1813,7 @@ __global__ void __launch_bounds__(64) tptGroupFilterTestKernel(const KernelArgs 
         o = mk3(rays[i * 6], rays[i * 6 + 1], rays[i * 6 + 2]);
         d = mk3(rays[i * 6 + 3], rays[i * 6 + 4], rays[i * 6 + 5]);
     }
-    unsigned long long bad = 0, kept = 0, exact = 0;
+    unsigned long long bad = 0, kept = 0, exact = 0, keptHalf = 0;
     if (sv.gmxTiles == 0) {
         // no matrix-core table in the scene set (the default): the two-level packed VALU filter of the path-queue kernel, the groups'
         // pair records read per lane from global memory here (the kernel stages them in LDS when they fit)
@@ -1789,15 +1821,20 @@ __global__ void __launch_bounds__(64) tptGroupFilterTestKernel(const KernelArgs 
         const float gx = d.x * TPT_PG_K, gy = d.y * TPT_PG_K, gz = d.z * TPT_PG_K;
         const v2f dx = {gx, gx}, dy = {gy, gy}, dz = {gz, gz};
         for (int pb0 = 0; pb0 < sv.nGroupPairs; pb0 += 128) {
-            uint64_t cm[4] = {0, 0, 0, 0};
-            groupMasksTwoLevel(sv, sv.gpairs, pb0, real, ox, oy, oz, dx, dy, dz, cm[0], cm[1], cm[2], cm[3]);
+            uint64_t cm[4] = {0, 0, 0, 0}, ch[4] = {0, 0, 0, 0};
+            groupMasksTwoLevel<false>(sv, sv.gpairs, pb0, real, ox, oy, oz, dx, dy, dz, cm[0], cm[1], cm[2], cm[3]);
+            // the half-line form the three-stage dealing uses: held against the reference's WHOLE acceptance (Maths.cpp:171-190: a
+            // positive discriminant and a root beyond tMin), and it must be a subset of the line form
+            groupMasksTwoLevel<true>(sv, sv.gpairs, pb0, real, ox, oy, oz, dx, dy, dz, ch[0], ch[1], ch[2], ch[3]);
             if (!real) continue;
             for (int w = 0; w < 4; ++w) {
                 kept += (unsigned long long)__popcll(cm[w]);
+                keptHalf += (unsigned long long)__popcll(ch[w]);
+                if (ch[w] & ~cm[w]) ++bad;
                 for (int q = 0; q < 64; ++q) {
                     const int grp = pb0 * 2 + w * 64 + q;
                     if (grp >= sv.nGroups) break;
-                    const bool keptBit = (cm[w] >> (63 - q)) & 1ull;
+                    const bool keptBit = (cm[w] >> (63 - q)) & 1ull, keptHalfBit = (ch[w] >> (63 - q)) & 1ull;
                     const f4* mem = sv.gsph + (size_t)grp * TPT_GROUP;
                     for (int j = 0; j < TPT_GROUP; ++j) {
                         const f4 s = mem[j];
@@ -1808,6 +1845,10 @@ __global__ void __launch_bounds__(64) tptGroupFilterTestKernel(const KernelArgs 
                         if (discr > 0) {
                             ++exact;
                             if (!keptBit) ++bad;
+                            const float sq = tsqrt(discr);
+                            float t = nb - sq;
+                            if (t <= TPT_MIN_T) t = nb + sq;
+                            if (t > TPT_MIN_T && !keptHalfBit) ++bad; // a hit the reference takes (whatever hitT it holds: tMax = 1e7) in a dropped group
                         }
                     }
                 }
@@ -1816,6 +1857,7 @@ __global__ void __launch_bounds__(64) tptGroupFilterTestKernel(const KernelArgs 
         if (bad) atomicAdd(&out[0], bad);
         atomicAdd(&out[1], kept);
         atomicAdd(&out[2], exact);
+        atomicAdd(&out[3], keptHalf);
         return;
     }
     MatrixRayOps mops;
@@ -1971,6 +2013,18 @@ hipError_t tptLaunchTraceQueue(const KernelArgs& a, bool ldsScene, int blocks, s
     if (e != hipSuccess) return e;
     return hipGetLastError();
 }
+#if defined(TPT_TEST_HOOKS)
+// hooks build: run-time sizes of the three-stage dealing's entry areas (0, 0, 0: the compiled ones); each between 64 and its compiled size
+hipError_t tptSetDealCapacitiesForTest(int ca, int cb, int cs)
+{
+    unsigned v[3] = {TPT_DEAL_CA, TPT_DEAL_CB, TPT_DEAL_CS};
+    if (ca || cb || cs) {
+        if (ca < 64 || ca > TPT_DEAL_CA || cb < 64 || cb > TPT_DEAL_CB || cs < 64 || cs > TPT_DEAL_CS) return hipErrorInvalidValue;
+        v[0] = (unsigned)ca; v[1] = (unsigned)cb; v[2] = (unsigned)cs;
+    }
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_dealCaps), v, sizeof(v));
+}
+#endif
 int tptQueuePathsPerBlock() { return TPT_Q_PATHS; } // (the larger of the two pools: what per-workgroup buffers are sized for)
 // Pair records of the groups' bounds the grouped instantiation keeps in LDS for a scene of nGroups groups: whole super-groups
 // (padded), or 0 when they do not fit the area the smaller path pool leaves (the flat filter runs over all groups then)

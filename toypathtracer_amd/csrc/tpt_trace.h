@@ -219,7 +219,22 @@ TPT_HD v2f fma2(v2f a, v2f b, v2f c)
     return r;
 #endif
 }
-TPT_HD void phase1Pair(PairPtr rec, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f dz, uint32_t& m)
+// HALF: the half-line form for BOUNDS (groups, super-groups: records carrying -R^2 (1 + 2^-12) of a sphere that holds every member
+// sphere; never for the spheres' own records).  The line test above keeps a bound the ray's LINE passes through, wherever: on the
+// 4096-sphere scene a quarter of the candidates it keeps lie wholly behind the ray's origin (profiles/r06/r06_run34.log).  A bound is
+// dropped as well when its centre is behind the origin (nb < 0) AND the origin is outside it by a margin, w = e' + 2^-11 (1.01) nsq > 0
+// with e' = S - R'^2, i.e. S > R'^2 (1 + 2^-11).  Why that is safe: for t >= 0 and nb <= 0 every point of the ray is at least sqrt(S)
+// from the centre (|o + t d - C|^2 = S - 2 t nb + t^2 >= S; a computed nb < 0 whose real value is a rounding error above zero costs
+// 9 u^2 S).  A member the reference accepts at t > tMin > 0 has its hit point within sqrt(r^2 + O(30 u)(S_m + r^2)) of its own
+// centre -- the reference's rounded roots of its rounded discriminant --, hence within a + that of C, whose square exceeds R^2 by at
+// most 26 u (S + R^2)(1 + rho) <= 1 690 u (S + R^2) (rho <= 64: the argument of "Group bounds are looser ..." below) -- so such a
+// point exists only if S (1 - 1 690 u) <= R^2 (1 + 1 690 u), i.e. S <= R^2 (1 + 2^-12.3).  The test asks for S > R^2 (1 + 2^-12)(1 +
+// 2^-11) = R^2 (1 + 2^-10.4): 3.6 x that.  (A member whose centre is ahead while the bound's is behind is covered: the argument is
+// about the hit POINT, which lies inside the bound.  Records of bounds that are "always a candidate" carry -inf: w = -inf, kept.
+// Padding records carry +inf: dropped by the line test.)  In sign bits: dropped = sign(discr) | (sign(nb) & sign(-w)).
+#define TPT_HALF_C 0.00049316406f /* 2^-11 x 1.01 */
+template <bool HALF>
+TPT_HD void phase1PairT(PairPtr rec, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f dz, uint32_t& m)
 {
     v2f cx = {rec[0], rec[1]}, cy = {rec[2], rec[3]}, cz = {rec[4], rec[5]}, nsq = {rec[6], rec[7]};
     v2f coX = cx - ox;
@@ -228,19 +243,31 @@ TPT_HD void phase1Pair(PairPtr rec, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f 
     v2f nb = fma2(coZ, dz, fma2(coY, dy, coX * dx));
     v2f e = fma2(coZ, coZ, fma2(coY, coY, fma2(coX, coX, nsq))); // S - r^2 (1 + 2^-16)
     v2f discr = fma2(nb, nb, -e);
-    m = alignbit(m, f2u(discr[0]), 31); // m = (m << 1) | sign(discr)
-    m = alignbit(m, f2u(discr[1]), 31);
+    if (HALF) {
+        const v2f hc = {-TPT_HALF_C, -TPT_HALF_C};
+        const v2f wn = fma2(nsq, hc, -e); // -w
+        m = alignbit(m, (f2u(nb[0]) & f2u(wn[0])) | f2u(discr[0]), 31);
+        m = alignbit(m, (f2u(nb[1]) & f2u(wn[1])) | f2u(discr[1]), 31);
+    } else {
+        m = alignbit(m, f2u(discr[0]), 31); // m = (m << 1) | sign(discr)
+        m = alignbit(m, f2u(discr[1]), 31);
+    }
 }
+TPT_HD void phase1Pair(PairPtr rec, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f dz, uint32_t& m) { phase1PairT<false>(rec, ox, oy, oz, dx, dy, dz, m); }
 
 // Candidate mask of up to 32 pair records (64 spheres): sphere k of the chunk sits at bit (63 - k).
-TPT_HD uint64_t phase1Chunk(PairPtr rec, int cnt, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f dz)
+template <bool HALF>
+TPT_HD uint64_t phase1ChunkT(PairPtr rec, int cnt, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f dz);
+TPT_HD uint64_t phase1Chunk(PairPtr rec, int cnt, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f dz) { return phase1ChunkT<false>(rec, cnt, ox, oy, oz, dx, dy, dz); }
+template <bool HALF>
+TPT_HD uint64_t phase1ChunkT(PairPtr rec, int cnt, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f dz)
 {
     const int c0 = cnt < 16 ? cnt : 16, c1 = cnt - c0;
     uint32_t m0 = 0, m1 = 0;
 #pragma unroll 4
-    for (int p = 0; p < c0; ++p) phase1Pair(rec + p * 8, ox, oy, oz, dx, dy, dz, m0);
+    for (int p = 0; p < c0; ++p) phase1PairT<HALF>(rec + p * 8, ox, oy, oz, dx, dy, dz, m0);
 #pragma unroll 4
-    for (int p = 0; p < c1; ++p) phase1Pair(rec + (16 + p) * 8, ox, oy, oz, dx, dy, dz, m1);
+    for (int p = 0; p < c1; ++p) phase1PairT<HALF>(rec + (16 + p) * 8, ox, oy, oz, dx, dy, dz, m1);
     // candidates = sign bit clear (value >= +0)
     uint32_t cand0 = ~m0 << (32 - 2 * c0);
     uint32_t cand1 = c1 ? (~m1 << (32 - 2 * c1)) : 0u;

@@ -165,6 +165,29 @@ def test_custom_scene_camera_stress(tpt_defaults, oracle):
     assert m2.tobytes() == m.tobytes() and list(em) == [1, 2, 3, 4] and cam2.tobytes() == cam.tobytes()
 
 
+@pytest.mark.parametrize("view", ["inside", "outside"])
+def test_grouped_cloud_scene_bit_exact(tpt_defaults, oracle, view):
+    """A grouped scene that is not flat: 3000 spheres spread through a cube, eight lights, the camera inside the cloud or outside it --
+    bounds in every direction around the rays, many of them behind the origin (what the half-line test of the bounds drops).  Default
+    kernel, flat filter, no groups, lane-refill kernel: the oracle's bits."""
+    from toypathtracer_amd.scenes import CLOUD_CAMERA_INSIDE, CLOUD_CAMERA_OUTSIDE, cloud_scene
+    tpt = tpt_defaults
+    s, m = cloud_scene(3000, 12.0, 7)
+    camera = CLOUD_CAMERA_INSIDE if view == "inside" else CLOUD_CAMERA_OUTSIDE
+    w, h, spp = 96, 54, 2
+    tpt.set_scene(s, m)
+    tpt.set_camera(**camera)
+    tpt.set_samples_per_pixel(spp)
+    assert tpt.scene_info()["groups"] > 300
+    cam = oracle.camera(camera["look_from"], camera["look_at"], (0, 1, 0), camera["vfov"], w / h, camera["aperture"], camera["focus_dist"])
+    ro, bo, pero = oracle_frames(oracle, w, h, spp, 2, spheres=s, mats=m, cam=cam, seed_mode=SEED_PER_PIXEL)
+    for hs, persist in ((0, 3), (3, 3), (2, 3), (0, 1)):
+        tpt.set_kernel_variant(hs, persist, -1)
+        rays, bb, per = gpu_frames(tpt, w, h, 2)
+        assert per == pero and bb.tobytes() == bo.tobytes(), (view, hs, persist)
+    tpt.set_kernel_variant(0, 3, -1)
+
+
 def test_grouped_traversal_with_64_entry_areas_takes_every_overflow_path(tpt_hooks, oracle):
     """The grouped traversal deals (ray, super-group), (ray, group) and (ray, member) pairs through three entry areas in LDS (256 / 256 / 128
     entries per wave).  At those sizes a frame almost never overflows them; with 64 entries each (hooks build: tptTestSetDealCapacities)

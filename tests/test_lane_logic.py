@@ -315,7 +315,7 @@ def test_group_bound_matrix_filter_keeps_every_group_with_an_accepted_member(emu
     assert out[1] / len(rays) < 40  # (and the filter filters: a few groups per ray, not hundreds)
 
 
-@pytest.mark.parametrize("n,grid", [(4096, 64), (1000, 20), (20000, 160)])
+@pytest.mark.parametrize("n,grid", [(4096, 64), (1000, 20), (20000, 160), (3000, 0), (6000, -1)], ids=["field4096", "field1000", "field20000", "cloud3000", "cloud6000"])
 def test_half_line_bounds_filter_keeps_every_group_with_an_accepted_member(emu, n, grid):
     """The three-stage dealing drops a group / super-group whose bound lies wholly behind the ray's origin (tpt_trace.h phase1PairT<true>:
     centre behind, origin outside the bound by a margin) on top of the line test.  Against the reference's whole acceptance of every
@@ -325,11 +325,15 @@ def test_half_line_bounds_filter_keeps_every_group_with_an_accepted_member(emu, 
     and it does drop a good part of what the line form keeps."""
     import ctypes as C
     from common import grazing_rays
-    from toypathtracer_amd.scenes import stress_scene
-    s, m = stress_scene(n, grid)
+    from toypathtracer_amd.scenes import cloud_scene, stress_scene
+    if grid > 0:
+        s, m = stress_scene(n, grid)
+    else:  # spheres spread through a volume: bounds all around the rays
+        s, m = cloud_scene(n, 12.0 if grid == 0 else 15.0, 7 if grid == 0 else 11)
+        grid = 24 if grid == 0 else 30
     rng = np.random.default_rng(23)
     k = 1200 if n <= 4096 else 250
-    o = np.stack([rng.uniform(-grid / 2, grid / 2, k), rng.uniform(0.0, 8.0, k), rng.uniform(-grid / 2, grid / 2, k)], 1)
+    o = np.stack([rng.uniform(-grid / 2, grid / 2, k), rng.uniform(-8.0 if n in (3000, 6000) else 0.0, 8.0, k), rng.uniform(-grid / 2, grid / 2, k)], 1)
     d = rng.normal(size=(k, 3))
     d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
     # rays leaving the surfaces of random spheres

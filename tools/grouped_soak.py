@@ -16,40 +16,19 @@ import torch  # noqa: E402
 
 from oracle_lib import fnv1a  # noqa: E402
 from toypathtracer_amd import api as tpt  # noqa: E402
-from toypathtracer_amd.api import MATERIAL_DT, SPHERE_DT  # noqa: E402
-from toypathtracer_amd.scenes import STRESS_CAMERA, stress_scene  # noqa: E402
+from toypathtracer_amd.scenes import CLOUD_CAMERA_INSIDE, CLOUD_CAMERA_OUTSIDE, STRESS_CAMERA, cloud_scene, stress_scene  # noqa: E402
 
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 hs = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 only = sys.argv[3] if len(sys.argv) > 3 else ""
 
 
-def cloud(n, extent, seed):
-    rng = np.random.default_rng(seed)
-    s = np.zeros(n, SPHERE_DT)
-    m = np.zeros(n, MATERIAL_DT)
-    s["cx"], s["cy"], s["cz"] = (rng.uniform(-extent, extent, n).astype(np.float32) for _ in range(3))
-    s["radius"] = (0.15 * 4.0 ** rng.uniform(0.0, 1.0, n)).astype(np.float32)  # (a factor of 4: a group whose members are more than 64 radii from its centre is dissolved, and a scene with more than 64 loose spheres is not grouped at all)
-    s["invRadius"] = (np.float32(1.0) / s["radius"]).astype(np.float32)
-    kind = rng.uniform(0, 1, n)
-    m["type"] = np.where(kind < 0.75, 0, np.where(kind < 0.9, 1, 2)).astype(np.int32)  # Lambert / Metal / Dielectric (Test.cpp:36-44)
-    m["albedo"] = rng.uniform(0.1, 0.9, (n, 3)).astype(np.float32)
-    m["roughness"] = rng.uniform(0.0, 0.3, n).astype(np.float32)
-    m["ri"] = np.float32(1.5)
-    for i in range(8):  # eight lights
-        m["type"][i] = 0
-        m["emissive"][i] = (20.0, 18.0, 12.0)
-        s["radius"][i] = 0.8
-        s["invRadius"][i] = np.float32(1.0) / np.float32(0.8)
-    return s, m
-
-
 SCENES = [
     ("field 4096", stress_scene(4096, 64), STRESS_CAMERA, 640, 360, 4),
     ("field 20000", stress_scene(20000, 160), STRESS_CAMERA, 480, 270, 2),
     ("field 1000 dense", stress_scene(1000, 20), STRESS_CAMERA, 480, 270, 4),
-    ("cloud 3000, from inside", cloud(3000, 12.0, 7), dict(look_from=(0.5, 0.3, 0.2), look_at=(4, 1, -3), vfov=70.0, aperture=0.0, focus_dist=5.0), 480, 270, 4),
-    ("cloud 6000, from outside", cloud(6000, 15.0, 11), dict(look_from=(30, 12, 28), look_at=(0, 0, 0), vfov=50.0, aperture=0.05, focus_dist=40.0), 480, 270, 4),
+    ("cloud 3000, from inside", cloud_scene(3000, 12.0, 7), CLOUD_CAMERA_INSIDE, 480, 270, 4),
+    ("cloud 6000, from outside", cloud_scene(6000, 15.0, 11), CLOUD_CAMERA_OUTSIDE, 480, 270, 4),
 ]
 tpt.InitializeTest()
 for name, (s, m), cam, w, h, spp in SCENES:

@@ -58,3 +58,31 @@ def stress_scene(n=4096, grid=64, seed=0x9E3779B9):
 
 
 STRESS_CAMERA = dict(look_from=(0.0, 6.0, 20.0), look_at=(0.0, 0.0, 0.0), vfov=60.0, aperture=0.02, focus_dist=20.0)
+
+
+def cloud_scene(n=3000, extent=12.0, seed=7, lights=8):
+    """N spheres spread through the cube [-extent, extent]^3 (radii 0.15 ... 0.6, three quarters Lambert, the rest metal / glass), the
+    first `lights` of them emissive: a grouped scene with bounds in every direction around the rays -- nothing like the flat field of
+    stress_scene (tests, tools/grouped_soak.py)."""
+    rng = np.random.default_rng(seed)
+    s = np.zeros(n, SPHERE_DT)
+    m = np.zeros(n, MATERIAL_DT)
+    s["cx"], s["cy"], s["cz"] = (rng.uniform(-extent, extent, n).astype(np.float32) for _ in range(3))
+    # (a factor of 4 in radius: a group whose members lie more than 64 radii from its centre is dissolved, and a scene with more than
+    #  64 loose spheres is not grouped at all)
+    s["radius"] = (0.15 * 4.0 ** rng.uniform(0.0, 1.0, n)).astype(np.float32)
+    kind = rng.uniform(0, 1, n)
+    m["type"] = np.where(kind < 0.75, LAMBERT, np.where(kind < 0.9, METAL, DIELECTRIC)).astype(np.int32)
+    m["albedo"] = rng.uniform(0.1, 0.9, (n, 3)).astype(np.float32)
+    m["roughness"] = rng.uniform(0.0, 0.3, n).astype(np.float32)
+    m["ri"] = np.float32(1.5)
+    for i in range(min(lights, n)):
+        m["type"][i] = LAMBERT
+        m["emissive"][i] = (20.0, 18.0, 12.0)
+        s["radius"][i] = 0.8
+    s["invRadius"] = np.float32(1.0) / s["radius"]
+    return s, m
+
+
+CLOUD_CAMERA_INSIDE = dict(look_from=(0.5, 0.3, 0.2), look_at=(4.0, 1.0, -3.0), vfov=70.0, aperture=0.0, focus_dist=5.0)
+CLOUD_CAMERA_OUTSIDE = dict(look_from=(30.0, 12.0, 28.0), look_at=(0.0, 0.0, 0.0), vfov=50.0, aperture=0.05, focus_dist=40.0)

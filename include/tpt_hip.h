@@ -203,7 +203,7 @@ TPT_API int tptCommInfo(int* outRanks, int* outRank, int* outLoopback);
 TPT_API int tptCommDestroy(void);
 TPT_API int tptDrawSharded(float time, int frameCount, int screenWidth, int screenHeight, float* deviceImageOnRoot, unsigned testFlags);
 /* How many consecutive frames tptDrawSharded collects into ONE trace launch + blend + exchange.  0 (default) = automatic: 1 when a
- * rank's tile is 2.4 M samples per frame or more (rows x width x spp) and for animated scenes; 2 / 4 below -- with small tiles the
+ * rank's tile is 2.4 M samples per frame or more (rows x width x spp) and for animated scenes; 2 / 4 / 8 below 2.4 / 1.2 / 0.6 M -- with small tiles the
  * chain behind a frame (trace launch, blend + snapshot, gather, de-interleave: four dispatches beside a machine full of trace
  * workgroups) bounds the frame rate, not the arithmetic.  k = 1..32 = the host's choice.  A frame that is collected is issued when the
  * k-th arrives, when anything it depends on is about to change (every setter, tptUpdate with another size), or when the caller waits

@@ -18,7 +18,7 @@ torch.cuda.synchronize()
 base = None
 for n in [int(v) for v in os.environ.get("TPT_EMU_N", "1,2,4,8").split(",")]:
     api.comm_init_loopback(n, 8)
-    api.set_shard_exchange_interval(int(os.environ.get("TPT_EMU_EVERY", "0")))  # 0: automatic (every 2nd / 4th frame for small tiles), 1: every frame
+    api.set_shard_exchange_interval(int(os.environ.get("TPT_EMU_EVERY", "0")))  # 0: automatic (deferred batches of 2 / 4 / 8 frames for small tiles), 1: frame by frame
     if os.environ.get("TPT_EMU_OV"):
         api.set_frame_overlap(int(os.environ["TPT_EMU_OV"]))
     for f in range(0, warm, batch):

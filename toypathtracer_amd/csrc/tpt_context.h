@@ -220,7 +220,7 @@ struct Context {
         // rate, not the arithmetic.  tptDrawSharded then DEFERS such frames: k consecutive frames of one configuration are
         // issued as one tptDrawShardedBatch (one trace launch, one blend, one exchange) when the k-th arrives, when anything about the
         // configuration is about to change, or when the caller waits (tptShardedFinish, tptSynchronize, tptRayCounterRead).
-        int exchangeEvery = 0;          // 0 = automatic (1 for tiles of >= 2.4 M samples per frame, 2 / 4 below), else the host's choice
+        int exchangeEvery = 0;          // 0 = automatic (1 for tiles of >= 2.4 M samples per frame, 2 / 4 / 8 below), else the host's choice
         int pendCount = 0, pendFirst = 0, pendW = 0, pendH = 0; // frames accepted but not issued yet: [pendFirst, pendFirst + pendCount)
         unsigned pendFlags = 0;
         float pendTime = 0.0f;

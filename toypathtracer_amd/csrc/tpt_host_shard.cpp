@@ -224,7 +224,7 @@ int tptDrawShardedBatch(float time, int frameCount, int nFrames, int w, int h, f
     int every = S.exchangeEvery;
     if (every <= 0) {
         const long long samples = (long long)shardPadRows(h, S.stripeRows, S.nRanks) * w * g.spp;
-        every = (S.nRanks <= 1 || (testFlags & TPT_FLAG_ANIMATE) || samples >= 2400000) ? 1 : (samples >= 1200000 ? 2 : 4);
+        every = (S.nRanks <= 1 || (testFlags & TPT_FLAG_ANIMATE) || samples >= 2400000) ? 1 : (samples >= 1200000 ? 2 : samples >= 600000 ? 4 : 8);
     }
     if (every > kMaxBatch) every = kMaxBatch;
     if (S.pendCount > 0 && !(nFrames == 1 && every > 1 && frameCount == S.pendFirst + S.pendCount && w == S.pendW && h == S.pendH && testFlags == S.pendFlags)) {
@@ -249,7 +249,7 @@ int tptDrawShardedBatch(float time, int frameCount, int nFrames, int w, int h, f
 }
 
 // How many consecutive frames tptDrawSharded collects into one launch + blend + exchange: 0 = automatic (1 for tiles of 2.4 M samples
-// or more and for animated scenes, 2 / 4 below), k = 1..32.  Every rank must choose the same.
+// or more and for animated scenes, 2 / 4 / 8 below 2.4 / 1.2 / 0.6 M), k = 1..32.  Every rank must choose the same.
 int tptSetShardExchangeInterval(int k)
 {
     if (k < 0 || k > kMaxBatch) return fail("tptSetShardExchangeInterval: 0 (automatic) or 1..32 frames");

@@ -423,7 +423,7 @@ def main():
                          "against a committed golden hash (comma list of c2_steady, c3, c5; auto = all three when the headline is the default "
                          "1-GPU configs[1] run, none otherwise; none = skip)")
     ap.add_argument("--hit-spheres", type=int, default=0, help="0 two-phase: matrix-core filter for <= 64 spheres, grouped traversal for >= 256 (default); 1 simple loop; 2 two-phase brute force; 3 as 0 with the flat packed VALU filter everywhere (no matrix cores, no second level over the groups); 4 as 0 with a grouped scene's bounds on the matrix cores (opt-in: not in a time-sliced process, DESIGN.md 2.2)")
-    ap.add_argument("--persistent", type=int, default=3, choices=[1, 3], help="3 path queues (default) 1 persistent waves with lane refill (the fallback kernel)")
+    ap.add_argument("--persistent", type=int, default=3, choices=[0, 1, 3], help="3 path queues (default) 1 persistent waves with lane refill (the fallback kernel) 0 one thread per pixel (the lane-refill kernel with re-filling off: the north_star's shape, for A/B runs)")
     ap.add_argument("--fold", type=int, default=0, help="0 recursive (reference order, default) 1 forward")
     ap.add_argument("--lds-scene", type=int, default=-1)
     ap.add_argument("--batch", type=int, default=1,
@@ -653,7 +653,7 @@ def main():
             "config": {"workload": label, "width": width, "height": height, "spp": spp, "spheres": n_spheres,
                        "seed_mode": "per_pixel", "fold": "forward" if args.fold else "recursive",
                        "hit_spheres": ["two_phase" + ("+groups+two_level_valu_bounds" if n_spheres >= 256 else "+matrix_core_filter" if n_spheres <= 64 else ""), "simple", "two_phase_brute_force", "two_phase_flat_valu_filter",
-                                       "two_phase+groups+matrix_core_bounds"][args.hit_spheres], "kernel": {1: "persistent_waves", 3: "path_queues"}[args.persistent], "frame_overlap": args.overlap, "frames_per_launch": frames_per_launch,
+                                       "two_phase+groups+matrix_core_bounds"][args.hit_spheres], "kernel": {0: "thread_per_pixel", 1: "persistent_waves", 3: "path_queues"}[args.persistent], "frame_overlap": args.overlap, "frames_per_launch": frames_per_launch,
                        "untimed_priming_frames": args.prime,
                        "flags": "progressive|animate" if args.animate else "progressive",
                        "sharding": "none" if world == 1 else "row stripes of %d, round-robin over %d ranks, pipelined gather to rank 0" % (args.stripe_rows, world),
@@ -680,7 +680,7 @@ def main():
                          "achieved_read_plus_write": 2 * hbm_write_gbs * k_ms / pl_ms, "launch_ms_avg": k_ms, "launches": launches,
                          "note": "north_star's HBM-write roofline (W*H*16 B per frame).  The kernel is FP32-VALU bound (arithmetic "
                                  "intensity ~440 flop/B against a machine balance of ~20): see roofline_valu, the binding one",
-                         "kernel": {1: "tptTraceKernel", 3: "tptTraceQueueKernel"}[args.persistent]},
+                         "kernel": {0: "tptTraceKernel", 1: "tptTraceKernel", 3: "tptTraceQueueKernel"}[args.persistent]},
             "roofline_valu": ({"bound": "valu_fp32", "achieved": valu_tflops * k_ms / pl_ms, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
                                "frac": valu_tflops * k_ms / pl_ms / PEAK_FP32_TFLOPS,
                                "achieved_per_launch": valu_tflops, "frac_per_launch": valu_tflops / PEAK_FP32_TFLOPS,

@@ -242,7 +242,10 @@ TPT_API int tptKernelTimingEnd(float* outSumMilliseconds, int* outLaunches);
  * hooks build only (the product library refuses it): in a process the device time-slices (more than ~22 hardware queues, or
  * anything else on the GPU) waves that have run that path lose a hit in ~1e-9 of their rays, and the two-level
  * VALU filter is no slower.  persistent: 3 = path queues in LDS (default; per-pixel seeds, recursive fold, two-phase
- * only -- anything else falls back to 1), 1 = persistent waves with lane refill (any other value selects 3).  ldsScene:
+ * only -- anything else falls back to 1), 1 = persistent waves with lane refill, 0 = ONE THREAD PER PIXEL: the same kernel with re-filling
+ * off -- a wave takes an 8x8 tile and every lane keeps its pixel until the tile is done (the shape of the reference's compute shaders,
+ * ComputeShader.hlsl:353-395, and of BASELINE.json's north_star; with hitSpheres 1 also its brute-force loop): kept as a live A/B,
+ * 4-6 x slower than the default.  ldsScene:
  * 1 = stage sphere records and materials in LDS (default when they fit), 0 = read them from global memory, -1 = auto.
  * All variants produce identical bits. */
 TPT_API int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene);

@@ -16,8 +16,9 @@ using namespace tpt;
 
 namespace {
 // (mirrors of constants that live in tpt_kernels.hip: path records, rings, control block of the path-queue kernel)
-const int kQPaths = 952, kQPathsGrouped = 720, kQRing = 1024, kQClasses = 6, kQThreads = 512, kQWaves = 8;
-const size_t kQCtlBytes = 256, kQDealWaveBytes = 448 * 4 + 16;
+const int kQPaths = 952, kQPathsGrouped = 608, kQRing = 1024, kQClasses = 6, kQThreads = 512, kQWaves = 8;
+const size_t kQCtlBytes = 256, kQDealWaveBytes = (256 + 256 + 128) * 4 + 16; // (entry areas of the three-stage dealing)
+const size_t kQGroupPairStride = 36 * 4, kQGroupLdsBytes = 9808;              // (144 B per super-group of 8 groups in LDS: TPT_GPAIR_LDS_STRIDE)
 
 bool mapItem(const KernelArgs& a, int idx, int& x, int& ly) // tpt_kernels.hip: mapItem
 {
@@ -332,7 +333,7 @@ size_t tptQueueLdsBytes(const KernelArgs& a, bool ldsScene) // = tpt_kernels.hip
     if (ldsScene) bytes += 1024 + ((size_t)nPad * 16 <= 1024 ? 0 : (size_t)nPad * 16) + (((size_t)nPad * 4 + 15) & ~(size_t)15) + (size_t)a.scene.nSpheres * 48;
     bytes += (size_t)a.scene.nLights * 32;
     bytes += (size_t)4 * (ldsScene ? kQPaths : kQPathsGrouped) * 16 + (size_t)kQClasses * kQRing * 2 + kQCtlBytes + ((sizeof(FrameConsts) + 15) & ~(size_t)15);
-    if (!ldsScene) bytes += (size_t)kQWaves * kQDealWaveBytes + (a.ldsGroupPairs > 0 ? 16 + (size_t)a.ldsGroupPairs * 32 : 0);
+    if (!ldsScene) bytes += (size_t)kQWaves * kQDealWaveBytes + (a.ldsGroupPairs > 0 ? 16 + (size_t)(a.ldsGroupPairs / (TPT_SUPER / 2)) * kQGroupPairStride : 0);
     if (ldsScene && a.scene.mxR1 >= 0) bytes += TPT_MXH_TABLE_DWORDS * sizeof(uint32_t) + 64;
     return bytes;
 }
@@ -341,7 +342,7 @@ int tptQueueGroupPairsInLds(int nGroups, int nSuperPairs) // = tpt_kernels.hip
 {
     if (nGroups <= 0 || nSuperPairs <= 0) return 0;
     const int pairs = ((nGroups + TPT_SUPER - 1) / TPT_SUPER) * (TPT_SUPER / 2);
-    return (size_t)pairs * 32 + 16 <= (size_t)8704 ? pairs : 0;
+    return (size_t)(pairs / (TPT_SUPER / 2)) * kQGroupPairStride + 16 <= kQGroupLdsBytes ? pairs : 0;
 }
 int tptQueueMatrixFilter() { return 1; }
 int tptQueueGroupMatrixBounds() { return 1; }

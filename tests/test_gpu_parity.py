@@ -165,6 +165,23 @@ def test_custom_scene_camera_stress(tpt_defaults, oracle):
     assert m2.tobytes() == m.tobytes() and list(em) == [1, 2, 3, 4] and cam2.tobytes() == cam.tobytes()
 
 
+@pytest.mark.parametrize("hs", [1, 3, 0], ids=["brute_force_loop", "valu_filter", "matrix_filter"])
+def test_one_thread_per_pixel_shape_bit_exact(tpt_defaults, oracle, hs):
+    """BASELINE.json's north_star names a kernel shape -- one thread per pixel, scene staged in LDS, no matrix cores -- that the product
+    deliberately does not ship as its default (lanes idle behind their 11-bounce neighbours).  It is kept as an instantiation
+    (tptSetKernelVariant persistent 0: the lane-refill kernel hands out 8x8 tiles and nothing else until the tile is done), so that the A/B
+    stays reproducible: with the reference's brute-force loop over all spheres (hitSpheres 1), the packed VALU filter (3) and the default
+    filter (0).  Same bits as the oracle, whole frames with accumulation."""
+    tpt = tpt_defaults
+    w, h, spp, frames = 328, 180, 4, 3  # (41 tiles across: ragged against nothing, 22.5 tiles down: a half-covered row of tiles)
+    tpt.set_samples_per_pixel(spp)
+    tpt.set_kernel_variant(hs, 0, -1)
+    rays, bb, per = gpu_frames(tpt, w, h, frames)
+    ro, bo, pero = oracle_frames(oracle, w, h, spp, frames, seed_mode=SEED_PER_PIXEL)
+    tpt.set_kernel_variant(0, 3, -1)
+    assert per == pero and bb.tobytes() == bo.tobytes(), hs
+
+
 @pytest.mark.parametrize("view", ["inside", "outside"])
 def test_grouped_cloud_scene_bit_exact(tpt_defaults, oracle, view):
     """A grouped scene that is not flat: 3000 spheres spread through a cube, eight lights, the camera inside the cloud or outside it --

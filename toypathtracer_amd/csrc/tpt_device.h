@@ -33,6 +33,7 @@ struct KernelArgs {
     int batchFrames, chunksPerFrame, framePlane;
     unsigned totalWaves;
     int laneCap;    // lane-refill kernel: lanes of a wave that take work items (64; fewer for row-serial seeds, whose items are whole rows)
+    int noRefill;   // lane-refill kernel: 1 = a wave takes 64 pixels and every lane keeps ITS pixel until all 64 are done (the north_star's one-thread-per-pixel shape, tptSetKernelVariant persistent 0: an A/B instantiation); 0 = idle lanes are re-filled at once
     // FOLD_RECURSIVE bounce stack: the first ldsStackLevels levels live in LDS (per thread), deeper ones in
     // stackBuf [TPT_MAX_DEPTH - ldsStackLevels][stackStride] (global, one column per thread of the launch).
     f4* stackBuf;

@@ -562,8 +562,8 @@ int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene)
     if (hitSpheres == 4 && !tptQueueGroupMatrixBounds())
         return fail("tptSetKernelVariant: hitSpheres 4 (a grouped scene's bounds on the matrix cores) is compiled into the hooks build only "
                     "(libtoypathtracer_hip_hooks.so): waves that have run that path are not safe in a time-sliced process, DESIGN.md 2.2");
-    if (persistent != 1 && persistent != 3)
-        return fail("tptSetKernelVariant: persistent 3 (path queues, the default) or 1 (lane refill); the thread-per-pixel (0) and lane-sorting (2) kernels were removed in round 3");
+    if (persistent != 0 && persistent != 1 && persistent != 3)
+        return fail("tptSetKernelVariant: persistent 3 (path queues, the default), 1 (lane refill) or 0 (one thread per pixel: the lane-refill kernel with re-filling off); the lane-sorting kernel (2) was removed in round 3");
     g.hs = hitSpheres == 1 ? HS_SIMPLE : HS_TWO_PHASE;
     const int allow = hitSpheres == 2 ? 0 : 1, matrix = hitSpheres == 3 ? 0 : 1; // 3: the packed VALU filter everywhere (no matrix-core table)
     const int groupMatrix = hitSpheres == 4 ? 1 : 0; // 4: as 0, and the bounds of a GROUPED scene on the matrix cores too (opt-in)
@@ -573,7 +573,7 @@ int tptSetKernelVariant(int hitSpheres, int persistent, int ldsScene)
         g.groupMatrix = groupMatrix;
         g.sceneDirty = true; // the staged scene set carries (or not) the grouped arrays / the matrix table
     }
-    g.persist = persistent; // 3 = path queues (default), 1 = lane-refill kernel
+    g.persist = persistent; // 3 = path queues (default), 1 = lane-refill kernel, 0 = the same kernel with re-filling off (one thread per pixel: the north_star's shape, kept for A/B runs)
     g.configEpoch++;
     g.ldsScene = ldsScene < 0 ? -1 : (ldsScene ? 1 : 0);
     return 0;

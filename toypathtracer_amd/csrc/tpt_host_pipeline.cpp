@@ -181,6 +181,7 @@ void sizeGrid(FramePlan& P)
     a.numChunks *= P.batch; // a batched launch hands out the chunks of all its frames, frame after frame
     int blocks = (a.numChunks + wavesPerBlock - 1) / wavesPerBlock;
     a.laneCap = 64;
+    a.noRefill = (g.persist == 0 && !P.rowSerial && !P.queued) ? 1 : 0; // (one thread per pixel: tptSetKernelVariant persistent 0)
     if (P.rowSerial && !P.queued) {
         // Row-serial seeds: a work item is a whole image row (thousands of sequential rays), and there are few of them -- rows x
         // frames of the batch.  A wave that fills all 64 lanes leaves most SIMDs idle; a SIMD runs one wave's instructions at

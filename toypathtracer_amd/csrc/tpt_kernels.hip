@@ -278,6 +278,9 @@ tptTraceKernel(const KernelArgs a)
         bool noMoreWork = false;
         for (;;) {
             bool need = !L.active && lane < a.laneCap; // (laneCap < 64: few, long work items -- spread them over more waves)
+            // one thread per pixel (persistent 0, the north_star's shape): nothing is handed out while any lane of the wave still works
+            // on the pixel it was given -- a lane whose path ended after one ray waits for its 11-bounce neighbour
+            if (a.noRefill && __ballot(L.active) != 0ull) need = false;
             for (;;) {
                 unsigned long long needMask = __ballot(need);
                 if (needMask == 0ull) break;

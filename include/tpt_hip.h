@@ -262,6 +262,13 @@ TPT_API int tptGetLaunchInfo(int* outBlocksPerCU, int* outLdsBytes, int* outGrid
  * buffers were (re-)allocated (once per frame shape; never on the steady-state path). */
 TPT_API int tptGetPipelineInfo(int* outHwQueues, int* outOverlapEffective, int* outStreamDepth, int* outSlotReservations);
 TPT_API const char* tptGetLastError(void);
+/* The reference's six functions (include/tpt_test_api.h == Test.h:10-17) return void: when one of them fails -- no GPU, a HIP error, DrawTest
+ * before UpdateTest -- the library by default prints the message and abort()s (there is no CPU path to fall back to; a frame that silently
+ * was not rendered is worse than a stop).  A host that wants to decide itself installs a handler: it is called on the calling thread with
+ * the entry point's name and the message, and the failed call then RETURNS without effect (DrawTest leaves the buffer alone and reports 0
+ * rays).  NULL restores the default.  The tpt* functions never abort: they return a negative code. */
+typedef void (*tptErrorHandler)(const char* where, const char* message);
+TPT_API int tptSetErrorHandler(tptErrorHandler handler);
 TPT_API const char* tptGetDeviceName(void);
 
 #ifdef __cplusplus

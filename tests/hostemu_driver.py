@@ -346,6 +346,22 @@ def errors_and_reinitialisation():
         raise AssertionError("draw before update was accepted")
     except tpt.TptError:
         pass
+    # the reference's own void DrawTest (Test.h:14) has no error channel: with a handler installed (tptSetErrorHandler) the failure is
+    # handed to it and the call returns without effect -- without one the library would print and abort()
+    seen = []
+    tpt.set_error_handler(lambda where, msg: seen.append((where, msg)))
+    try:
+        lib = tpt.load_library()
+        fn = getattr(lib, "_Z8DrawTestfiiiPfRij")
+        fn.restype = None
+        fn.argtypes = [C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_uint]
+        rays = C.c_int(123)
+        before = tile.copy()
+        fn(0.0, 0, W, H, ptr(tile), C.byref(rays), FLAG_PROGRESSIVE)
+        assert len(seen) == 1 and seen[0][0] == b"DrawTest" and b"tptUpdate" in seen[0][1], seen
+        assert rays.value == 0 and tile.tobytes() == before.tobytes()
+    finally:
+        tpt.set_error_handler(None)
     streaming(frames=3)
 
 

@@ -39,7 +39,7 @@ C_ABI_SYMBOLS = [
     "tptSetSamplesPerPixel", "tptSetConfig", "tptSetSeedMode", "tptSetFoldMode", "tptSetScene", "tptSetCamera", "tptSetStream",
     "tptSetRowShard", "tptLocalRowCount", "tptLocalRowToGlobal", "tptDrawDevice", "tptRayCounterRead", "tptSetRayCounter", "tptSetFrameOverlap", "tptDisplayRGBA8", "tptKernelTimingBegin", "tptKernelTimingEnd",
     "tptSynchronize", "tptTimerBegin", "tptTimerEnd", "tptSetKernelVariant",
-    "tptDrawDeviceBatch", "tptDrawShardedBatch", "tptGetLookaheadHits", "tptCommGetUniqueId", "tptCommInit", "tptCommInitLoopback", "tptCommInfo", "tptCommDestroy", "tptDrawSharded", "tptSetShardExchangeInterval", "tptShardedFinish", "tptGetLaunchInfo", "tptGetPipelineInfo", "tptGetSceneInfo", "tptSetHostBufferMode", "tptSetHostLookahead", "tptSetStreamBatching", "tptSetTileMirror", "tptGetLastError", "tptGetDeviceName",
+    "tptDrawDeviceBatch", "tptDrawShardedBatch", "tptGetLookaheadHits", "tptCommGetUniqueId", "tptCommInit", "tptCommInitLoopback", "tptCommInfo", "tptCommDestroy", "tptDrawSharded", "tptSetShardExchangeInterval", "tptShardedFinish", "tptGetLaunchInfo", "tptGetPipelineInfo", "tptGetSceneInfo", "tptSetHostBufferMode", "tptSetHostLookahead", "tptSetStreamBatching", "tptSetTileMirror", "tptGetLastError", "tptSetErrorHandler", "tptGetDeviceName",
 ]
 # include/tpt_test_hooks.h: exported by the second build (libtoypathtracer_hip_hooks.so) only
 HOOK_SYMBOLS = ["tptTestMath", "tptTestMathExhaustive", "tptTestHitSpheres", "tptTestMatrixFilter", "tptTestGroupFilter", "tptTestSetDealCapacities", "tptDebugStats", "tptDebugChunkOrder"]
@@ -232,6 +232,21 @@ def set_seed_mode(mode):
 
 def set_fold_mode(mode):
     _chk(load_library().tptSetFoldMode(mode), "tptSetFoldMode")
+
+
+ERROR_HANDLER = C.CFUNCTYPE(None, C.c_char_p, C.c_char_p)
+_error_handler_keepalive = None
+
+
+def set_error_handler(fn):
+    """tptSetErrorHandler: fn(where: bytes, message: bytes) is called when one of the reference's void functions fails, instead of
+    abort(); None restores the default."""
+    global _error_handler_keepalive
+    cb = ERROR_HANDLER(fn) if fn is not None else C.cast(None, ERROR_HANDLER)
+    lib = load_library()
+    lib.tptSetErrorHandler.argtypes = [ERROR_HANDLER]
+    _chk(lib.tptSetErrorHandler(cb), "tptSetErrorHandler")
+    _error_handler_keepalive = cb
 
 
 def set_kernel_variant(hit_spheres=0, persistent=3, lds_scene=-1):

@@ -728,13 +728,25 @@ int tptGetLaunchInfo(int* outBlocksPerCU, int* outLdsBytes, int* outGridBlocks, 
 // Same names, signatures and C++ linkage, so `nm` shows the very symbols Test.cpp exports
 // (_Z14InitializeTestv, _Z12ShutdownTestv, _Z10UpdateTestfiiij, _Z8DrawTestfiiiPfRij,
 // _Z14GetObjectCountRiS_S_S_, _Z12GetSceneDescPvS_S_S_Pi).  The reference functions return void and
-// have no error channel: a HIP failure is reported on stderr and the process aborts.
-static void dieOn(int rc, const char* where)
+// have no error channel: by default a failure is reported on stderr and the process aborts -- there is no CPU path to fall back to, and
+// a frame that silently was not rendered is worse than a stop.  A host that wants to decide itself installs a handler
+// (tptSetErrorHandler): it is called with the entry point's name and tptGetLastError()'s text, and the call then RETURNS without
+// having rendered (DrawTest leaves the buffer alone and reports 0 rays).
+static tptErrorHandler g_errorHandler = nullptr;
+extern "C" int tptSetErrorHandler(tptErrorHandler handler)
 {
-    if (rc) {
-        fprintf(stderr, "toypathtracer_hip: %s failed: %s\n", where, tptGetLastError());
-        abort();
+    g_errorHandler = handler;
+    return 0;
+}
+static bool dieOn(int rc, const char* where)
+{
+    if (!rc) return false;
+    if (g_errorHandler) {
+        g_errorHandler(where, tptGetLastError());
+        return true;
     }
+    fprintf(stderr, "toypathtracer_hip: %s failed: %s\n", where, tptGetLastError());
+    abort();
 }
 void InitializeTest() { dieOn(tptInitialize(), "InitializeTest"); }
 void ShutdownTest() { dieOn(tptShutdown(), "ShutdownTest"); }
@@ -744,7 +756,7 @@ void UpdateTest(float time, int frameCount, int screenWidth, int screenHeight, u
 }
 void DrawTest(float time, int frameCount, int screenWidth, int screenHeight, float* backbuffer, int& outRayCount, unsigned testFlags)
 {
-    dieOn(tptDraw(time, frameCount, screenWidth, screenHeight, backbuffer, &outRayCount, testFlags), "DrawTest");
+    if (dieOn(tptDraw(time, frameCount, screenWidth, screenHeight, backbuffer, &outRayCount, testFlags), "DrawTest")) outRayCount = 0;
 }
 void GetObjectCount(int& outCount, int& outObjectSize, int& outMaterialSize, int& outCamSize)
 {

@@ -18,7 +18,7 @@ namespace {
 // (mirrors of constants that live in tpt_kernels.hip: path records, rings, control block of the path-queue kernel)
 const int kQPaths = 952, kQPathsGrouped = 608, kQRing = 1024, kQClasses = 6, kQThreads = 512, kQWaves = 8;
 const size_t kQCtlBytes = 256, kQDealWaveBytes = (256 + 256 + 128) * 4 + 16; // (entry areas of the three-stage dealing)
-const size_t kQGroupPairStride = 36 * 4, kQGroupLdsBytes = 9808;              // (144 B per super-group of 8 groups in LDS: TPT_GPAIR_LDS_STRIDE)
+const size_t kQGroupPairStride = ((TPT_SUPER / 2) * 8 + 4) * 4, kQGroupLdsBytes = 9808; // (144 B per super-group of 8 groups in LDS: TPT_GPAIR_LDS_STRIDE)
 
 bool mapItem(const KernelArgs& a, int idx, int& x, int& ly) // tpt_kernels.hip: mapItem
 {

@@ -745,7 +745,7 @@ def test_matrix_filter_hits_equal_the_exact_loop_on_grazing_rays(tpt_hooks, orac
 @pytest.mark.parametrize("variant", [0, 4], ids=["two_level_valu", "matrix_cores"])
 def test_group_bounds_filters_on_the_device(tpt_hooks, variant):
     """Grouped scenes: the groups' bounding spheres go through the two-level packed VALU filter (super-groups of 8 groups, then
-    the groups: groupMasksTwoLevel, the default) or, opt-in, through the matrix-core filter with doubled slack (buildGroupMatrixTable).
+    the groups: what the path-queue kernel's three-stage dealing evaluates, in its line form and its half-line form, the default) or, opt-in, through the matrix-core filter with doubled slack (buildGroupMatrixTable).
     On the device, against the reference's discriminant of EVERY member sphere (Maths.cpp:171-178): for 400 000 rays that graze
     spheres within 1e-8 .. 1e-3 radii plus random ones, no member the reference accepts sits in a group the filter dropped --
     4096 spheres (512 groups, 64 super-groups) and 20 000 (2500 groups)."""

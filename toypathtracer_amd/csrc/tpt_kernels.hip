@@ -446,10 +446,10 @@ __device__ __forceinline__ f4 mk4(float x, float y, float z, float w)
 // group) entries waiting for a member pass and the stack of survivors waiting for an exact pass; the flat / matrix-core variants use the
 // first TPT_GROUP_DEAL_CAP entries as one pair list.  Four counters behind the entries.
 #ifndef TPT_DEAL_CA
-#define TPT_DEAL_CA 256
+#define TPT_DEAL_CA (TPT_SUPER == 8 ? 256 : 192)
 #endif
 #ifndef TPT_DEAL_CB
-#define TPT_DEAL_CB 256 // (a sub-round of 64 super-group entries leaves 93 group entries on average, 512 at most; fewer than 64 wait when it starts)
+#define TPT_DEAL_CB (TPT_SUPER == 8 ? 256 : 320) // (a sub-round of 64 super-group entries leaves ~90 group entries on average -- more with super-groups of 16 --, 64 x TPT_SUPER at most; fewer than 64 wait when it starts)
 #endif
 #ifndef TPT_DEAL_CS
 #define TPT_DEAL_CS 128 // (a member pass leaves 17 survivors on average, 512 at most; fewer than 64 wait when it starts)
@@ -488,8 +488,8 @@ static_assert(TPT_GROUP_DEAL_ENTRIES >= TPT_GROUP_DEAL_CAP, "the flat variants' 
 // stride of 128 B every lane's read of "record q, half h" lands on one of two 16-byte bank groups of the 16 -- an 8-way conflict on
 // every read (68 % of the LDS's active cycles were conflict cycles, profiles/r06/r06_run30.log).  Nine bank groups per super-group
 // (144 B: 16 B of padding) spread consecutive super-groups over all sixteen.
-#define TPT_GPAIR_LDS_STRIDE 36 /* floats per super-group in LDS (32 of data) */
-static_assert((TPT_SUPER / 2) * 8 == 32, "the padded LDS layout of the groups' pair records is written for super-groups of 8 groups");
+#define TPT_GPAIR_FLOATS ((TPT_SUPER / 2) * 8) /* floats of a super-group's pair records: 32 (64 for super-groups of 16) */
+#define TPT_GPAIR_LDS_STRIDE (TPT_GPAIR_FLOATS + 4) /* floats per super-group in LDS: 9 (17) bank groups of 16 bytes */
 #define TPT_Q_GROUP_LDS_BYTES 9808 /* group pair records in LDS at most: 68 super-groups x 144 B + 16 (a launch that would lose its second workgroup per CU to them reads them from global memory instead: chooseKernel) */
 #ifndef TPT_Q_FUSE_MIN
 #define TPT_Q_FUSE_MIN 48 // a batch intersects its own rays when at least this many lanes still hold one
@@ -630,33 +630,6 @@ __device__ __forceinline__ void phase1PairLaneT(const float* rec, v2f ox, v2f oy
 __device__ __forceinline__ void phase1PairLane(const float* rec, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f dz, uint32_t& m)
 {
     phase1PairLaneT<false>(rec, ox, oy, oz, dx, dy, dz, m);
-}
-// The groups' bounds through two levels of the packed filter, for the 256 groups from group pair pb0 on: the super-groups' bounds
-// (TPT_SUPER = 8 consecutive groups each; 16 pair records, wave-uniform scalar loads) first, then per lane the 8 groups (4 pair
-// records at gpairsLane: LDS in the path-queue kernel) of every super-group this lane's ray touches.  Super-group k of the block
-// holds groups pb0 * 2 + 8 k + j: candidate word k / 8, bit 63 - (8 (k % 8) + j).  gpairsLane must be padded to whole super-groups
-// with never-a-candidate records.
-template <bool HALF = false>
-__device__ __forceinline__ void groupMasksTwoLevel(const SceneView& sv, const float* gpairsLane, int pb0, bool go, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f dz,
-                                                   uint64_t& cm0, uint64_t& cm1, uint64_t& cm2, uint64_t& cm3)
-{
-    const int sp0 = pb0 / TPT_SUPER, leftS = sv.nSuperPairs - sp0; // (a super pair = 2 x TPT_SUPER groups = TPT_SUPER group pairs)
-    uint32_t sm = (uint32_t)(phase1ChunkT<HALF>(pairPtr(sv.spairs + (size_t)sp0 * 8), leftS < 16 ? leftS : 16, ox, oy, oz, dx, dy, dz) >> 32);
-    if (!go) sm = 0u;
-    while (sm) {
-        const int k = __builtin_clz(sm);
-        sm &= ~(0x80000000u >> k);
-        const float* rec = gpairsLane + (size_t)(pb0 + (TPT_SUPER / 2) * k) * 8;
-        uint32_t m = 0;
-#pragma unroll
-        for (int q = 0; q < TPT_SUPER / 2; ++q) phase1PairLaneT<HALF>(rec + q * 8, ox, oy, oz, dx, dy, dz, m);
-        const uint64_t bits = (uint64_t)(~m & 0xffu) << (56 - 8 * (k & 7));
-        const int w = k >> 3;
-        cm0 |= w == 0 ? bits : 0ull;
-        cm1 |= w == 1 ? bits : 0ull;
-        cm2 |= w == 2 ? bits : 0ull;
-        cm3 |= w == 3 ? bits : 0ull;
-    }
 }
 // profiling build (-DTPT_STATS=2): s_memtime ticks of the dealing's stages, summed by lane 0 of every wave into g_tptStats[90..99]
 // ([90] big spheres [91] super-groups' bounds, wave-wide [92] groups' bounds per lane + list entries [93] member filter (list, parked
@@ -968,7 +941,7 @@ __device__ __forceinline__ void dealThreeStage(const SceneView& sv, const float*
                     uint32_t m = 0;
 #pragma unroll
                     for (int q = 0; q < TPT_SUPER / 2; ++q) phase1PairLaneT<TPT_DEAL_HALF_LINE != 0>(rec + q * 8, qx, qy, qz, ex, ey, ez, m);
-                    c8 = ~m & 0xffu; // bit 7 = the super-group's first group
+                    c8 = ~m & ((1u << TPT_SUPER) - 1u); // bit TPT_SUPER - 1 = the super-group's first group
 #if defined(TPT_STATS) && TPT_STATS >= 2
                     // profiling build: how many of these candidates lie wholly BEHIND the ray's origin (centre behind: nb < 0; origin
                     // outside the bound by a margin: e' > 2^-11 R'^2) -- what a half-line test on top of the line test would take away
@@ -984,7 +957,7 @@ __device__ __forceinline__ void dealThreeStage(const SceneView& sv, const float*
                         statSgBehind = behind(sp[0], sp[2], sp[4], sp[6]) ? 1u : 0u;
                         for (int q = 0; q < TPT_SUPER / 2; ++q)
                             for (int h = 0; h < 2; ++h)
-                                if (((c8 >> (7 - (2 * q + h))) & 1u) && behind(rec[q * 8 + h], rec[q * 8 + 2 + h], rec[q * 8 + 4 + h], rec[q * 8 + 6 + h])) statGBehind++;
+                                if (((c8 >> (TPT_SUPER - 1 - (2 * q + h))) & 1u) && behind(rec[q * 8 + h], rec[q * 8 + 2 + h], rec[q * 8 + 4 + h], rec[q * 8 + 6 + h])) statGBehind++;
                     }
 #endif
                 }
@@ -1005,7 +978,7 @@ __device__ __forceinline__ void dealThreeStage(const SceneView& sv, const float*
                     TPT_DEAL_TRIP(102);
                     const int b = __builtin_ctz(c8);
                     c8 &= c8 - 1u;
-                    const int g = sg * TPT_SUPER + 7 - b;
+                    const int g = sg * TPT_SUPER + (TPT_SUPER - 1) - b;
                     if (pos < capB)
                         B[pos] = ((unsigned)po << 16) | (unsigned)g;
                     else
@@ -1253,7 +1226,7 @@ __device__ __forceinline__ void traceQueueBody(const KernelArgs& a)
     // (a.ldsGroupPairs: > 0 records staged in LDS, 0 read from global memory, < 0 flat filter)
     float* ldsGpairs = reinterpret_cast<float*>(smem + ((off + 15) & ~15));
     if (!LDS_SCENE && a.ldsGroupPairs > 0) // (the host pads to whole super-groups; in LDS each super-group's 32 floats sit at a stride of TPT_GPAIR_LDS_STRIDE)
-        for (int i = tid; i < a.ldsGroupPairs * 8; i += TPT_Q_T) ldsGpairs[(i >> 5) * TPT_GPAIR_LDS_STRIDE + (i & 31)] = a.scene.gpairs[i];
+        for (int i = tid; i < a.ldsGroupPairs * 8; i += TPT_Q_T) ldsGpairs[(i / TPT_GPAIR_FLOATS) * TPT_GPAIR_LDS_STRIDE + (i % TPT_GPAIR_FLOATS)] = a.scene.gpairs[i];
 #if TPT_MATRIX_FILTER
     if (useMatrix)
         for (int i = tid; i < TPT_MXH_TABLE_DWORDS; i += TPT_Q_T) ldsA[i] = a.scene.amatH[i];
@@ -1823,21 +1796,27 @@ __global__ void __launch_bounds__(64) tptGroupFilterTestKernel(const KernelArgs 
         const v2f ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
         const float gx = d.x * TPT_PG_K, gy = d.y * TPT_PG_K, gz = d.z * TPT_PG_K;
         const v2f dx = {gx, gx}, dy = {gy, gy}, dz = {gz, gz};
-        for (int pb0 = 0; pb0 < sv.nGroupPairs; pb0 += 128) {
-            uint64_t cm[4] = {0, 0, 0, 0}, ch[4] = {0, 0, 0, 0};
-            groupMasksTwoLevel<false>(sv, sv.gpairs, pb0, real, ox, oy, oz, dx, dy, dz, cm[0], cm[1], cm[2], cm[3]);
-            // the half-line form the three-stage dealing uses: held against the reference's WHOLE acceptance (Maths.cpp:171-190: a
-            // positive discriminant and a root beyond tMin), and it must be a subset of the line form
-            groupMasksTwoLevel<true>(sv, sv.gpairs, pb0, real, ox, oy, oz, dx, dy, dz, ch[0], ch[1], ch[2], ch[3]);
-            if (!real) continue;
-            for (int w = 0; w < 4; ++w) {
-                kept += (unsigned long long)__popcll(cm[w]);
-                keptHalf += (unsigned long long)__popcll(ch[w]);
-                if (ch[w] & ~cm[w]) ++bad;
-                for (int q = 0; q < 64; ++q) {
-                    const int grp = pb0 * 2 + w * 64 + q;
-                    if (grp >= sv.nGroups) break;
-                    const bool keptBit = (cm[w] >> (63 - q)) & 1ull, keptHalfBit = (ch[w] >> (63 - q)) & 1ull;
+        // per lane, super-group by super-group: the super-group's own bound, then its groups' -- in the line form and in the half-line
+        // form the three-stage dealing uses, the latter held against the reference's WHOLE acceptance (Maths.cpp:171-190: a positive
+        // discriminant and a root beyond tMin); it must be a subset of the line form
+        const int nSupers = (sv.nGroups + TPT_SUPER - 1) / TPT_SUPER;
+        for (int sg = 0; sg < nSupers && real; ++sg) {
+            uint32_t sl = 0, sh = 0;
+            phase1PairLaneT<false>(sv.spairs + (size_t)(sg >> 1) * 8, ox, oy, oz, dx, dy, dz, sl);
+            phase1PairLaneT<true>(sv.spairs + (size_t)(sg >> 1) * 8, ox, oy, oz, dx, dy, dz, sh);
+            const bool sgLine = !((sl >> (1 - (sg & 1))) & 1u), sgHalf = !((sh >> (1 - (sg & 1))) & 1u);
+            for (int q = 0; q < TPT_SUPER / 2; ++q) {
+                const float* rec = sv.gpairs + ((size_t)sg * (TPT_SUPER / 2) + q) * 8;
+                uint32_t gl = 0, gh = 0;
+                phase1PairLaneT<false>(rec, ox, oy, oz, dx, dy, dz, gl);
+                phase1PairLaneT<true>(rec, ox, oy, oz, dx, dy, dz, gh);
+                for (int hIdx = 0; hIdx < 2; ++hIdx) {
+                    const int grp = sg * TPT_SUPER + q * 2 + hIdx;
+                    if (grp >= sv.nGroups) continue;
+                    const bool keptBit = sgLine && !((gl >> (1 - hIdx)) & 1u), keptHalfBit = sgHalf && !((gh >> (1 - hIdx)) & 1u);
+                    kept += keptBit;
+                    keptHalf += keptHalfBit;
+                    if (keptHalfBit && !keptBit) ++bad;
                     const f4* mem = sv.gsph + (size_t)grp * TPT_GROUP;
                     for (int j = 0; j < TPT_GROUP; ++j) {
                         const f4 s = mem[j];

@@ -93,7 +93,10 @@ enum { SCENE_LIGHT_R2_DIV_SAFE = 1 }; // every light's radius^2 lies in [2^-60, 
                        to visit -- 4096-sphere scene: 7.9 / 7.7 / 7.8 / 7.8 / 7.05 / 3.6 Gray/s at 4 / 6 / 8 / 12 / 16 / 32 (profiles/r04/r04_run15-16.log) */
 #endif
 #define TPT_GROUP_MIN_SPHERES 256
-#define TPT_SUPER 8 /* groups per super-group (one 64-bit candidate word holds 8 super-groups' groups) */
+#ifndef TPT_SUPER
+#define TPT_SUPER 8 /* groups per super-group: 8 or 16 (host packing and kernels alike; the three-stage dealing keeps one candidate bit per group of a super-group in a 32-bit word) */
+#endif
+static_assert(TPT_SUPER == 8 || TPT_SUPER == 16, "super-groups of 8 or 16 groups");
 
 struct FrameConsts {
     CameraPOD cam;

@@ -566,6 +566,9 @@ extern "C" {
 int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, unsigned testFlags)
 {
     (void)time; // stored but never read by the reference either (Test.cpp:257,347)
+    // (a host that mixes sharded and plain frames on one context: sharded frames accepted earlier go out first, in call order.  The
+    //  sharded path itself comes through here with nothing pending.)
+    if (int rc_ = flushShardDeferred()) return rc_;
     if (requireInit()) return -1;
     if (!g.updated) return fail("tptDrawDevice: call tptUpdate (UpdateTest) first");
     if (!deviceTile || w <= 0 || h <= 0) return fail("tptDrawDevice: bad arguments");
@@ -662,6 +665,7 @@ int tptDrawDevice(float time, int frameCount, int w, int h, float* deviceTile, u
 int tptDrawDeviceBatch(float time, int firstFrame, int nFrames, int w, int h, float* deviceTile, unsigned testFlags)
 {
     (void)time;
+    if (int rc_ = flushShardDeferred()) return rc_; // (see tptDrawDevice)
     if (requireInit()) return -1;
     if (!g.updated) return fail("tptDrawDeviceBatch: call tptUpdate (UpdateTest) first");
     if (!deviceTile || w <= 0 || h <= 0 || nFrames < 1) return fail("tptDrawDeviceBatch: bad arguments");

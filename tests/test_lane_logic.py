@@ -362,6 +362,53 @@ def test_half_line_bounds_filter_keeps_every_group_with_an_accepted_member(emu, 
     assert adv[3] > 3000 and adv[0] == 0 and adv[4] == 0, adv
 
 
+def test_half_line_bounds_filter_with_loose_bounds_and_far_origins(emu):
+    """The half-line rule's margin is priced with rho = (member's distance from the bound's centre) / (its radius) at the limit the
+    grouping accepts, 64, and with the reference's own rounding slack, which grows with the squared distance to the ray's origin.  A scene
+    made for both: 2025 spheres of radius 0.02-0.03 half a unit apart (rho 40-60: still grouped), rays that graze them from 1 ... 1000
+    units away -- and the same rays reversed, every sphere behind the origin."""
+    import ctypes as C
+    from toypathtracer_amd.api import MATERIAL_DT, SPHERE_DT
+    rng = np.random.default_rng(5)
+    g = 45
+    n = g * g
+    s = np.zeros(n, SPHERE_DT)
+    m = np.zeros(n, MATERIAL_DT)
+    ix, iz = np.meshgrid(np.arange(g), np.arange(g))
+    s["cx"] = ((ix.ravel() - g / 2) * 0.5 + rng.uniform(-0.05, 0.05, n)).astype(np.float32)
+    s["cz"] = ((iz.ravel() - g / 2) * 0.5 + rng.uniform(-0.05, 0.05, n)).astype(np.float32)
+    s["cy"] = rng.uniform(0, 0.3, n).astype(np.float32)
+    s["radius"] = (0.02 * rng.uniform(1, 1.5, n)).astype(np.float32)
+    s["invRadius"] = np.float32(1) / s["radius"]
+    m["albedo"] = 0.5
+    info = (C.c_int * 3)()
+    emu.emu_group_info.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    emu.emu_group_info(s.ctypes.data, m.ctypes.data, n, C.addressof(info))
+    assert info[0] > 200 and info[2] == 0, list(info)  # grouped, no group dissolved
+    k = 4000
+    idx = rng.integers(0, n, k)
+    c = np.stack([s["cx"][idx], s["cy"][idx], s["cz"][idx]], 1).astype(np.float64)
+    dirs = rng.normal(size=(k, 3))
+    dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+    perp = rng.normal(size=(k, 3))
+    perp -= (perp * dirs).sum(1, keepdims=True) * dirs
+    perp /= np.linalg.norm(perp, axis=1, keepdims=True)
+    o = c - dirs * (10.0 ** rng.uniform(0, 3, k))[:, None] + perp * (s["radius"][idx].astype(np.float64) * rng.uniform(0.0, 1.5, k))[:, None]
+    rays = np.concatenate([o, dirs], 1).astype(np.float32)
+    rays[:, 3:] /= np.linalg.norm(rays[:, 3:], axis=1, keepdims=True)
+    back = rays.copy()
+    back[:, 3:] *= -1
+    rays = np.concatenate([rays, back], 0)
+    out = np.zeros(5, np.int64)
+    emu.emu_group_half_check.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    emu.emu_group_half_check(s.ctypes.data, m.ctypes.data, n, rays.ctypes.data, len(rays), out.ctypes.data)
+    assert out[3] > 1000 and out[0] == 0 and out[4] == 0 and out[1] < 0.7 * out[2], out
+    adv = np.zeros(5, np.int64)
+    emu.emu_group_half_adversarial.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint, C.c_int, C.c_void_p]
+    emu.emu_group_half_adversarial(s.ctypes.data, m.ctypes.data, n, 12345, 10, adv.ctypes.data)
+    assert adv[3] > 100 and adv[0] == 0 and adv[4] == 0, adv
+
+
 def _queue_frames(emu, s, m, cam, w, h, spp, frames, flags, hs):
     import ctypes as C
     fn = emu.emu_render_queue_classes

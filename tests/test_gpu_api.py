@@ -35,6 +35,31 @@ def test_draw_before_update_and_bad_args_fail_cleanly(tpt_defaults):
         tpt.draw_device(0.0, 0, 64, 64, 0, FLAG_PROGRESSIVE)
 
 
+def test_error_handler_takes_a_failure_of_the_void_api(tpt_defaults):
+    """The reference's DrawTest (Test.h:14) returns void: by default a failure prints and abort()s; with tptSetErrorHandler installed the
+    handler gets (entry point, message) and the call returns without effect -- through the very C++ symbol a relinked host calls."""
+    import ctypes as C
+    import numpy as np
+    tpt = tpt_defaults
+    seen = []
+    tpt.set_error_handler(lambda where, msg: seen.append((where, msg)))
+    try:
+        lib = tpt.load_library()
+        fn = getattr(lib, "_Z8DrawTestfiiiPfRij")
+        fn.restype = None
+        fn.argtypes = [C.c_float, C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_int), C.c_uint]
+        rays = C.c_int(123)
+        buf = np.full((8, 8, 4), 0.25, np.float32)
+        fn(0.0, 0, 8, 8, None, C.byref(rays), FLAG_PROGRESSIVE)  # a null backbuffer: tptDraw refuses it
+        assert len(seen) == 1 and seen[0][0] == b"DrawTest" and seen[0][1], seen
+        assert rays.value == 0 and (buf == 0.25).all()
+        tpt.UpdateTest(0.0, 0, 8, 8, FLAG_PROGRESSIVE)
+        fn(0.0, 0, 8, 8, buf.ctypes.data, C.byref(rays), FLAG_PROGRESSIVE)  # ... and a good call still renders
+        assert len(seen) == 1 and rays.value > 64
+    finally:
+        tpt.set_error_handler(None)
+
+
 def test_scene_desc_round_trip(tpt_defaults, oracle):
     tpt = tpt_defaults
     tpt.UpdateTest(0.0, 0, 640, 360, FLAG_PROGRESSIVE)

@@ -878,6 +878,8 @@ __device__ __forceinline__ void dealMemberPass(const SceneView& sv, LdsList B, u
 //   C  a member pass (dealMemberPass): 8 member filters per entry, survivors pushed on the stack S; whenever 64 are waiting: an exact pass.
 // What is left on B and S when the last chunk is through is drained by one partial pass each.  Order is irrelevant: hits merge into the
 // owners' keys with ds_min_u64 on (t bits, original index).  An entry that finds its stack full is served in place by the lane holding it.
+// Both bounds levels test the HALF-line (TPT_DEAL_HALF_LINE; tpt_trace.h phase1PairT<true>): a bound whose centre lies behind the ray's
+// origin, the origin outside it by a margin, holds nothing the reference could accept -- a quarter of what the line test kept.
 template <int PATHS>
 __device__ __forceinline__ void dealThreeStage(const SceneView& sv, const float* gpairsLane, int recStride, bool go, f3 o, f3 d, v2f ox, v2f oy, v2f oz, v2f dx, v2f dy, v2f dz,
                                                LdsList list, unsigned* cnt, f4* st, int p, int lane, float hitT, int id, bool& parked)
